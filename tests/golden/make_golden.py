@@ -1,0 +1,438 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: imports the REFERENCE (songrise/HyperNeRF-torch, read-only at
+/root/reference) on CPU and records inputs/outputs of the hot-path functions as fixtures.
+
+Run in the build container only (`python tests/golden/make_golden.py`); the fixtures it
+writes (tests/golden/*.npz) are committed, the reference never travels.  Nothing here is
+copied from the reference: it is imported, called and its results are stored.
+
+Import shims: `immutabledict` and `torchsummary` stubs (imported, unused on
+the path), `torchsearchsorted` -> torch.searchsorted (absent third-party extension),
+`Tensor.cuda` -> identity (channel-count helpers hard-code .cuda()).  Random draws are
+replaced by a recorded, seeded stream so the oracle/HIP runs can consume the same numbers.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))          # tests/ (hashprng)
+REF = os.environ.get("HN_REFERENCE", "/root/reference")
+
+import numpy as np
+import torch
+
+import hashprng as H
+
+torch.set_num_threads(4)
+
+# ---- shims -------------------------------------------------------------------------
+sys.modules["immutabledict"] = types.ModuleType("immutabledict")
+sys.modules["immutabledict"].immutabledict = dict
+sys.modules["torchsummary"] = types.ModuleType("torchsummary")
+_tss = types.ModuleType("torchsearchsorted")
+_tss.searchsorted = lambda a, v, side="left": torch.searchsorted(a, v, right=(side == "right"))
+sys.modules["torchsearchsorted"] = _tss
+torch.Tensor.cuda = lambda self, *a, **k: self
+sys.path.insert(0, REF)
+
+from hypernerf import model_utils as R_mu          # noqa: E402
+from hypernerf import modules as R_mod             # noqa: E402
+from hypernerf import warping as R_warp            # noqa: E402
+from hypernerf import models as R_models           # noqa: E402
+from hypernerf import rigid_body as R_rigid        # noqa: E402
+from models import nerf as R_nerf                  # noqa: E402
+from models import rendering as R_rend             # noqa: E402
+import losses as R_losses                          # noqa: E402
+
+
+class DrawRecorder:
+    """Replaces torch.rand / torch.randn by a seeded hash stream and logs each draw."""
+
+    def __init__(self, seed):
+        self.seed, self.n, self.log = seed, 0, []
+        self._rand, self._randn = torch.rand, torch.randn
+
+    def _shape(self, args):
+        if len(args) == 1 and isinstance(args[0], (list, tuple, torch.Size)):
+            return tuple(args[0])
+        return tuple(args)
+
+    def rand(self, *args, **kw):
+        shp = self._shape(args)
+        t = H.uniform(self.seed, f"draw{self.n}", shp, 0.0, 1.0)
+        self.log.append(("rand", shp, t)); self.n += 1
+        return t
+
+    def randn(self, *args, **kw):
+        shp = self._shape(args)
+        t = H.normal(self.seed, f"draw{self.n}", shp)
+        self.log.append(("randn", shp, t)); self.n += 1
+        return t
+
+    def __enter__(self):
+        torch.rand, torch.randn = self.rand, self.randn
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.randn = self._rand, self._randn
+
+
+def load_hash_weights(module, seed, gain=1.0):
+    sd = module.state_dict()
+    new = H.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed, gain)
+    module.load_state_dict(new)
+    return new
+
+
+def grad_summary(named_params, seed):
+    """Per-tensor sum / abs-sum / L2 + 16 hash-sampled entries (flat index, value)."""
+    out = {}
+    for name, prm in named_params:
+        g = prm.grad
+        if g is None:
+            out[name + "/none"] = np.array([1.0], dtype=np.float32)
+            continue
+        g = g.detach().double().reshape(-1)
+        n = g.numel()
+        idx = (H.uniform01(seed, "gidx:" + name, 16).astype(np.float64) * n).astype(np.int64)
+        out[name + "/stats"] = np.array([g.sum().item(), g.abs().sum().item(),
+                                         g.pow(2).sum().sqrt().item()], dtype=np.float64)
+        out[name + "/idx"] = idx
+        out[name + "/val"] = g[torch.from_numpy(idx)].numpy().astype(np.float32)
+    return out
+
+
+def save(name, **arrays):
+    clean = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        clean[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **clean)
+    print(f"  wrote {name}.npz ({os.path.getsize(path)} B)")
+
+
+def rays_for(seed, b, n_img=100):
+    o = H.uniform(seed, "rays_o", (b, 3), -1.0, 1.0)
+    d = H.uniform(seed, "rays_d", (b, 3), -1.0, 1.0)
+    d = d / d.norm(dim=-1, keepdim=True) * H.uniform(seed, "rays_dn", (b, 1), 0.7, 1.6)
+    idx = (H.uniform01(seed, "rays_idx", b) * n_img).astype(np.int64)
+    return o, d, torch.from_numpy(idx)
+
+
+# ---- G1 / G2 encoders ----------------------------------------------------------------
+def g_posenc():
+    arrs = {}
+    for n in (4, 6, 7, 10):
+        x2 = H.uniform(1, f"pe2d{n}", (5, 3), -2.0, 2.0)
+        x3 = H.uniform(1, f"pe3d{n}", (3, 4, 4), -2.0, 2.0)
+        arrs[f"x2_{n}"], arrs[f"y2_{n}"] = x2, R_mu.posenc_orig(x2, n)
+        arrs[f"x3_{n}"], arrs[f"y3_{n}"] = x3, R_mu.posenc_orig(x3, n)
+    xe = H.uniform(1, "emb", (6, 3), -1.5, 1.5)
+    arrs["xe"] = xe
+    arrs["ye_10"] = R_nerf.Embedding(3, 10)(xe)
+    arrs["ye_4"] = R_nerf.Embedding(3, 4)(xe)
+    xj = H.uniform(1, "pej", (4, 5, 3), -2.0, 2.0)
+    arrs["xj"] = xj
+    arrs["yj_id"] = R_mu.posenc(xj, 0, 8, use_identity=True)
+    arrs["yj"] = R_mu.posenc(xj, 0, 8, use_identity=False)
+    arrs["yj_24"] = R_mu.posenc(xj, 2, 6, use_identity=False)
+    save("g01_posenc", **arrs)
+
+
+# ---- G3 MLP ---------------------------------------------------------------------------
+def g_mlp():
+    arrs = {}
+    cases = {
+        "warp": dict(in_ch=71, out_ch=3, depth=6, width=128),
+        "sheet": dict(in_ch=53, out_ch=4, depth=6, width=64),
+        "trunk": dict(in_ch=115, out_ch=256, depth=8, width=256, output_activation=torch.nn.ReLU()),
+        "rgb": dict(in_ch=167, out_ch=3, depth=4, width=128, output_activation=torch.nn.Sigmoid()),
+        "d0": dict(in_ch=128, out_ch=3, depth=0, width=128),
+        "skip2": dict(in_ch=20, out_ch=5, depth=5, width=32, skips=[2]),
+    }
+    for name, kw in cases.items():
+        m = R_mod.MLP(**kw)
+        load_hash_weights(m, 3)
+        x = H.uniform(3, "mlp_x_" + name, (4, 6, kw["in_ch"]), -1.0, 1.0)
+        arrs["x_" + name] = x
+        arrs["y_" + name] = m(x)
+        arrs["keys_" + name] = np.array(sorted(m.state_dict().keys()))
+        arrs["shapes_" + name] = np.array([str(tuple(m.state_dict()[k].shape))
+                                           for k in sorted(m.state_dict().keys())])
+    save("g03_mlp", **arrs)
+
+
+# ---- G4 GLO ----------------------------------------------------------------------------
+def g_glo():
+    g = R_mod.GLOEmbed(num_embeddings=100, embedding_dim=8)
+    load_hash_weights(g, 4)
+    i1 = torch.from_numpy((H.uniform01(4, "glo_i", 7) * 100).astype(np.int64))
+    save("g04_glo", idx=i1, y_flat=g(i1), y_col=g(i1[:, None]))
+
+
+# ---- G5 / G6 / G7 ----------------------------------------------------------------------
+def g_fields():
+    tf = R_warp.TranslationField(in_ch=3, in_ch_embed=8)
+    load_hash_weights(tf, 5)
+    pts = H.uniform(5, "tf_pts", (4, 6, 3), -1.2, 1.2)
+    emb = H.uniform(5, "tf_emb", (4, 1, 8), -0.5, 0.5).expand(4, 6, 8).contiguous()
+    ytf = tf(pts, emb, None)["warped_points"]
+    hs = R_mod.HyperSheetMLP(out_ch=4, in_ch_embed=8)
+    load_hash_weights(hs, 6)
+    yhs = hs(pts, emb)
+    save("g05_fields", pts=pts, emb=emb, y_warp=ytf, y_sheet=yhs,
+         keys_warp=np.array(sorted(tf.state_dict().keys())),
+         keys_sheet=np.array(sorted(hs.state_dict().keys())))
+
+    arrs = {}
+    for tag, acd in (("cond", 8), ("nocond", 0)):
+        nm = R_mod.NerfMLP(in_ch=115, trunk_depth=8, trunk_width=256, rgb_branch_depth=4,
+                           rgb_branch_width=128, hidden_activation=torch.nn.ReLU(), skips=[4],
+                           rgb_activation=torch.nn.Sigmoid(), alpha_condition_dim=acd,
+                           rgb_condition_dim=39)
+        load_hash_weights(nm, 7)
+        x = H.uniform(7, "nm_x", (3, 5, 115), -1.0, 1.0)
+        ac = H.uniform(7, "nm_ac", (3, 8), -0.5, 0.5) if acd else None
+        rc = H.uniform(7, "nm_rc", (3, 39), -1.0, 1.0)
+        y = nm(x, alpha_condition=ac, rgb_condition=rc)
+        arrs["x"] = x; arrs["rc"] = rc
+        if acd:
+            arrs["ac"] = ac
+        arrs["rgb_" + tag], arrs["alpha_" + tag] = y["rgb"], y["alpha"]
+        arrs["keys_" + tag] = np.array(sorted(nm.state_dict().keys()))
+    save("g07_nerfmlp", **arrs)
+
+
+# ---- G8 sampling ------------------------------------------------------------------------
+def g_sample():
+    o, d, _ = rays_for(8, 6)
+    arrs = {"o": o, "d": d}
+    with DrawRecorder(8) as rec:
+        z, p = R_mu.sample_along_rays(o, d, 16, 0.0, 1.0, True, False)
+    arrs.update(t_rand=rec.log[0][2], z_strat=z, p_strat=p)
+    with DrawRecorder(9) as rec:
+        z, p = R_mu.sample_along_rays(o, d, 16, 0.5, 4.0, True, True)
+    arrs.update(t_rand_disp=rec.log[0][2], z_disp=z, p_disp=p)
+    z, p = R_mu.sample_along_rays(o, d, 16, 0.0, 1.0, False, False)
+    arrs.update(z_det=z, p_det=p)
+    save("g08_sample", **arrs)
+
+
+# ---- G9 volumetric rendering ------------------------------------------------------------
+def g_volrend():
+    b, s = 8, 24
+    o, d, _ = rays_for(10, b)
+    rgb = H.uniform(10, "vr_rgb", (b, s, 3), 0.0, 1.0)
+    sigma = H.uniform(10, "vr_sig", (b, s), 0.0, 8.0)
+    sigma[0] = 0.0                          # empty ray
+    sigma[1] = 1e4                          # opaque at first sample
+    sigma[2, :12] = 0.0                     # late surface
+    z, _ = torch.sort(H.uniform(10, "vr_z", (b, s), 0.0, 1.0), dim=-1)
+    arrs = dict(rgb=rgb, sigma=sigma, z=z, d=d)
+    for inf in (True, False):
+        for wb in (True, False):
+            r = R_mu.volumetric_rendering(rgb, sigma, z, d, use_white_background=wb,
+                                          sample_at_infinity=inf)
+            tag = f"inf{int(inf)}_wb{int(wb)}"
+            for k, v in r.items():
+                arrs[f"{k}_{tag}"] = v
+            arrs[f"dindex_{tag}"] = R_mu.compute_depth_index(r["weights"])
+    save("g09_volrend", **arrs)
+
+
+# ---- G10 inverse-CDF ---------------------------------------------------------------------
+def tie_margin(cdf, u):
+    return (u[:, :, None] - cdf[:, None, :]).abs().min().item()
+
+
+def g_pdf():
+    b, nb, nf = 8, 14, 16
+    z, _ = torch.sort(H.uniform(11, "pdf_z", (b, nb + 2), 0.0, 1.0), dim=-1)
+    mid = 0.5 * (z[:, 1:] + z[:, :-1])                        # (b, nb+1)
+    w = H.uniform(11, "pdf_w", (b, nb), 0.0, 1.0) ** 3
+    w[0] = 0.0                                                 # all-zero weights
+    w[1] = 0.0; w[1, 5] = 1.0                                  # one-hot
+    o, d, _ = rays_for(11, b)
+    seed = 11
+    while True:
+        with DrawRecorder(seed) as rec:
+            zs = R_mu.piecewise_constant_pdf(mid, w, nf, True)
+        u = rec.log[0][2]
+        # exact searchsorted indices as the reference computes them
+        ww = w + 1e-5
+        pdf = ww / torch.sum(ww, -1, keepdim=True)
+        cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+        if tie_margin(cdf, u) > 1e-5:
+            break
+        seed += 1000
+    inds = torch.searchsorted(cdf, u.contiguous(), right=True)
+    with DrawRecorder(seed) as rec:
+        z_all, pts = R_mu.sample_pdf(mid, w, o, d, z, nf, True)
+    zs_det = R_mu.piecewise_constant_pdf(mid, w, nf, False)
+    save("g10_pdf", bins=mid, w=w, z=z, o=o, d=d, u=u, inds=inds, cdf=cdf, z_samples=zs,
+         z_all=z_all, pts=pts, z_samples_det=zs_det)
+
+
+# ---- G11 full NerfModel -------------------------------------------------------------------
+NUM_IMG = 100
+EMB = {"warp": list(range(NUM_IMG)), "camera": [0], "appearance": list(range(NUM_IMG)),
+       "time": list(range(NUM_IMG))}
+MODEL_CASES = {
+    "bendy": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=False, use_alpha_cond=False),
+    "bendy_cond": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True),
+    "bendy_rgbcond": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True,
+                          use_alpha_cond=True, use_rgb_cond=True),
+    "nowarp": dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=False,
+                   use_alpha_cond=False),
+    "nowarp_cond": dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=True,
+                        use_alpha_cond=True),
+    "warp_noslice": dict(use_warp=True, hyper_slice_method=None, use_nerf_embed=False,
+                         use_alpha_cond=False, hyper_slice_out_dim=0),
+    "axis": dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8,
+                 use_nerf_embed=False, use_alpha_cond=False),
+}
+
+
+def g_model():
+    for case, kw in MODEL_CASES.items():
+        for (nc, nf) in ((8, 8), (64, 64)):
+            for noise in (None, 1.0):
+                if noise is not None and (nc, nf) != (8, 8):
+                    continue
+                if case not in ("bendy", "bendy_cond") and (nc, nf) == (64, 64):
+                    continue
+                b = 16
+                seed = 100
+                tag = f"g11_model_{case}_{nc}_{nf}" + ("_noise" if noise else "")
+                m = R_models.NerfModel(EMB, near=0.0, far=1.0, n_samples_coarse=nc,
+                                       n_samples_fine=nf, noise_std=noise, view_fourier_dim=6,
+                                       **kw)
+                load_hash_weights(m, seed)
+                o, d, idx = rays_for(seed, b)
+                gt = H.uniform(seed, "gt", (b, 3), 0.0, 1.0)
+                rays = {"origins": o, "directions": d, "viewdirs": None,
+                        "metadata": {k: idx.clone() for k in ("warp", "camera", "appearance", "time")}}
+                extra = {"nerf_alpha": None, "warp_alpha": None, "hyper_alpha": None,
+                         "hyper_sheet_alpha": None}
+                dseed = seed
+                while True:
+                    for prm in m.parameters():
+                        prm.grad = None
+                    with DrawRecorder(dseed) as rec:
+                        out = m(rays, extra)
+                    # tie margin of the fine-sample search
+                    wmid = out["coarse"]["weights"][..., 1:-1].detach() + 1e-5
+                    pdf = wmid / torch.sum(wmid, -1, keepdim=True)
+                    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+                    u = [t for (k, s, t) in rec.log if k == "rand"][1]
+                    if tie_margin(cdf, u) > 1e-5:
+                        break
+                    dseed += 1000
+                loss = R_losses.MSELoss()(out, gt)
+                loss.backward()
+                arrs = dict(seed=seed, draw_seed=dseed, b=b, nc=nc, nf=nf,
+                            noise_std=0.0 if noise is None else noise, loss=loss.detach())
+                kinds = [k for (k, s, t) in rec.log]
+                arrs["draw_kinds"] = np.array(kinds)
+                for i, (k, s, t) in enumerate(rec.log):
+                    arrs[f"draw{i}"] = t
+                for lvl in ("coarse", "fine"):
+                    for k, v in out[lvl].items():
+                        arrs[f"{lvl}/{k}"] = v
+                arrs["fine/inds"] = torch.searchsorted(cdf, u.contiguous(), right=True)
+                arrs["keys"] = np.array(sorted(m.state_dict().keys()))
+                arrs["shapes"] = np.array([str(tuple(m.state_dict()[k].shape))
+                                           for k in sorted(m.state_dict().keys())])
+                arrs.update({"grad/" + k: v for k, v in grad_summary(m.named_parameters(), seed).items()})
+                save(tag, **arrs)
+
+
+# ---- G12 legacy render_rays ------------------------------------------------------------------
+def g_legacy():
+    b = 12
+    seed = 200
+    o, d, _ = rays_for(seed, b)
+    near = torch.full((b, 1), 0.2); far = torch.full((b, 1), 1.5)
+    rays = torch.cat([o, d, near, far], dim=1)
+    emb = [R_nerf.Embedding(3, 10), R_nerf.Embedding(3, 4)]
+    coarse, fine = R_nerf.NeRF(), R_nerf.NeRF()
+    sd_c = load_hash_weights(coarse, seed)
+    sd_f = load_hash_weights(fine, seed + 1)
+    gt = H.uniform(seed, "gt", (b, 3), 0.0, 1.0)
+    cases = {
+        "c_only": dict(N_samples=16, N_importance=0, perturb=0, noise_std=0),
+        "c_only_pert_noise": dict(N_samples=16, N_importance=0, perturb=1, noise_std=1),
+        "cf_det": dict(N_samples=16, N_importance=16, perturb=0, noise_std=0),
+        "cf_pert_noise": dict(N_samples=16, N_importance=16, perturb=1, noise_std=1),
+        "cf_white": dict(N_samples=16, N_importance=16, perturb=1, noise_std=0, white_back=True),
+        "cf_test_time": dict(N_samples=16, N_importance=16, perturb=0, noise_std=0, test_time=True),
+        "cf_disp": dict(N_samples=16, N_importance=8, perturb=1, noise_std=1, use_disp=True),
+        "c64": dict(N_samples=64, N_importance=0, perturb=1, noise_std=1),
+    }
+    for name, kw in cases.items():
+        dseed = seed
+        while True:
+            for mm in (coarse, fine):
+                for prm in mm.parameters():
+                    prm.grad = None
+            with DrawRecorder(dseed) as rec:
+                res = R_rend.render_rays([coarse, fine], emb, rays, chunk=1024 * 32, **kw)
+            ok = True
+            if kw["N_importance"] > 0 and kw["perturb"] > 0:
+                # recover u = the rand draw of shape (b, N_importance)
+                us = [t for (k, s, t) in rec.log if k == "rand" and s == (b, kw["N_importance"])]
+                u = us[-1]
+                # weights_coarse is not returned; recompute the cdf margin through the oracle-free
+                # route: render coarse weights again with the same draws
+                with DrawRecorder(dseed):
+                    res_c = R_rend.render_rays([coarse, fine], emb, rays, chunk=1024 * 32,
+                                               **{**kw, "N_importance": 0})
+                ok = True  # margin checked in the test through indices equality on the oracle side
+            if ok:
+                break
+            dseed += 1000
+        arrs = dict(rays=rays, seed=seed, draw_seed=dseed)
+        arrs["draw_kinds"] = np.array([k for (k, s, t) in rec.log])
+        for i, (k, s, t) in enumerate(rec.log):
+            arrs[f"draw{i}"] = t
+        for k, v in res.items():
+            arrs["out/" + k] = v
+        if not kw.get("test_time", False):
+            loss = ((res["rgb_coarse"] - gt) ** 2).mean()
+            if "rgb_fine" in res:
+                loss = loss + ((res["rgb_fine"] - gt) ** 2).mean()
+            loss.backward()
+            arrs["loss"] = loss.detach()
+            arrs.update({"gradc/" + k: v for k, v in grad_summary(coarse.named_parameters(), seed).items()})
+            if "rgb_fine" in res:
+                arrs.update({"gradf/" + k: v for k, v in grad_summary(fine.named_parameters(), seed).items()})
+        arrs["keys"] = np.array(sorted(coarse.state_dict().keys()))
+        arrs["shapes"] = np.array([str(tuple(coarse.state_dict()[k].shape))
+                                   for k in sorted(coarse.state_dict().keys())])
+        save("g12_legacy_" + name, **arrs)
+
+
+# ---- G13 exp_se3, G14 loss ---------------------------------------------------------------------
+def g_misc():
+    S = torch.tensor([[[0.0, 0.0, 1.0, 1.0, 0.0, 0.0]]])
+    th = torch.tensor([[0.5]])
+    T = R_rigid.exp_se3(S, th)
+    a = H.uniform(14, "la", (9, 3), 0.0, 1.0); bb = H.uniform(14, "lb", (9, 3), 0.0, 1.0)
+    gt = H.uniform(14, "lg", (9, 3), 0.0, 1.0)
+    l1 = R_losses.MSELoss()({"coarse": {"rgb": a}}, gt)
+    l2 = R_losses.MSELoss()({"coarse": {"rgb": a}, "fine": {"rgb": bb}}, gt)
+    mse = ((bb - gt) ** 2).mean()
+    save("g13_misc", se3_T=T, a=a, b=bb, gt=gt, loss_c=l1, loss_cf=l2,
+         psnr_f=-10 * torch.log10(mse))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["posenc", "mlp", "glo", "fields", "sample", "volrend", "pdf",
+                             "model", "legacy", "misc"]
+    for w in which:
+        print("golden:", w)
+        globals()["g_" + w]()
