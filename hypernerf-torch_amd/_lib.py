@@ -1,0 +1,162 @@
+"""ctypes binding of the C-ABI shared library (include/hn_kernels.h).
+
+The product path has NO CPU fallback: if the library is missing, or a tensor is not on a
+ROCm device, the ops raise.  `load()` is lazy so that module construction, state_dict
+handling and program building work on a machine without a GPU (tests -m "not gpu").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libhn_hip.so")
+SOURCES = ["hn_mlp.hip", "hn_render.hip"]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "hn_kernels.h")
+
+HN_MODE_F32, HN_MODE_BF16 = 0, 1
+HN_MAX_SRC, HN_MAX_DST, HN_MAX_SLOTS = 8, 4, 64
+HN_OP_WORDS, HN_CHUNK_UNITS, HN_DSRC_COMPS = 8, 32, 16
+HN_AUXG_MAX = 3
+
+HN_OP_LAYER, HN_OP_OUT, HN_OP_OUT_WIDE = 1, 4, 5
+HN_ACT_NONE, HN_ACT_RELU = 0, 1
+HN_LAYER_NO_COMMIT = 1
+HN_BOP_LOAD, HN_BOP_LOAD_WIDE, HN_BOP_LAYER, HN_BOP_AUX = 1, 2, 3, 4
+HN_FEAT_ZERO, HN_FEAT_ID, HN_FEAT_SIN, HN_FEAT_COS, HN_FEAT_SINP = 0, 1, 2, 3, 4
+
+
+class HnSrc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int32), ("per_ray", C.c_int32)]
+
+
+class HnDst(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int32), ("pad", C.c_int32)]
+
+
+class HnSlot(C.Structure):
+    _fields_ = [("off", C.c_uint64), ("nt", C.c_int32), ("pad", C.c_int32)]
+
+
+class HnMlpArgs(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32), ("n_points", C.c_int32), ("samples_per_ray", C.c_int32), ("training", C.c_int32),
+        ("n_ops", C.c_int32), ("n_chunks", C.c_int32), ("n_dsrc", C.c_int32), ("pad0", C.c_int32),
+        ("ops", C.c_void_p), ("wstream", C.c_void_p), ("bias", C.c_void_p), ("feat", C.c_void_p),
+        ("stash", C.c_void_p), ("masks", C.c_void_p), ("dsrc", C.c_void_p),
+        ("src", HnSrc * HN_MAX_SRC), ("dst", HnDst * HN_MAX_DST), ("slots", HnSlot * HN_MAX_SLOTS),
+    ]
+
+
+class HnCompositeArgs(C.Structure):
+    _fields_ = [
+        ("variant", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("white_bg", C.c_int32),
+        ("sample_at_infinity", C.c_int32), ("warped_ld", C.c_int32), ("pad0", C.c_int32), ("pad1", C.c_int32),
+        ("rgb", C.c_void_p), ("raw", C.c_void_p), ("noise", C.c_void_p), ("z", C.c_void_p), ("dirs", C.c_void_p),
+        ("ray_ld", C.c_int64), ("warped", C.c_void_p),
+        ("out_rgb", C.c_void_p), ("out_depth", C.c_void_p), ("out_acc", C.c_void_p), ("out_weights", C.c_void_p),
+        ("out_med_depth", C.c_void_p), ("out_med_points", C.c_void_p),
+        ("g_rgb", C.c_void_p), ("g_depth", C.c_void_p), ("g_acc", C.c_void_p), ("g_weights", C.c_void_p),
+        ("d_rgb", C.c_void_p), ("d_raw", C.c_void_p),
+    ]
+
+
+# numpy mirrors of the table structs (uploaded to the device as raw bytes)
+PACK_UNIT_DT = np.dtype([("w_id", "<i4"), ("ld", "<i4"), ("r0", "<i4"), ("c0", "<i4"), ("r_end", "<i4"),
+                         ("c_end", "<i4"), ("k0", "<i4"), ("transposed", "<i4")])
+PACK_BIAS_DT = np.dtype([("w_id", "<i4"), ("n", "<i4"), ("off", "<i4"), ("len", "<i4")])
+FEAT_DT = np.dtype([("packed", "<i4"), ("freq", "<f4")])
+DWJOB_DT = np.dtype([("z_off", "<u8"), ("x_off", "<u8"), ("z_nt", "<i4"), ("x_nt", "<i4"), ("z_t0", "<i4"),
+                     ("x_t0", "<i4"), ("n_nt", "<i4"), ("n_kt", "<i4"), ("blk0", "<i4"), ("blk1", "<i4"),
+                     ("w_off", "<i4"), ("ld", "<i4"), ("r0", "<i4"), ("c0", "<i4"), ("r_end", "<i4"),
+                     ("c_end", "<i4"), ("b_off", "<i4"), ("pad", "<i4")])
+
+EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
+           "hn_sample_along_rays", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf",
+           "hn_embed_gather", "hn_embed_backward", "hn_probe_mfma"]
+
+_lib = None
+
+
+class HnError(RuntimeError):
+    pass
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "hn_common.h"), HEADER]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into csrc/libhn_hip.so (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
+           "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise HnError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
+    if verbose:
+        print(res.stdout + res.stderr)
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library (building it first only if hipcc is around and sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HnError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built (run __graft_entry__.build()). "
+            "hypernerf_torch_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise HnError(f"{LIB_PATH} does not export {name}")
+        getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = "argument error" if rc < 0 else "hipError_t"
+        raise HnError(f"{what} failed: {kind} {rc}")
+
+
+def stream_handle() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HnError("hypernerf_torch_amd runs on MI355X only: got a CPU tensor and there is no CPU fallback "
+                          "(the CPU oracle lives in oracle/ and is test infrastructure)")
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def to_device_bytes(arr: np.ndarray, device) -> torch.Tensor:
+    raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+    if raw.size == 0:
+        raw = np.zeros(16, dtype=np.uint8)
+    return torch.from_numpy(raw.copy()).to(device)

@@ -1,0 +1,702 @@
+// MLP machine for gfx950: weight packing, fused forward, fused backward-data, weight gradient.
+// See include/hn_kernels.h for the program format and hn_common.h for the register layouts.
+#include "hn_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// weight stream through LDS (2 x 32 KiB chunks, filled by LDS-DMA, one barrier per chunk)
+// ------------------------------------------------------------------------------------------------
+template <int WAVES>
+struct WStream {
+  const char* g;  // packed units in global memory
+  char* lds;      // 2 * 32 KiB
+  int ctr;        // next unit
+  int nchunks;
+  int wave, lane;
+
+  HN_DEV void issue(int c) {
+    const char* src = g + (size_t)c * (HN_CHUNK_UNITS * 1024);
+    char* dst = lds + (c & 1) * (HN_CHUNK_UNITS * 1024);
+#pragma unroll
+    for (int i = 0; i < HN_CHUNK_UNITS / WAVES; ++i) {
+      const int unit = wave + i * WAVES;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + unit * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*)(dst + unit * 1024), 16, 0, 0);
+    }
+  }
+  HN_DEV void start() {
+    ctr = 0;
+    __syncthreads();  // previous tile's readers are done with both buffers
+    issue(0);
+  }
+  // returns the LDS address of `n` consecutive units (never straddles a chunk; host packs alike)
+  HN_DEV const char* take(int n) {
+    if ((ctr & (HN_CHUNK_UNITS - 1)) + n > HN_CHUNK_UNITS) ctr = (ctr + HN_CHUNK_UNITS - 1) & ~(HN_CHUNK_UNITS - 1);
+    if ((ctr & (HN_CHUNK_UNITS - 1)) == 0) {
+      const int c = ctr / HN_CHUNK_UNITS;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // chunk c landed for every wave; everyone is done with chunk c-1
+      if (c + 1 < nchunks) issue(c + 1);
+    }
+    const char* p = lds + (((ctr / HN_CHUNK_UNITS) & 1) * HN_CHUNK_UNITS + (ctr & (HN_CHUNK_UNITS - 1))) * 1024;
+    ctr += n;
+    return p;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// generated input features
+// ------------------------------------------------------------------------------------------------
+HN_DEV HnSrc hn_src_select(const HnMlpArgs& a, int sid) {
+  HnSrc s = a.src[0];
+  if (sid == 1) s = a.src[1];
+  if (sid == 2) s = a.src[2];
+  if (sid == 3) s = a.src[3];
+  return s;
+}
+
+template <bool BF16>
+HN_DEV float hn_feature(const HnFeat e, const HnMlpArgs& a, int p, int ray) {
+  const int kind = (e.packed >> 12) & 15;
+  if (kind == HN_FEAT_ZERO) return 0.0f;
+  const HnSrc s = hn_src_select(a, (e.packed >> 8) & 15);
+  const float x = s.ptr[(size_t)(s.per_ray ? ray : p) * s.ld + (e.packed & 255)];
+  if (kind == HN_FEAT_ID) return x;
+  float arg = __fmul_rn(e.freq, x);
+  if (kind == HN_FEAT_SINP) arg = __fadd_rn(arg, 0.5f * 3.1415926f);
+  if (BF16) return kind == HN_FEAT_COS ? __cosf(arg) : __sinf(arg);
+  return kind == HN_FEAT_COS ? cosf(arg) : sinf(arg);
+}
+
+// d value / d x  of a generated feature
+template <bool BF16>
+HN_DEV float hn_feature_grad(const HnFeat e, const HnMlpArgs& a, int p, int ray) {
+  const int kind = (e.packed >> 12) & 15;
+  if (kind == HN_FEAT_ID) return 1.0f;
+  const HnSrc s = hn_src_select(a, (e.packed >> 8) & 15);
+  const float x = s.ptr[(size_t)(s.per_ray ? ray : p) * s.ld + (e.packed & 255)];
+  float arg = __fmul_rn(e.freq, x);
+  if (kind == HN_FEAT_SINP) arg = __fadd_rn(arg, 0.5f * 3.1415926f);
+  if (kind == HN_FEAT_COS) return -e.freq * (BF16 ? __sinf(arg) : sinf(arg));
+  return e.freq * (BF16 ? __cosf(arg) : cosf(arg));
+}
+
+// fragments of one group of 64 generated features (invalid points -> zeros)
+HN_DEV void hn_make_group(bf16x8* out, const HnFeat* ft, const HnMlpArgs& a, int p, int ray, bool valid, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = hn_feature<true>(ft[16 * s + hn_pi16(h, j)], a, p, ray);
+      out[s][j] = (__bf16)(valid ? v : 0.0f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+HN_DEV void hn_make_group(float* out, const HnFeat* ft, const HnMlpArgs& a, int p, int ray, bool valid, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const float v = hn_feature<false>(ft[32 * (s >> 4) + hn_rho(s & 15, h)], a, p, ray);
+    out[s] = valid ? v : 0.0f;
+    if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+HN_DEV void hn_init_acc(f32x16& acc, const float* bias, int t, int h) {
+  if (bias != nullptr) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 32 * t + 8 * g + 4 * h);
+      acc[4 * g] = b[0]; acc[4 * g + 1] = b[1]; acc[4 * g + 2] = b[2]; acc[4 * g + 3] = b[3];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  }
+}
+
+// acc += W[tile][32*K32 features] . in   (K32 consecutive blocks of the stream)
+template <bool BF16, int K32>
+HN_DEV void hn_gemm_blocks(f32x16& acc, const typename ModeT<BF16>::Frag* in, WStream<ModeT<BF16>::WAVES>& ws) {
+  using M = ModeT<BF16>;
+  const char* w = ws.take(K32 * M::UNITS32);
+#pragma unroll
+  for (int k = 0; k < K32; ++k) hn_mma_block32(acc, w + k * M::UNITS32 * 1024, in + k * M::STEPS32, ws.lane);
+}
+template <bool BF16>
+HN_DEV void hn_gemm_k(f32x16& acc, const typename ModeT<BF16>::Frag* in, int K32, WStream<ModeT<BF16>::WAVES>& ws) {
+  if (K32 == 8) hn_gemm_blocks<BF16, 8>(acc, in, ws);
+  else if (K32 == 4) hn_gemm_blocks<BF16, 4>(acc, in, ws);
+  else if (K32 == 2) hn_gemm_blocks<BF16, 2>(acc, in, ws);
+  else if (K32 == 1) hn_gemm_blocks<BF16, 1>(acc, in, ws);
+}
+
+template <bool BF16>
+HN_DEV void hn_stash(const typename ModeT<BF16>::Frag* fr, const HnMlpArgs& a, int slot, int blk, int t, int lane) {
+  using M = ModeT<BF16>;
+  const HnSlot sl = a.slots[slot];
+  char* base = reinterpret_cast<char*>(a.stash) + sl.off + ((size_t)blk * sl.nt + t) * (M::TILE_UNITS * 1024);
+  const f32x16 z = hn_transpose_tile(fr, lane);
+  hn_store_tile(z, base, lane, (typename M::Frag*)nullptr);
+}
+
+constexpr int HN_AUXG_MAX = 3;  // generated-feature groups per layer (192 features)
+
+// ------------------------------------------------------------------------------------------------
+// forward machine
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_fwd_kernel(const HnMlpArgs a) {
+  using M = ModeT<BF16>;
+  using Frag = typename M::Frag;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int PTS = M::WAVES * 32;
+  const int ntiles = (a.n_points + PTS - 1) / PTS;
+
+  WStream<M::WAVES> ws;
+  ws.g = reinterpret_cast<const char*>(a.wstream);
+  ws.lds = smem;
+  ws.nchunks = a.n_chunks;
+  ws.wave = wave;
+  ws.lane = lane;
+
+  Frag cur[8 * M::STEPS32];
+  Frag nxt[8 * M::STEPS32];
+  f32x16 accL;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int blk = tile * M::WAVES + wave;  // 32-point block of this wave
+    const int p0 = blk * 32 + r;
+    const bool valid = p0 < a.n_points;
+    const int p = valid ? p0 : a.n_points - 1;
+    const int ray = p / a.samples_per_ray;
+    const bool wave_valid = blk * 32 < a.n_points;  // wave-uniform: the block holds at least one point
+    ws.start();
+
+    for (int op = 0; op < a.n_ops; ++op) {
+      const int* w = a.ops + op * HN_OP_WORDS;
+      const int code = w[0];
+      if (code == HN_OP_LAYER) {
+        const int K32 = w[1] & 255, nG = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
+        const int act = (w[1] >> 24) & 15, flags = (w[1] >> 28) & 15;
+        const float* bias = a.bias + w[2];
+        const bool do_mask = a.training && w[4] >= 0 && wave_valid;
+        const bool do_stash = a.training && w[5] >= 0 && wave_valid;
+        Frag aux[HN_AUXG_MAX * 2 * M::STEPS32];
+#pragma unroll
+        for (int g = 0; g < HN_AUXG_MAX; ++g) {
+          if (g < nG) {
+            hn_make_group(aux + g * 2 * M::STEPS32, a.feat + w[3] + 64 * g, a, p, ray, valid, lane);
+            if (a.training && w[6] >= 0 && wave_valid) {
+              hn_stash<BF16>(aux + g * 2 * M::STEPS32, a, w[6], blk, 2 * g, lane);
+              hn_stash<BF16>(aux + (g * 2 + 1) * M::STEPS32, a, w[6], blk, 2 * g + 1, lane);
+            }
+          }
+        }
+        unsigned bits = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (t < NT) {
+            f32x16 acc;
+            hn_init_acc(acc, bias, t, h);
+            hn_gemm_k<BF16>(acc, cur, K32, ws);
+#pragma unroll
+            for (int g = 0; g < HN_AUXG_MAX; ++g)
+              if (g < nG) hn_gemm_blocks<BF16, 2>(acc, aux + g * 2 * M::STEPS32, ws);
+            accL = acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const bool pos = acc[i] > 0.0f;
+              bits |= (pos ? 1u : 0u) << (16 * (t & 1) + i);
+              float x = acc[i];
+              if (act == HN_ACT_RELU) x = pos ? x : 0.0f;
+              acc[i] = valid ? x : 0.0f;
+            }
+            hn_acc_to_frags(acc, nxt + t * M::STEPS32);
+            if ((t & 1) || t == NT - 1) {
+              if (do_mask) {
+                const HnSlot sl = a.slots[w[4]];
+                uint32_t* mp = a.masks + sl.off / 4 + ((size_t)blk * sl.nt + (t >> 1)) * 64 + lane;
+                __builtin_nontemporal_store(bits, mp);
+              }
+              bits = 0;
+            }
+            if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, a, w[5], blk, t, lane);
+          }
+        }
+        if (!(flags & HN_LAYER_NO_COMMIT)) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (t < NT)
+#pragma unroll
+              for (int s = 0; s < M::STEPS32; ++s) cur[t * M::STEPS32 + s] = nxt[t * M::STEPS32 + s];
+        }
+      } else if (code == HN_OP_OUT) {
+        const int n = w[3];
+        if (h == 0 && valid) {
+          const HnDst d = a.dst[w[1]];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i < n) {
+              float y = accL[i];
+              if (w[4] == 1) y = 1.0f / (1.0f + expf(-y));
+              if (w[5] >= 0) {
+                const HnSrc s = a.src[w[5]];
+                y = __fadd_rn(s.ptr[(size_t)(s.per_ray ? ray : p) * s.ld + w[6] + i], y);
+              }
+              d.ptr[(size_t)p * d.ld + w[2] + i] = y;
+            }
+          }
+        }
+      } else if (code == HN_OP_OUT_WIDE) {
+        const int n = w[3], NT = w[4];
+        if (valid) {
+          const HnDst d = a.dst[w[1]];
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (t < NT) {
+              if constexpr (BF16) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) {
+                    const int row = 32 * t + 16 * s + hn_pi16(h, j);
+                    if (row < n) d.ptr[(size_t)p * d.ld + w[2] + row] = (float)cur[2 * t + s][j];
+                  }
+              } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                  const int row = 32 * t + hn_rho(q, h);
+                  if (row < n) d.ptr[(size_t)p * d.ld + w[2] + row] = cur[16 * t + q];
+                }
+              }
+            }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward-data machine
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_bwd_kernel(const HnMlpArgs a) {
+  using M = ModeT<BF16>;
+  using Frag = typename M::Frag;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int PTS = M::WAVES * 32;
+  const int ntiles = (a.n_points + PTS - 1) / PTS;
+  float* dsrc_lds = reinterpret_cast<float*>(smem + 2 * HN_CHUNK_UNITS * 1024) + wave * (32 * HN_DSRC_COMPS);
+
+  WStream<M::WAVES> ws;
+  ws.g = reinterpret_cast<const char*>(a.wstream);
+  ws.lds = smem;
+  ws.nchunks = a.n_chunks;
+  ws.wave = wave;
+  ws.lane = lane;
+
+  Frag cur[8 * M::STEPS32];
+  Frag nxt[8 * M::STEPS32];
+  Frag cur2[M::STEPS32];
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int blk = tile * M::WAVES + wave;
+    const int p0 = blk * 32 + r;
+    const bool valid = p0 < a.n_points;
+    const int p = valid ? p0 : a.n_points - 1;
+    const int ray = p / a.samples_per_ray;
+    const bool wave_valid = blk * 32 < a.n_points;
+    for (int i = lane; i < 32 * HN_DSRC_COMPS; i += 64) dsrc_lds[i] = 0.0f;
+    ws.start();
+
+    for (int op = 0; op < a.n_ops; ++op) {
+      const int* w = a.ops + op * HN_OP_WORDS;
+      const int code = w[0];
+      if (code == HN_BOP_LOAD) {
+        // dZ (<= 4 columns) of an output layer -> one 32-feature tile
+        const int n = w[3] & 255;
+        const bool to2 = (w[3] >> 8) & 1;
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+        if (h == 0 && valid) {
+          const HnSrc s = a.src[w[1]];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (i < n) {
+              float g = s.ptr[(size_t)p * s.ld + w[2] + i];
+              if (w[4] == 1) {
+                const HnSrc ys = a.src[w[5]];
+                const float y = ys.ptr[(size_t)p * ys.ld + w[6] + i];
+                g = g * y * (1.0f - y);
+              }
+              d[i] = g;
+            }
+        }
+        Frag tmp[M::STEPS32];
+        hn_zero_frags(tmp, M::STEPS32);
+        if constexpr (BF16) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tmp[0][i] = (__bf16)d[i];  // h==0, j<4 <-> features 0..3
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tmp[i] = d[i];             // step q, h==0 <-> feature q
+        }
+        if (a.training && w[7] >= 0 && wave_valid) hn_stash<BF16>(tmp, a, w[7], blk, 0, lane);
+#pragma unroll
+        for (int s = 0; s < M::STEPS32; ++s) {
+          if (to2) cur2[s] = tmp[s];
+          else cur[s] = tmp[s];
+        }
+      } else if (code == HN_BOP_LOAD_WIDE) {
+        const int n = w[3], NT = w[4];
+        const HnSrc s = a.src[w[1]];
+        unsigned bits = 0xffffffffu;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (t < NT) {
+            if (w[5] >= 0 && !(t & 1)) {  // output activation was relu: dZ = dY * relu'
+              const HnSlot sl = a.slots[w[5]];
+              bits = wave_valid ? a.masks[sl.off / 4 + ((size_t)blk * sl.nt + (t >> 1)) * 64 + lane] : 0u;
+            }
+            f32x16 v;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int row = 32 * t + hn_rho(i, h);
+              const bool keep = ((bits >> (16 * (t & 1) + i)) & 1u) != 0u;
+              v[i] = (valid && keep && row < n) ? s.ptr[(size_t)p * s.ld + w[2] + row] : 0.0f;
+            }
+            hn_acc_to_frags(v, cur + t * M::STEPS32);
+            if (a.training && w[7] >= 0 && wave_valid) hn_stash<BF16>(cur + t * M::STEPS32, a, w[7], blk, t, lane);
+          }
+        }
+      } else if (code == HN_BOP_LAYER) {
+        const int K32 = w[1] & 255, K32b = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
+        const bool has_mask = w[4] >= 0;
+        const bool do_stash = a.training && w[5] >= 0 && wave_valid;
+        unsigned bits = 0xffffffffu;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (t < NT) {
+            f32x16 acc;
+            hn_init_acc(acc, nullptr, t, h);
+            hn_gemm_k<BF16>(acc, cur, K32, ws);
+            if (K32b) hn_gemm_blocks<BF16, 1>(acc, cur2, ws);
+            if (has_mask && !(t & 1)) {
+              const HnSlot sl = a.slots[w[4]];
+              bits = wave_valid ? a.masks[sl.off / 4 + ((size_t)blk * sl.nt + (t >> 1)) * 64 + lane] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const bool keep = ((bits >> (16 * (t & 1) + i)) & 1u) != 0u;
+              acc[i] = (keep && valid) ? acc[i] : 0.0f;
+            }
+            hn_acc_to_frags(acc, nxt + t * M::STEPS32);
+            if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, a, w[5], blk, t, lane);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (t < NT)
+#pragma unroll
+            for (int s = 0; s < M::STEPS32; ++s) cur[t * M::STEPS32 + s] = nxt[t * M::STEPS32 + s];
+      } else if (code == HN_BOP_AUX) {
+        // gradient of generated features: per 32-feature tile tmp = W_aux^T . dZ, then the chain rule
+        const int K32 = w[1] & 255, K32b = (w[1] >> 8) & 255, nG = (w[1] >> 16) & 255;
+        for (int tt = 0; tt < 2 * nG; ++tt) {
+          f32x16 acc;
+          hn_init_acc(acc, nullptr, 0, h);
+          hn_gemm_k<BF16>(acc, cur, K32, ws);
+          if (K32b) hn_gemm_blocks<BF16, 1>(acc, cur2, ws);
+          const HnFeat* ft = a.feat + w[3] + 32 * tt;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const HnFeat e = ft[hn_rho(i, h)];
+            const int slot = ((e.packed >> 16) & 255) - 1;
+            if (slot >= 0 && valid)
+              atomicAdd(dsrc_lds + r * HN_DSRC_COMPS + slot, acc[i] * hn_feature_grad<BF16>(e, a, p, ray));
+          }
+        }
+      }
+    }
+    // source gradients of this block -> global
+    if (a.n_dsrc > 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int i = lane; i < 32 * HN_DSRC_COMPS; i += 64) {
+        const int rr = i / HN_DSRC_COMPS, c = i % HN_DSRC_COMPS;
+        const int pp = blk * 32 + rr;
+        if (c < a.n_dsrc && pp < a.n_points) a.dsrc[(size_t)pp * a.n_dsrc + c] = dsrc_lds[i];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ void hn_pack_kernel(const HnPackUnit* units, int n_units, const float* const* ptrs, char* out,
+                               const HnPackBias* bias, int n_bias, float* bias_out) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row = lane & 31, h = lane >> 5;
+  if (wid < n_units) {
+    const HnPackUnit u = units[wid];
+    const float* W = u.w_id >= 0 ? ptrs[u.w_id] : nullptr;
+    auto fetch = [&](int k) -> float {
+      int sr, sc;
+      if (u.transposed) { sr = u.r0 + k; sc = u.c0 + row; }
+      else { sr = u.r0 + row; sc = u.c0 + k; }
+      if (W == nullptr || sr < 0 || sc < 0 || sr >= u.r_end || sc >= u.c_end) return 0.0f;
+      return W[(size_t)sr * u.ld + sc];
+    };
+    char* dst = out + (size_t)wid * 1024 + lane * 16;
+    if (BF16) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (__bf16)fetch(u.k0 + hn_pi16(h, j));
+      *reinterpret_cast<bf16x8*>(dst) = o;
+    } else {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fetch(hn_rho(u.k0 + e, h));
+      *reinterpret_cast<f32x4*>(dst) = o;
+    }
+  } else if (wid - n_units < n_bias) {
+    const HnPackBias b = bias[wid - n_units];
+    const float* src = b.w_id >= 0 ? ptrs[b.w_id] : nullptr;
+    for (int i = lane; i < b.len; i += 64) bias_out[b.off + i] = (src != nullptr && i < b.n) ? src[i] : 0.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: dW[n][k] += sum_p dZ[p][n] X[p][k] straight from the transposed stashes
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+struct DwFrag;
+template <>
+struct DwFrag<true> {
+  bf16x8 v[2];
+  HN_DEV void load(const char* tile, int lane) {
+    v[0] = *reinterpret_cast<const bf16x8*>(tile + lane * 16);
+    v[1] = *reinterpret_cast<const bf16x8*>(tile + 1024 + lane * 16);
+  }
+  HN_DEV static void mma(f32x16& acc, const DwFrag& a, const DwFrag& b) {
+    acc = hn_mfma_bf16(a.v[0], b.v[0], acc);
+    acc = hn_mfma_bf16(a.v[1], b.v[1], acc);
+  }
+  HN_DEV static void mma_ones(f32x16& acc, const DwFrag& a) {
+    bf16x8 one;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) one[j] = (__bf16)1.0f;
+    acc = hn_mfma_bf16(a.v[0], one, acc);
+    acc = hn_mfma_bf16(a.v[1], one, acc);
+  }
+};
+template <>
+struct DwFrag<false> {
+  f32x4 v[4];
+  HN_DEV void load(const char* tile, int lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(tile + g * 1024 + lane * 16);
+  }
+  HN_DEV static void mma(f32x16& acc, const DwFrag& a, const DwFrag& b) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = hn_mfma_f32(a.v[g][e], b.v[g][e], acc);
+  }
+  HN_DEV static void mma_ones(f32x16& acc, const DwFrag& a) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = hn_mfma_f32(a.v[g][e], 1.0f, acc);
+  }
+};
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 1) void hn_wgrad_kernel(const HnDwJob* jobs, int n_jobs, const char* stash,
+                                                          float* grads) {
+  using M = ModeT<BF16>;
+  constexpr size_t TB = M::TILE_UNITS * 1024;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= n_jobs) return;
+  const HnDwJob jb = jobs[wid];
+  const int c = lane & 31, h = lane >> 5;
+  f32x16 acc[2][4];
+  f32x16 accb[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accb[n][i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[n][k][i] = 0.0f;
+  }
+  const bool do_bias = jb.b_off >= 0;
+  for (int b = jb.blk0; b < jb.blk1; ++b) {
+    DwFrag<BF16> za[2], xb[4];
+    const char* zt = stash + jb.z_off + ((size_t)b * jb.z_nt + jb.z_t0) * TB;
+    const char* xt = stash + jb.x_off + ((size_t)b * jb.x_nt + jb.x_t0) * TB;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+      if (n < jb.n_nt) za[n].load(zt + n * TB, lane);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < jb.n_kt) xb[k].load(xt + k * TB, lane);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      if (n < jb.n_nt) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < jb.n_kt) DwFrag<BF16>::mma(acc[n][k], za[n], xb[k]);
+        if (do_bias) DwFrag<BF16>::mma_ones(accb[n], za[n]);
+      }
+    }
+  }
+  // D[n][k]: lane = column k (c), register q -> row rho(q,h)
+  if (jb.w_off >= 0) {
+    float* G = grads + jb.w_off;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+      if (n < jb.n_nt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < jb.n_kt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int row = jb.r0 + 32 * n + hn_rho(q, h);
+              const int col = jb.c0 + 32 * k + c;
+              if (row >= 0 && col >= 0 && row < jb.r_end && col < jb.c_end)
+                atomicAdd(G + (size_t)row * jb.ld + col, acc[n][k][q]);
+            }
+  }
+  if (do_bias && c == 0) {
+    float* gb = grads + jb.b_off;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+      if (n < jb.n_nt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = jb.r0 + 32 * n + hn_rho(q, h);
+          if (row >= 0 && row < jb.r_end) atomicAdd(gb + row, accb[n][q]);
+        }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static int hn_grid_for(int n_points, int pts_per_wg) {
+  int tiles = (n_points + pts_per_wg - 1) / pts_per_wg;
+  const int cap = 256 * 4;  // persistent: at most 4 tiles' worth of workgroups per CU queue
+  return tiles < cap ? tiles : cap;
+}
+
+extern "C" int hn_version(void) { return HN_VERSION; }
+
+extern "C" int hn_abi_sizes(int32_t* out, int n) {
+  const int32_t v[8] = {(int32_t)sizeof(HnMlpArgs),      (int32_t)sizeof(HnPackUnit), (int32_t)sizeof(HnPackBias),
+                        (int32_t)sizeof(HnDwJob),        (int32_t)sizeof(HnCompositeArgs), (int32_t)sizeof(HnFeat),
+                        (int32_t)sizeof(HnSlot),         (int32_t)sizeof(HnSrc)};
+  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  return 8;
+}
+
+static void hn_allow_big_lds() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  const int big = 96 * 1024;
+  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+}
+
+extern "C" int hn_pack_units(int mode, const HnPackUnit* units, int n_units, const float* const* ptrs, void* wstream,
+                             const HnPackBias* bias, int n_bias, float* bias_out, hnStream_t stream) {
+  if (n_units < 0 || n_bias < 0) return -1;
+  const int total = n_units + n_bias;
+  if (total == 0) return 0;
+  const int grid = (total + 3) / 4;
+  if (mode == HN_MODE_BF16)
+    hipLaunchKernelGGL(hn_pack_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, units, n_units, ptrs,
+                       (char*)wstream, bias, n_bias, bias_out);
+  else if (mode == HN_MODE_F32)
+    hipLaunchKernelGGL(hn_pack_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, units, n_units, ptrs,
+                       (char*)wstream, bias, n_bias, bias_out);
+  else
+    return -2;
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+static int hn_check_args(const HnMlpArgs* a) {
+  if (a == nullptr) return -1;
+  if (a->n_points <= 0 || a->samples_per_ray <= 0 || a->n_ops <= 0 || a->n_chunks <= 0) return -2;
+  if (a->ops == nullptr || a->wstream == nullptr) return -3;
+  if (a->mode != HN_MODE_BF16 && a->mode != HN_MODE_F32) return -4;
+  if (a->n_dsrc < 0 || a->n_dsrc > HN_DSRC_COMPS) return -5;
+  return 0;
+}
+
+extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
+  int rc = hn_check_args(a);
+  if (rc) return rc;
+  hn_allow_big_lds();
+  const size_t lds = 2 * HN_CHUNK_UNITS * 1024;
+  if (a->mode == HN_MODE_BF16) {
+    hipLaunchKernelGGL(hn_mlp_fwd_kernel<true>, dim3(hn_grid_for(a->n_points, 256)), dim3(512), lds,
+                       (hipStream_t)stream, *a);
+  } else {
+    hipLaunchKernelGGL(hn_mlp_fwd_kernel<false>, dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
+                       (hipStream_t)stream, *a);
+  }
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
+  int rc = hn_check_args(a);
+  if (rc) return rc;
+  hn_allow_big_lds();
+  if (a->mode == HN_MODE_BF16) {
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + 8 * 32 * HN_DSRC_COMPS * 4;
+    hipLaunchKernelGGL(hn_mlp_bwd_kernel<true>, dim3(hn_grid_for(a->n_points, 256)), dim3(512), lds,
+                       (hipStream_t)stream, *a);
+  } else {
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + 4 * 32 * HN_DSRC_COMPS * 4;
+    hipLaunchKernelGGL(hn_mlp_bwd_kernel<false>, dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
+                       (hipStream_t)stream, *a);
+  }
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hn_mlp_wgrad(int mode, const HnDwJob* jobs, int n_jobs, const void* stash, float* grads,
+                            hnStream_t stream) {
+  if (n_jobs < 0) return -1;
+  if (n_jobs == 0) return 0;
+  if (jobs == nullptr || stash == nullptr || grads == nullptr) return -3;
+  const int grid = (n_jobs + 3) / 4;
+  if (mode == HN_MODE_BF16)
+    hipLaunchKernelGGL(hn_wgrad_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs,
+                       (const char*)stash, grads);
+  else if (mode == HN_MODE_F32)
+    hipLaunchKernelGGL(hn_wgrad_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs,
+                       (const char*)stash, grads);
+  else
+    return -2;
+  HN_CHECK_LAUNCH();
+  return 0;
+}

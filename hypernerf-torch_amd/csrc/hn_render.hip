@@ -1,0 +1,463 @@
+// Per-ray kernels of the HyperNeRF render path for gfx950: stratified sampling, density activation +
+// alpha compositing (forward/backward), inverse-CDF hierarchical sampling with merge sort, GLO
+// embedding gather / gradient.  One wavefront (64 lanes) per ray; all HBM accesses are coalesced
+// rows of the (B,S,*) arrays.  These kernels are HBM-bound (tens of bytes per sample).
+#include "hn_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// wave64 scans
+// ------------------------------------------------------------------------------------------------
+HN_DEV float hn_wave_incl_scan_mul(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    if (lane >= d) v *= o;
+  }
+  return v;
+}
+HN_DEV float hn_wave_incl_scan_add(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+HN_DEV float hn_wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampling along rays
+// ------------------------------------------------------------------------------------------------
+__global__ void hn_sample_kernel(const float* __restrict__ origins, const float* __restrict__ dirs, int ray_ld,
+                                 const float* __restrict__ lower, const float* __restrict__ upper,
+                                 int per_ray_bounds, const float* __restrict__ t_rand, float scale, int n_rays,
+                                 int n, float* __restrict__ z_out, float* __restrict__ pts_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_rays * n) return;
+  const int b = (int)(i / n), s = (int)(i % n);
+  const size_t bi = per_ray_bounds ? i : (size_t)s;
+  float z = lower[bi];
+  if (t_rand != nullptr) {
+    // z = lower + (upper - lower) * (scale * t): three separately rounded fp32 ops, as ATen does
+    float t = t_rand[i];
+    if (scale != 1.0f) t = __fmul_rn(scale, t);
+    z = __fadd_rn(z, __fmul_rn(__fsub_rn(upper[bi], z), t));
+  }
+  z_out[i] = z;
+  if (pts_out != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      pts_out[i * 3 + c] = __fadd_rn(origins[(size_t)b * ray_ld + c], __fmul_rn(z, dirs[(size_t)b * ray_ld + c]));
+  }
+}
+
+extern "C" int hn_sample_along_rays(const float* origins, const float* dirs, int ray_ld, const float* lower,
+                                    const float* upper, int per_ray_bounds, const float* t_rand, float scale,
+                                    int n_rays, int n, float* z_out, float* pts_out, hnStream_t stream) {
+  if (n_rays <= 0 || n <= 0) return -2;
+  if (lower == nullptr || z_out == nullptr) return -3;
+  if (t_rand != nullptr && upper == nullptr) return -3;
+  if (pts_out != nullptr && (origins == nullptr || dirs == nullptr)) return -3;
+  const size_t total = (size_t)n_rays * n;
+  hipLaunchKernelGGL(hn_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     origins, dirs, ray_ld, lower, upper, per_ray_bounds, t_rand, scale, n_rays, n, z_out, pts_out);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compositing
+// ------------------------------------------------------------------------------------------------
+constexpr int HN_MAX_SEG = 8;  // up to 512 samples per ray
+
+HN_DEV float hn_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }  // torch Softplus(beta=1,threshold=20)
+HN_DEV float hn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct HnRaySample {
+  float alpha, one_minus, trans, w, sigma_pre;  // one_minus = 1 - alpha + eps
+};
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.n_rays) return;
+  const int S = a.n_samples;
+  const int nseg = (S + 63) / 64;
+  const size_t row = (size_t)ray * S;
+  const float* d = a.dirs + (size_t)ray * a.ray_ld;
+  const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const float eps = a.variant != 1 ? 1e-5f : 1e-10f;
+  const float last = a.variant != 1 ? (a.sample_at_infinity ? 1e7f : 1e-7f) : 1e10f;
+
+  float alpha[HN_MAX_SEG], om[HN_MAX_SEG], trans[HN_MAX_SEG], wgt[HN_MAX_SEG], pre[HN_MAX_SEG], dist[HN_MAX_SEG];
+  float carry = 1.0f;   // product of (1-alpha+eps) over all earlier segments
+  float csum = 0.0f;    // running sum of weights (median depth)
+  float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_d = 0.f, s_w = 0.f, s_wl = 0.f;
+  float med_z = 0.0f, med_pt = 0.0f;
+  bool med_found = false;
+#pragma unroll
+  for (int k = 0; k < HN_MAX_SEG; ++k) {
+    if (k < nseg) {
+      const int s = k * 64 + lane;
+      const bool in = s < S;
+      float zz = 0.f, zn = 0.f, raw = 0.f;
+      if (in) {
+        zz = a.z[row + s];
+        zn = (s + 1 < S) ? a.z[row + s + 1] : 0.f;
+        raw = a.raw[row + s];
+        if (a.noise != nullptr) raw += a.noise[row + s];
+      }
+      const float dz = (s + 1 < S) ? (zn - zz) : last;
+      const float dd = dz * dnorm;
+      const float sigma = a.variant == 0 ? hn_softplus(raw) : (a.variant == 1 ? fmaxf(raw, 0.0f) : raw);
+      float al = in ? (1.0f - expf(-sigma * dd)) : 0.0f;
+      const float o = in ? (1.0f - al + eps) : 1.0f;
+      // exclusive product scan: T_s = prod_{j<s} om_j
+      const float inc = hn_wave_incl_scan_mul(o, lane);
+      float ex = __shfl_up(inc, 1, 64);
+      if (lane == 0) ex = 1.0f;
+      const float T = carry * ex;
+      carry *= __shfl(inc, 63, 64);
+      const float w = al * T;
+      alpha[k] = al; om[k] = o; trans[k] = T; wgt[k] = w; pre[k] = raw; dist[k] = dd;
+      if (!BACKWARD) {
+        if (in) {
+          a.out_weights[row + s] = w;
+          s_r += w * a.rgb[(row + s) * 3 + 0];
+          s_g += w * a.rgb[(row + s) * 3 + 1];
+          s_b += w * a.rgb[(row + s) * 3 + 2];
+          s_d += w * zz;
+          s_w += w;
+          if (s < S - 1) s_wl += w;
+        }
+        if (a.out_med_depth != nullptr) {
+          // first sample whose inclusive weight sum reaches 0.5 (model_utils.py:319-345)
+          const float cs = csum + hn_wave_incl_scan_add(in ? w : 0.0f, lane);
+          const unsigned long long m = __ballot(in && cs >= 0.5f);
+          if (!med_found && m != 0ull) {
+            const int first = __ffsll((long long)m) - 1;
+            med_z = __shfl(zz, first, 64);
+            const int sidx = k * 64 + first;
+            if (a.warped != nullptr) med_pt = a.warped[(row + sidx) * a.warped_ld];
+            med_found = true;
+          }
+          csum = __shfl(cs, 63, 64);
+        }
+      }
+    }
+  }
+  if (!BACKWARD) {
+    s_r = hn_wave_sum(s_r); s_g = hn_wave_sum(s_g); s_b = hn_wave_sum(s_b);
+    s_d = hn_wave_sum(s_d); s_w = hn_wave_sum(s_w); s_wl = hn_wave_sum(s_wl);
+    if (lane == 0) {
+      float bg = a.white_bg ? (1.0f - s_w) : 0.0f;
+      a.out_rgb[ray * 3 + 0] = s_r + bg;
+      a.out_rgb[ray * 3 + 1] = s_g + bg;
+      a.out_rgb[ray * 3 + 2] = s_b + bg;
+      a.out_depth[ray] = s_d;
+      a.out_acc[ray] = (a.variant != 1 && a.sample_at_infinity) ? s_wl : s_w;
+      if (a.out_med_depth != nullptr) {
+        a.out_med_depth[ray] = med_z;
+        if (a.out_med_points != nullptr)
+          a.out_med_points[ray] = med_found ? med_pt : (a.warped != nullptr ? a.warped[row * a.warped_ld] : 0.0f);
+      }
+    }
+    return;
+  }
+  // ---- backward -------------------------------------------------------------------------------
+  // L depends on w_s through rgb (sum w c), depth (sum w z), acc and explicit weight gradients;
+  // white background adds -(g_r+g_g+g_b) to every dL/dw.
+  float gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f, ga = 0.f;
+  if (a.g_rgb != nullptr) { gr = a.g_rgb[ray * 3]; gg = a.g_rgb[ray * 3 + 1]; gb = a.g_rgb[ray * 3 + 2]; }
+  if (a.g_depth != nullptr) gd = a.g_depth[ray];
+  if (a.g_acc != nullptr) ga = a.g_acc[ray];
+  const float gbg = a.white_bg ? -(gr + gg + gb) : 0.0f;
+  const bool acc_drops_last = (a.variant != 1 && a.sample_at_infinity);
+  float suffix = 0.0f;  // sum_{k > s} dL/dw_k * w_k  over later segments
+#pragma unroll
+  for (int k = HN_MAX_SEG - 1; k >= 0; --k) {
+    if (k < nseg) {
+      const int s = k * 64 + lane;
+      const bool in = s < S;
+      float dw = 0.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+      if (in) {
+        c0 = a.rgb[(row + s) * 3]; c1 = a.rgb[(row + s) * 3 + 1]; c2 = a.rgb[(row + s) * 3 + 2];
+        dw = gr * c0 + gg * c1 + gb * c2 + gd * a.z[row + s] + gbg;
+        if (!acc_drops_last || s < S - 1) dw += ga;
+        if (a.g_weights != nullptr) dw += a.g_weights[row + s];
+      }
+      const float dww = in ? dw * wgt[k] : 0.0f;
+      // exclusive suffix sum inside the segment: sum_{j > lane} dww_j
+      float v = dww;
+#pragma unroll
+      for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const float o = __shfl_down(v, dlt, 64);
+        if (lane + dlt < 64) v += o;
+      }
+      const float seg_total = __shfl(v, 0, 64);
+      const float after = (v - dww) + suffix;
+      suffix += seg_total;
+      if (in) {
+        const float dalpha = dw * trans[k] - after / om[k];
+        // alpha = 1 - exp(-sigma*dist)  ->  dalpha/dsigma = dist * exp(-sigma*dist) = dist * (1 - alpha)
+        const float dsigma = dalpha * dist[k] * (1.0f - alpha[k]);
+        float draw;
+        if (a.variant == 0) draw = dsigma * (pre[k] > 20.0f ? 1.0f : hn_sigmoid(pre[k]));
+        else if (a.variant == 1) draw = pre[k] > 0.0f ? dsigma : 0.0f;
+        else draw = dsigma;
+        a.d_raw[row + s] = draw;
+        const float ws = wgt[k];
+        a.d_rgb[(row + s) * 3 + 0] = gr * ws;
+        a.d_rgb[(row + s) * 3 + 1] = gg * ws;
+        a.d_rgb[(row + s) * 3 + 2] = gb * ws;
+      }
+    }
+  }
+}
+
+static int hn_check_comp(const HnCompositeArgs* a, bool bwd) {
+  if (a == nullptr) return -1;
+  if (a->n_rays <= 0 || a->n_samples <= 0 || a->n_samples > 64 * HN_MAX_SEG) return -2;
+  if (a->rgb == nullptr || a->raw == nullptr || a->z == nullptr || a->dirs == nullptr) return -3;
+  if (!bwd && (a->out_rgb == nullptr || a->out_depth == nullptr || a->out_acc == nullptr || a->out_weights == nullptr))
+    return -3;
+  if (bwd && (a->d_rgb == nullptr || a->d_raw == nullptr)) return -3;
+  return 0;
+}
+
+extern "C" int hn_composite_forward(const HnCompositeArgs* a, hnStream_t stream) {
+  int rc = hn_check_comp(a, false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(hn_composite_kernel<false>, dim3((a->n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int hn_composite_backward(const HnCompositeArgs* a, hnStream_t stream) {
+  int rc = hn_check_comp(a, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(hn_composite_kernel<true>, dim3((a->n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// inverse-CDF sampling + merge sort (one wave per ray; LDS: cdf/bins + 512-entry sort buffer)
+// ------------------------------------------------------------------------------------------------
+constexpr int HN_PDF_MAXC = 256;   // max coarse samples
+constexpr int HN_PDF_MAXT = 512;   // max coarse + fine
+
+__global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const float* __restrict__ weights, int w_ld,
+                                                            const float* __restrict__ bins_in, int nb,
+                                                            const float* __restrict__ z, int nc,
+                                                            const float* __restrict__ u, const float* __restrict__ origins,
+                                                            const float* __restrict__ dirs, int ray_ld, int n_rays,
+                                                            int nf, float* __restrict__ z_all,
+                                                            float* __restrict__ pts, int64_t* __restrict__ inds,
+                                                            float* __restrict__ z_samples) {
+  __shared__ float s_cdf[4][HN_PDF_MAXC];
+  __shared__ float s_bins[4][HN_PDF_MAXC];
+  __shared__ float s_sort[4][HN_PDF_MAXT];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  if (ray >= n_rays) return;
+  float* cdf = s_cdf[wv];
+  float* bins = s_bins[wv];
+  float* srt = s_sort[wv];
+  const int ncdf = nb + 1;     // cdf entries = bin edges
+  const float* zr = z != nullptr ? z + (size_t)ray * nc : nullptr;
+  const float* wr = weights + (size_t)ray * w_ld;
+  if (bins_in != nullptr) {
+    for (int i = lane; i < ncdf; i += 64) bins[i] = bins_in[(size_t)ray * ncdf + i];
+  } else {
+    for (int i = lane; i < ncdf; i += 64) bins[i] = 0.5f * (zr[i + 1] + zr[i]);   // z_vals_mid
+  }
+  for (int i = lane; i < nb; i += 64) srt[i] = wr[i] + 1e-5f;
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    // fp64 sequential normaliser rounded once; fp64 sequential prefix sum rounded per entry
+    double tot = 0.0;
+    for (int i = 0; i < nb; ++i) tot += (double)srt[i];
+    const float norm = (float)tot;
+    double run = 0.0;
+    cdf[0] = 0.0f;
+    for (int i = 0; i < nb; ++i) {
+      const float pdf = __fdiv_rn(srt[i], norm);
+      run += (double)pdf;
+      cdf[i + 1] = (float)run;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  const int nmerge = zr != nullptr ? nc : 0;
+  const int total = nmerge + nf;
+  for (int i = lane; i < nf; i += 64) {
+    const float uu = u[(size_t)ray * nf + i];
+    // searchsorted(cdf, u, right=True): number of entries <= u
+    int lo = 0, hi = ncdf;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+    }
+    const int ind = lo;
+    const int below = ind - 1 < 0 ? 0 : ind - 1;
+    const int above = ind > nb ? nb : ind;
+    const float c0 = cdf[below], c1 = cdf[above];
+    const float b0 = bins[below], b1 = bins[above];
+    float den = __fsub_rn(c1, c0);
+    if (den < 1e-5f) den = 1.0f;
+    const float t = __fdiv_rn(__fsub_rn(uu, c0), den);
+    const float smp = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));
+    if (inds != nullptr) inds[(size_t)ray * nf + i] = ind;
+    if (z_samples != nullptr) z_samples[(size_t)ray * nf + i] = smp;
+    srt[nmerge + i] = smp;
+  }
+  if (z_all == nullptr) return;
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < nmerge; i += 64) srt[i] = zr[i];
+  // pad to a power of two with +inf and bitonic-sort ascending
+  int n2 = 1;
+  while (n2 < total) n2 <<= 1;
+  for (int i = total + lane; i < n2; i += 64) srt[i] = __builtin_inff();
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = lane; i < n2; i += 64) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const float x = srt[i], y = srt[ixj];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { srt[i] = y; srt[ixj] = x; }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  for (int i = lane; i < total; i += 64) {
+    const float zz = srt[i];
+    z_all[(size_t)ray * total + i] = zz;
+    if (pts != nullptr) {
+      const float* o = origins + (size_t)ray * ray_ld;
+      const float* d = dirs + (size_t)ray * ray_ld;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pts[((size_t)ray * total + i) * 3 + c] = __fadd_rn(o[c], __fmul_rn(zz, d[c]));
+    }
+  }
+}
+
+extern "C" int hn_sample_pdf(const float* weights, int w_ld, const float* bins, int n_bins, const float* z,
+                             int n_coarse, const float* u, const float* origins, const float* dirs, int ray_ld,
+                             int n_rays, int n_fine, float* z_all, float* pts, int64_t* inds, float* z_samples,
+                             hnStream_t stream) {
+  if (n_rays <= 0 || n_bins < 1 || n_fine <= 0) return -2;
+  if (z != nullptr && n_coarse < 2) return -2;
+  if (bins == nullptr && (z == nullptr || n_coarse - 2 != n_bins)) return -2;
+  if (n_bins + 1 > HN_PDF_MAXC || (z != nullptr ? n_coarse : 0) + n_fine > HN_PDF_MAXT) return -2;
+  if (weights == nullptr || u == nullptr) return -3;
+  if (z_all == nullptr && z_samples == nullptr && inds == nullptr) return -3;
+  if (pts != nullptr && (origins == nullptr || dirs == nullptr || z_all == nullptr)) return -3;
+  hipLaunchKernelGGL(hn_sample_pdf_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, weights, w_ld,
+                     bins, n_bins, z, n_coarse, u, origins, dirs, ray_ld, n_rays, n_fine, z_all, pts, inds, z_samples);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GLO embedding
+// ------------------------------------------------------------------------------------------------
+__global__ void hn_embed_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx, int n_rays,
+                                       int dim, int n_rows, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rays * dim) return;
+  const int b = i / dim, c = i % dim;
+  int64_t row = idx[b];
+  row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+  out[i] = table[row * dim + c];
+}
+
+__global__ __launch_bounds__(256) void hn_embed_bwd_kernel(const float* __restrict__ d_points, int ld, int col0,
+                                                           const int64_t* __restrict__ idx, int n_rays, int S,
+                                                           int dim, int n_rows, float* __restrict__ d_table) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  int64_t row = idx[ray];
+  row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+  for (int c = 0; c < dim; ++c) {
+    float v = 0.0f;
+    for (int s = lane; s < S; s += 64) v += d_points[((size_t)ray * S + s) * ld + col0 + c];
+    v = hn_wave_sum(v);
+    if (lane == 0) atomicAdd(d_table + row * dim + c, v);
+  }
+}
+
+extern "C" int hn_embed_gather(const float* table, const int64_t* idx, int n_rays, int dim, int n_rows, float* out,
+                               hnStream_t stream) {
+  if (n_rays <= 0 || dim <= 0 || n_rows <= 0) return -2;
+  if (table == nullptr || idx == nullptr || out == nullptr) return -3;
+  hipLaunchKernelGGL(hn_embed_gather_kernel, dim3((n_rays * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     table, idx, n_rays, dim, n_rows, out);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hn_embed_backward(const float* d_points, int ld, int col0, const int64_t* idx, int n_rays,
+                                 int n_samples, int dim, int n_rows, float* d_table, hnStream_t stream) {
+  if (n_rays <= 0 || dim <= 0 || n_rows <= 0 || n_samples <= 0) return -2;
+  if (d_points == nullptr || idx == nullptr || d_table == nullptr) return -3;
+  hipLaunchKernelGGL(hn_embed_bwd_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_points, ld,
+                     col0, idx, n_rays, n_samples, dim, n_rows, d_table);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hardware layout probe (run once on a real MI355X by tests/test_gpu_probe.py)
+// ------------------------------------------------------------------------------------------------
+__global__ void hn_probe_kernel(float* out_bf16, float* out_f32, float* out_glds, const float* src) {
+  __shared__ __attribute__((aligned(16))) char smem[1024];
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  // probe 1: A[i][k] = i, B[k][j] = (k == j % 16)            -> D[i][j] = i
+  // probe 2: A[i][k] = k (k = 8h+j as documented), same B     -> D[i][j] = j % 16
+  // Together: A row = lane&31, B col = lane&31, element (h,j) of A meets element (h,j) of B, C/D map.
+  bf16x8 a1, a2, b;
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * h + j;
+    a1[j] = (__bf16)(float)r;
+    a2[j] = (__bf16)(float)k;
+    b[j] = (__bf16)((k == (r & 15)) ? 1.0f : 0.0f);
+  }
+  f32x16 c = {0}, c2 = {0};
+  c = hn_mfma_bf16(a1, b, c);
+  c2 = hn_mfma_bf16(a2, b, c2);
+  for (int i = 0; i < 16; ++i) out_bf16[lane * 16 + i] = c[i];
+  for (int i = 0; i < 16; ++i) out_bf16[1024 + lane * 16 + i] = c2[i];
+  // fp32: A[i][k] = i + 1000*k (k = h), B[k][j] = (k==0 ? 1 : 0.5*j)  -> D[i][j] = i + (i+1000)*0.5*j
+  f32x16 d = {0};
+  d = hn_mfma_f32((float)(r + 1000 * h), h == 0 ? 1.0f : 0.5f * (float)r, d);
+  for (int i = 0; i < 16; ++i) out_f32[lane * 16 + i] = d[i];
+  // LDS-DMA: 16 B per lane from src into LDS, read back
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 4),
+                                   (__attribute__((address_space(3))) void*)smem, 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int i = 0; i < 4; ++i) out_glds[lane * 4 + i] = reinterpret_cast<float*>(smem)[lane * 4 + i];
+}
+
+extern "C" int hn_probe_mfma(float* out_bf16_acc, float* out_f32_acc, float* out_glds, hnStream_t stream) {
+  if (out_bf16_acc == nullptr || out_f32_acc == nullptr || out_glds == nullptr) return -3;
+  // source for the LDS-DMA test: reuse out_glds's second half (256 floats) — caller fills [256,512) with a ramp
+  hipLaunchKernelGGL(hn_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_bf16_acc, out_f32_acc, out_glds,
+                     out_glds + 256);
+  HN_CHECK_LAUNCH();
+  return 0;
+}

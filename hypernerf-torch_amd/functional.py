@@ -1,0 +1,316 @@
+"""autograd glue between PyTorch tensors and the C-ABI kernels.
+
+PyTorch is used for device memory, streams and the autograd graph only; all arithmetic of the
+hot path happens in the HIP kernels.  Every function here raises if handed a CPU tensor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from .machine import MlpRunner, Program
+
+_PRECISION = os.environ.get("HN_PRECISION", "bf16")
+
+
+def set_precision(p: str):
+    """'bf16' (bf16 MFMA operands, fp32 accumulate; throughput mode) or 'fp32' (fp32 MFMA; parity mode)."""
+    global _PRECISION
+    if p not in ("bf16", "fp32"):
+        raise ValueError(p)
+    _PRECISION = p
+
+
+def get_precision() -> str:
+    return _PRECISION
+
+
+def mode_of(precision: Optional[str] = None) -> int:
+    return L.HN_MODE_BF16 if (precision or _PRECISION) == "bf16" else L.HN_MODE_F32
+
+
+# --------------------------------------------------------------------------------------------
+# fused MLP programs
+# --------------------------------------------------------------------------------------------
+class ProgramCall:
+    """A compiled program + how its sources / outputs map to tensors."""
+
+    def __init__(self, program: Program, src_per_ray: Sequence[bool], dst_widths: Sequence[int],
+                 grad_srcs: Sequence[Tuple[str, int]]):
+        # grad_srcs[i] describes backward source 4+i: ('g', k) = gradient of output k, ('y', k) = output k
+        self.program = program
+        self.runner = MlpRunner(program)
+        self.src_per_ray = list(src_per_ray)
+        self.dst_widths = list(dst_widths)
+        self.grad_srcs = list(grad_srcs)
+
+
+class _ProgramFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, call: ProgramCall, mode: int, samples_per_ray: int, n_src: int, *tensors):
+        srcs = list(tensors[:n_src])
+        L.require_gpu(*[s for s in srcs if s is not None])
+        first = next(s for s in srcs if s is not None)
+        device = first.device
+        n_points = None
+        flat_srcs = []
+        for s, per_ray in zip(srcs, call.src_per_ray):
+            if s is None:
+                flat_srcs.append(None)
+                continue
+            s2 = s.detach().reshape(-1, s.shape[-1]).contiguous()
+            if not per_ray:
+                n_points = s2.shape[0] if n_points is None else n_points
+                if s2.shape[0] != n_points:
+                    raise L.HnError("per-point sources disagree on the number of points")
+            flat_srcs.append((s2, per_ray))
+        if n_points is None:
+            raise L.HnError("a program needs at least one per-point source")
+        training = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+        outs = [torch.empty(n_points, w, dtype=torch.float32, device=device) for w in call.dst_widths]
+        stash, masks = call.runner.forward(mode, n_points, samples_per_ray, flat_srcs, outs, training)
+        ctx.call, ctx.mode, ctx.spr, ctx.n_src, ctx.n_points = call, mode, samples_per_ray, n_src, n_points
+        ctx.flat_srcs = flat_srcs
+        ctx.src_shapes = [None if s is None else s.shape for s in srcs]
+        ctx.stash, ctx.masks = stash, masks
+        ctx.outs = outs
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        call: ProgramCall = ctx.call
+        if ctx.stash is None:
+            raise L.HnError("backward through a program that ran without training=True")
+        bsrcs = list(ctx.flat_srcs) + [None] * (4 - len(ctx.flat_srcs))
+        for kind, k in call.grad_srcs:
+            if kind == "g":
+                g = gouts[k]
+                if g is None:
+                    g = torch.zeros_like(ctx.outs[k])
+                bsrcs.append((g.contiguous(), False))
+            else:
+                bsrcs.append((ctx.outs[k], False))
+        dsrc, flat = call.runner.backward(ctx.mode, ctx.n_points, ctx.spr, bsrcs, ctx.stash, ctx.masks)
+        ctx.stash = ctx.masks = None
+        src_grads: List[Optional[torch.Tensor]] = []
+        prog = call.program
+        for i, shp in enumerate(ctx.src_shapes):
+            if shp is None or not ctx.needs_input_grad[4 + i]:
+                src_grads.append(None)
+                continue
+            cols = {c: s for (si, c), s in prog.dsrc_map.items() if si == i}
+            if not cols:
+                src_grads.append(None)
+                continue
+            width = shp[-1]
+            if call.src_per_ray[i]:
+                n_rays = ctx.n_points // ctx.spr
+                g = torch.zeros(n_rays, width, dtype=torch.float32, device=dsrc.device)
+                sum_samples_into(dsrc, cols, n_rays, ctx.spr, g)
+            else:
+                g = torch.zeros(ctx.n_points, width, dtype=torch.float32, device=dsrc.device)
+                for c, s in cols.items():
+                    g[:, c] = dsrc[:, s]
+            src_grads.append(g.view(shp))
+        pgrads = call.runner.split_grads(flat)
+        n_par = len(prog.params)
+        out_p = []
+        for j in range(n_par):
+            out_p.append(pgrads[j] if ctx.needs_input_grad[4 + ctx.n_src + j] else None)
+        return (None, None, None, None, *src_grads, *out_p)
+
+
+def run_program(call: ProgramCall, srcs: Sequence[Optional[torch.Tensor]], samples_per_ray: int,
+                precision: Optional[str] = None) -> Tuple[torch.Tensor, ...]:
+    L.load()
+    return _ProgramFn.apply(call, mode_of(precision), int(samples_per_ray), len(srcs), *srcs, *call.program.params)
+
+
+def sum_samples_into(d_points: torch.Tensor, cols: Dict[int, int], n_rays: int, n_samples: int, out: torch.Tensor):
+    """out[b, c] += sum_s d_points[b*S + s, slot]  for every (c -> slot) — HIP reduction kernel.
+    Consecutive (c, slot) pairs are reduced by one launch."""
+    lib = L.load()
+    idx = torch.arange(n_rays, dtype=torch.int64, device=out.device)
+    items = sorted(cols.items())
+    i = 0
+    while i < len(items):
+        j = i
+        while j + 1 < len(items) and items[j + 1][0] == items[j][0] + 1 and items[j + 1][1] == items[j][1] + 1:
+            j += 1
+        c0, s0, run = items[i][0], items[i][1], j - i + 1
+        tmp = torch.zeros(n_rays, run, dtype=torch.float32, device=out.device)
+        L.check(lib.hn_embed_backward(L.ptr(d_points), C.c_int(d_points.shape[1]), C.c_int(s0), L.ptr(idx),
+                                      C.c_int(n_rays), C.c_int(n_samples), C.c_int(run), C.c_int(n_rays), L.ptr(tmp),
+                                      L.stream_handle()), "hn_embed_backward")
+        out[:, c0:c0 + run] += tmp
+        i = j + 1
+
+
+# --------------------------------------------------------------------------------------------
+# GLO embedding
+# --------------------------------------------------------------------------------------------
+class _EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table: torch.Tensor, idx: torch.Tensor):
+        L.require_gpu(table, idx)
+        lib = L.load()
+        idx = idx.reshape(-1).to(torch.int64).contiguous()
+        n, dim = idx.numel(), table.shape[1]
+        out = torch.empty(n, dim, dtype=torch.float32, device=table.device)
+        L.check(lib.hn_embed_gather(L.ptr(table.detach().contiguous()), L.ptr(idx), C.c_int(n), C.c_int(dim),
+                                    C.c_int(table.shape[0]), L.ptr(out), L.stream_handle()), "hn_embed_gather")
+        ctx.idx, ctx.shape = idx, table.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        g = g.contiguous()
+        d_table = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        n, dim = g.shape
+        L.check(lib.hn_embed_backward(L.ptr(g), C.c_int(dim), C.c_int(0), L.ptr(ctx.idx), C.c_int(n), C.c_int(1),
+                                      C.c_int(dim), C.c_int(ctx.shape[0]), L.ptr(d_table), L.stream_handle()),
+                "hn_embed_backward")
+        return d_table, None
+
+
+def embed_lookup(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    return _EmbedFn.apply(table, idx)
+
+
+# --------------------------------------------------------------------------------------------
+# sampling (no gradients flow through sample positions: the reference detaches them too)
+# --------------------------------------------------------------------------------------------
+def sample_along_rays(origins, directions, lower, upper, t_rand, scale: float = 1.0, want_points=True):
+    """z = lower + (upper-lower)*(scale*t_rand), pts = o + z*d.  lower/upper: (n,) or (B,n)."""
+    L.require_gpu(origins, directions, lower)
+    lib = L.load()
+    b = origins.shape[0]
+    n = lower.shape[-1]
+    if origins.stride(-1) != 1 or directions.stride(-1) != 1 or origins.stride(0) != directions.stride(0):
+        origins, directions = origins.contiguous(), directions.contiguous()
+    z = torch.empty(b, n, dtype=torch.float32, device=origins.device)
+    pts = torch.empty(b, n, 3, dtype=torch.float32, device=origins.device) if want_points else None
+    lower = lower.contiguous()
+    upper = upper.contiguous() if upper is not None else None
+    t_rand = t_rand.contiguous() if t_rand is not None else None
+    L.check(lib.hn_sample_along_rays(L.ptr(origins), L.ptr(directions), C.c_int(origins.stride(0)), L.ptr(lower),
+                                     L.ptr(upper), C.c_int(1 if lower.dim() == 2 else 0), L.ptr(t_rand),
+                                     C.c_float(scale), C.c_int(b), C.c_int(n), L.ptr(z), L.ptr(pts),
+                                     L.stream_handle()), "hn_sample_along_rays")
+    return z, pts
+
+
+def sample_pdf(weights, z, u, origins=None, directions=None, want_points=True, bins=None, merge=True):
+    """Inverse-CDF sampling at draws u (B,Nf).
+
+    Fused form (bins=None): `weights` = coarse weights (B,S); the kernel uses columns 1..S-2 and the
+    midpoints of z (B,S) as bin edges.  General form: `bins` (B,n+1) and `weights` (B,n) given.
+    Returns (z_all | None, pts | None, inds (B,Nf) int64, z_samples (B,Nf))."""
+    L.require_gpu(weights, u)
+    lib = L.load()
+    nf = u.shape[1]
+    dev = u.device
+    weights = weights.detach()
+    if weights.stride(-1) != 1:
+        weights = weights.contiguous()
+    if bins is None:
+        b, nc = z.shape
+        nb = nc - 2
+        w_ptr = C.c_void_p(weights.data_ptr() + 4)
+    else:
+        b, nb = weights.shape
+        bins = bins.detach().contiguous()
+        nc = z.shape[1] if z is not None else 0
+        w_ptr = L.ptr(weights)
+    if z is not None:
+        z = z.contiguous()
+    do_merge = merge and z is not None
+    want_points = want_points and do_merge and origins is not None
+    if want_points and (origins.stride(-1) != 1 or directions.stride(-1) != 1 or origins.stride(0) != directions.stride(0)):
+        origins, directions = origins.contiguous(), directions.contiguous()
+    z_all = torch.empty(b, nc + nf, dtype=torch.float32, device=dev) if do_merge else None
+    pts = torch.empty(b, nc + nf, 3, dtype=torch.float32, device=dev) if want_points else None
+    inds = torch.empty(b, nf, dtype=torch.int64, device=dev)
+    zs = torch.empty(b, nf, dtype=torch.float32, device=dev)
+    L.check(lib.hn_sample_pdf(w_ptr, C.c_int(weights.stride(0)), L.ptr(bins), C.c_int(nb),
+                              L.ptr(z if (do_merge or bins is None) else None), C.c_int(nc), L.ptr(u.contiguous()),
+                              L.ptr(origins if want_points else None), L.ptr(directions if want_points else None),
+                              C.c_int(origins.stride(0) if want_points else 0), C.c_int(b), C.c_int(nf),
+                              L.ptr(z_all), L.ptr(pts), L.ptr(inds), L.ptr(zs), L.stream_handle()), "hn_sample_pdf")
+    return z_all, pts, inds, zs
+
+
+# --------------------------------------------------------------------------------------------
+# compositing
+# --------------------------------------------------------------------------------------------
+class _CompositeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median):
+        L.require_gpu(rgb, raw, z, dirs)
+        lib = L.load()
+        b, s = z.shape
+        dev = z.device
+        rgb_c, raw_c, z_c = rgb.detach().contiguous(), raw.detach().reshape(b, s).contiguous(), z.contiguous()
+        noise_c = noise.detach().reshape(b, s).contiguous() if noise is not None else None
+        dirs_c = dirs if dirs.stride(-1) == 1 else dirs.contiguous()
+        warped_c = warped.detach().contiguous() if warped is not None else None
+        a = L.HnCompositeArgs()
+        a.variant, a.n_rays, a.n_samples = variant, b, s
+        a.white_bg, a.sample_at_infinity = int(white_bg), int(sample_at_infinity)
+        a.warped_ld = warped_c.shape[-1] if warped_c is not None else 0
+        a.rgb, a.raw, a.noise, a.z = rgb_c.data_ptr(), raw_c.data_ptr(), (noise_c.data_ptr() if noise_c is not None else 0), z_c.data_ptr()
+        a.dirs, a.ray_ld = dirs_c.data_ptr(), dirs_c.stride(0)
+        a.warped = warped_c.data_ptr() if warped_c is not None else 0
+        o_rgb = torch.empty(b, 3, dtype=torch.float32, device=dev)
+        o_depth = torch.empty(b, dtype=torch.float32, device=dev)
+        o_acc = torch.empty(b, dtype=torch.float32, device=dev)
+        o_w = torch.empty(b, s, dtype=torch.float32, device=dev)
+        o_md = torch.empty(b, dtype=torch.float32, device=dev) if want_median else None
+        o_mp = torch.empty(b, dtype=torch.float32, device=dev) if (want_median and warped is not None) else None
+        a.out_rgb, a.out_depth, a.out_acc, a.out_weights = o_rgb.data_ptr(), o_depth.data_ptr(), o_acc.data_ptr(), o_w.data_ptr()
+        a.out_med_depth = o_md.data_ptr() if o_md is not None else 0
+        a.out_med_points = o_mp.data_ptr() if o_mp is not None else 0
+        L.check(lib.hn_composite_forward(C.byref(a), L.stream_handle()), "hn_composite_forward")
+        ctx.saved = (rgb_c, raw_c, noise_c, z_c, dirs_c)
+        ctx.cfg = (variant, int(white_bg), int(sample_at_infinity), b, s)
+        ctx.raw_shape = raw.shape
+        outs = [o_rgb, o_depth, o_acc, o_w]
+        nd = []
+        if o_md is not None:
+            outs.append(o_md); nd.append(o_md)
+        if o_mp is not None:
+            outs.append(o_mp); nd.append(o_mp)
+        ctx.mark_non_differentiable(*nd)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_acc, g_w, *unused):
+        lib = L.load()
+        rgb_c, raw_c, noise_c, z_c, dirs_c = ctx.saved
+        variant, white_bg, sai, b, s = ctx.cfg
+        a = L.HnCompositeArgs()
+        a.variant, a.n_rays, a.n_samples, a.white_bg, a.sample_at_infinity = variant, b, s, white_bg, sai
+        a.rgb, a.raw, a.z = rgb_c.data_ptr(), raw_c.data_ptr(), z_c.data_ptr()
+        a.noise = noise_c.data_ptr() if noise_c is not None else 0
+        a.dirs, a.ray_ld = dirs_c.data_ptr(), dirs_c.stride(0)
+        keep = []
+        for name, g in (("g_rgb", g_rgb), ("g_depth", g_depth), ("g_acc", g_acc), ("g_weights", g_w)):
+            if g is not None:
+                g = g.contiguous(); keep.append(g)
+                setattr(a, name, g.data_ptr())
+        d_rgb = torch.empty_like(rgb_c)
+        d_raw = torch.empty_like(raw_c)
+        a.d_rgb, a.d_raw = d_rgb.data_ptr(), d_raw.data_ptr()
+        L.check(lib.hn_composite_backward(C.byref(a), L.stream_handle()), "hn_composite_backward")
+        return d_rgb, d_raw.view(ctx.raw_shape), None, None, None, None, None, None, None, None
+
+
+def composite(rgb, raw, noise, z, dirs, warped=None, variant=0, white_bg=False, sample_at_infinity=True,
+              want_median=True):
+    """Returns (rgb (B,3), depth (B), acc (B), weights (B,S)[, med_depth (B)[, med_points (B)]])."""
+    return _CompositeFn.apply(rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median)

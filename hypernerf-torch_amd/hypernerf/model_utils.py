@@ -1,0 +1,147 @@
+"""MI355X drop-in for the reference's `hypernerf/model_utils.py` (function names, arguments and
+return values as in the reference; file:line cited per function).  Device work goes through the
+C-ABI HIP kernels; the ray-dict helpers are host-side dict plumbing."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _lib as L
+from .. import functional as F
+from ..machine import AuxSpec, GradIn, Layer, OutSpec, Program, posenc_features, posenc_jax_features
+
+_BOUNDS_CACHE = {}
+
+
+def stratified_bounds(n: int, near: float, far: float, lindisp: bool, device):
+    """(lower, upper, z_lin) of the n stratified bins, computed once on the host with the same ATen
+    CPU ops as the reference (model_utils.py:25-33) so that z is bit-identical, then cached on `device`."""
+    key = (n, float(near), float(far), bool(lindisp), str(device))
+    if key not in _BOUNDS_CACHE:
+        t = torch.linspace(0., 1., n)
+        if not lindisp:
+            z = near * (1. - t) + far * t
+        else:
+            z = 1. / (1. / near * (1. - t) + 1. / far * t)
+        mids = .5 * (z[..., 1:] + z[..., :-1])
+        upper = torch.cat([mids, z[..., -1:]], dim=-1)
+        lower = torch.cat([z[..., :1], mids], dim=-1)
+        _BOUNDS_CACHE[key] = tuple(x.to(device) for x in (lower, upper, z))
+    return _BOUNDS_CACHE[key]
+
+
+def sample_along_rays(origins, directions, num_coarse_samples, near, far, use_stratified_sampling,
+                      use_linear_disparity, t_rand: Optional[torch.Tensor] = None):
+    """Stratified sampling along rays (reference: hypernerf/model_utils.py:6-41).
+    Returns (z_vals (B,N), points (B,N,3)).  `t_rand` overrides the torch.rand draw (tests)."""
+    L.require_gpu(origins, directions)
+    lower, upper, z_lin = stratified_bounds(num_coarse_samples, near, far, use_linear_disparity, origins.device)
+    b = origins.shape[0]
+    if use_stratified_sampling:
+        if t_rand is None:
+            t_rand = torch.rand([b, num_coarse_samples], device=origins.device)
+        return F.sample_along_rays(origins, directions, lower, upper, t_rand)
+    return F.sample_along_rays(origins, directions, z_lin, None, None)
+
+
+def volumetric_rendering(rgb, sigma, z_vals, dirs, use_white_background, sample_at_infinity=True, eps=1e-5):
+    """Alpha compositing of ACTIVATED densities (reference: hypernerf/model_utils.py:43-107).
+    The fused model path feeds raw densities + noise to the kernel; this entry point exists for API
+    parity and inverts nothing: it runs the legacy-variant kernel arithmetic on sigma directly."""
+    if eps != 1e-5:
+        raise NotImplementedError("eps is fixed to 1e-5 in the HIP kernel (the reference never changes it)")
+    outs = F.composite(rgb, sigma, None, z_vals, dirs, None, variant=2, white_bg=use_white_background,
+                       sample_at_infinity=sample_at_infinity, want_median=True)
+    return {"rgb": outs[0], "depth": outs[1], "med_depth": outs[4], "acc": outs[2], "weights": outs[3]}
+
+
+def _draws(b, n, stratified, device, u):
+    if u is not None:
+        return u
+    if stratified:
+        return torch.rand(b, n, device=device)
+    return torch.linspace(0, 1, n).to(device).expand(b, n).contiguous()
+
+
+def piecewise_constant_pdf(bins, weights, num_coarse_samples, use_stratified_sampling, u=None):
+    """Inverse-CDF samples (reference: hypernerf/model_utils.py:160-204).  bins (B,n+1), weights (B,n)."""
+    L.require_gpu(bins, weights)
+    u = _draws(weights.shape[0], num_coarse_samples, use_stratified_sampling, bins.device, u)
+    _, _, _, zs = F.sample_pdf(weights, None, u, bins=bins, merge=False)
+    return zs
+
+
+def sample_pdf(bins, weights, origins, directions, z_vals, num_coarse_samples, use_stratified_sampling, u=None):
+    """Hierarchical sampling: new samples merged into z_vals, sorted, + points
+    (reference: hypernerf/model_utils.py:206-232)."""
+    L.require_gpu(bins, weights, z_vals)
+    u = _draws(weights.shape[0], num_coarse_samples, use_stratified_sampling, bins.device, u)
+    z_all, pts, _, _ = F.sample_pdf(weights, z_vals, u, origins, directions, bins=bins)
+    return z_all, pts
+
+
+def get_posenc_ch_orig(in_ch, N_freq, log_scale=True):
+    """Channel count of posenc_orig (reference: hypernerf/model_utils.py:248-252), no device work."""
+    return in_ch * (1 + 2 * N_freq)
+
+
+def get_posenc_ch(in_ch, min_deg, max_deg, use_identity=False, alpha=None):
+    """Channel count of posenc (reference: hypernerf/model_utils.py:276-280)."""
+    return in_ch * (2 * (max_deg - min_deg) + (1 if use_identity else 0))
+
+
+def noise_regularize(raw, noise_std, use_stratified_sampling, noise=None):
+    """reference: hypernerf/model_utils.py:300-317.  (The fused path adds the noise inside the compositing
+    kernel; this helper keeps the reference's dict-in/dict-out contract.)"""
+    if (noise_std is not None) and noise_std > 0.0 and use_stratified_sampling:
+        if noise is None:
+            noise = torch.randn(raw['alpha'].shape, device=raw['alpha'].device, dtype=raw['alpha'].dtype) * noise_std
+        raw["alpha"] = raw["alpha"] + noise
+    return raw
+
+
+def prepare_ray_dict(rays: torch.Tensor) -> dict:
+    """(B,8|9) nerf_pl ray rows -> ray dict (reference: hypernerf/model_utils.py:365-404).
+    near/far columns are read and dropped, viewdirs is None, column 8 feeds all four metadata keys."""
+    use_meta = rays.shape[-1] == 9
+    if len(rays.shape) > 2:
+        rays = rays.view(-1, 8)
+    b = rays.shape[0]
+    idx = torch.ones((b, 1), dtype=torch.long, device=rays.device)
+    if use_meta:
+        idx = rays[:, 8].type(torch.long)
+    metadata = {k: idx.clone() for k in ('warp', 'camera', 'appearance', 'time')}
+    return {"origins": rays[:, :3], "directions": rays[:, 3:6], "viewdirs": None, "metadata": metadata}
+
+
+def extract_rays_batch(rays: dict, start: int, end: int, drop_last=True) -> dict:
+    """reference: hypernerf/model_utils.py:407-430."""
+    out = {}
+    for key, val in rays.items():
+        if key == 'metadata':
+            out[key] = {k: (v[start:end] if v is not None else None) for k, v in val.items()}
+        else:
+            out[key] = val[start:end] if val is not None else None
+    return out
+
+
+def append_batch(all_ret, batch) -> dict:
+    """reference: hypernerf/model_utils.py:432-442."""
+    for k, v in all_ret.items():
+        if v is None:
+            all_ret[k] = batch[k]
+        else:
+            for kk, vv in batch[k].items():
+                if vv is not None:
+                    all_ret[k][kk] = torch.cat([all_ret[k][kk], vv], dim=0)
+    return all_ret
+
+
+def concat_ray_batch(rays: list) -> dict:
+    """reference: hypernerf/model_utils.py:444-461."""
+    result = {k: None for k in rays[0].keys()}
+    for c in rays:
+        for k, v in c.items():
+            result[k] = v if result[k] is None else torch.cat([result[k], v], dim=0)
+    return result

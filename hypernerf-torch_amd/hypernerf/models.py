@@ -1,0 +1,342 @@
+"""MI355X drop-in for the reference's `hypernerf/models.py`: `NerfModel` and `filter_sigma`.
+
+Constructor arguments, attribute / sub-module names (=> `state_dict` keys), forward signature and the
+returned dict follow hypernerf/models.py:111-127, 673-780.  The render itself is a short sequence of
+fused HIP launches per level: sampling -> warp-field machine -> hyper-sheet machine -> template machine
+(encoders fused as generated features) -> compositing kernel; inverse-CDF sampling between the levels.
+"""
+from __future__ import annotations
+
+import functools
+from typing import Any, Callable, Dict, Mapping, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import functional as F
+from ..machine import AuxSpec, Program, copy_features, posenc_features
+from . import model_utils, modules, warping
+
+
+def filter_sigma(points, sigma, render_opts):
+    """Dust-threshold / bounding-box masking of densities (reference: hypernerf/models.py:35-63).
+    `render_opts` is None on every call the reference makes; the masks are plain tensor ops."""
+    if render_opts is None:
+        return sigma
+    if 'dust_threshold' in render_opts:
+        sigma = (sigma >= render_opts.get('dust_threshold', 0.0)) * sigma
+    if 'bounding_box' in render_opts:
+        xmin, xmax, ymin, ymax, zmin, zmax = render_opts['bounding_box']
+        m = ((points[..., 0] >= xmin) & (points[..., 0] <= xmax) & (points[..., 1] >= ymin)
+             & (points[..., 1] <= ymax) & (points[..., 2] >= zmin) & (points[..., 2] <= zmax))
+        sigma = m * sigma
+    return sigma
+
+
+class NerfModel(nn.Module):
+    """HyperNeRF model with coarse and fine template MLPs (reference: hypernerf/models.py:67-780)."""
+
+    def __init__(self, embeddings_dict, near: float = 0.0, far: float = 1.0, n_samples_coarse: int = 64,
+                 n_samples_fine: int = 128, noise_std: float = None, use_warp: bool = True,
+                 use_nerf_embed: bool = True, use_alpha_cond: bool = True, use_rgb_cond: bool = False,
+                 hyper_slice_method: str = None, hyper_slice_out_dim: int = 4, GLO_dim: int = 8,
+                 share_GLO: bool = True, xyz_fourier_dim: int = 10, hyper_fourier_dim: int = 6,
+                 view_fourier_dim: int = 4):
+        super().__init__()
+        self.embeddings_dict: Mapping[str, Sequence[int]] = embeddings_dict
+        self.near, self.far = near, far
+        self.use_viewdirs: bool = True
+        self.noise_std = noise_std
+        self.nerf_trunk_depth: int = 8
+        self.nerf_trunk_width: int = 256
+        self.nerf_rgb_branch_depth: int = 4
+        self.nerf_rgb_branch_width: int = 128
+        self.nerf_skips = [4, ]
+        self.num_coarse_samples = n_samples_coarse
+        self.num_fine_samples = n_samples_fine
+        self.use_stratified_sampling: bool = True
+        self.use_white_background: bool = False
+        self.use_linear_disparity: bool = False
+        self.use_sample_at_infinity: bool = True
+        self.spatial_point_min_deg, self.spatial_point_max_deg = 0, 10
+        self.hyper_point_min_deg, self.hyper_point_max_deg = 0, 4
+        self.viewdir_min_deg, self.viewdir_max_deg = 0, 4
+        self.use_posenc_identity: bool = True
+        self.alpha_channels: int = 1
+        self.rgb_channels: int = 3
+        self.activation = nn.ReLU()
+        self.norm_type: Optional[str] = None
+        self.sigma_activation = nn.Softplus()
+        self.rgb_activation = nn.Sigmoid()
+        if not share_GLO:
+            # the reference leaves nerf_use_warp_embed / hyper_use_warp_embed unbound (models.py:167-174,186)
+            raise UnboundLocalError("share_GLO=False is not constructible in the reference (models.py:167-186): "
+                                    "local variable 'nerf_use_warp_embed' referenced before assignment")
+        nerf_use_warp_embed = hyper_use_warp_embed = use_warp
+        self.use_nerf_embed: bool = use_nerf_embed
+        self.nerf_embed_cls: Callable[..., nn.Module] = functools.partial(modules.GLOEmbed, embedding_dim=GLO_dim)
+        self.nerf_embed_key: str = 'warp'
+        self.nerf_use_warp_embed: bool = nerf_use_warp_embed
+        self.use_alpha_condition: bool = use_alpha_cond
+        self.use_rgb_condition: bool = use_rgb_cond
+        self.hyper_slice_method = 'none' if hyper_slice_method is None else hyper_slice_method
+        self.hyper_embed_cls: Callable[..., nn.Module] = functools.partial(modules.GLOEmbed, embedding_dim=GLO_dim)
+        self.hyper_embed_key: str = 'time'
+        self.hyper_use_warp_embed: bool = hyper_use_warp_embed
+        self.hyper_sheet_mlp_cls: Callable[..., nn.Module] = modules.HyperSheetMLP
+        self.hyper_sheet_use_input_points: bool = True
+        self.hyper_sheet_out_dim: int = hyper_slice_out_dim
+        self.use_warp: bool = use_warp
+        self.warp_field_cls: Callable[..., nn.Module] = warping.TranslationField
+        self.warp_embed_cls: Callable[..., nn.Module] = functools.partial(modules.GLOEmbed, embedding_dim=GLO_dim)
+        self.warp_embed_key: str = 'time'
+        self.use_original_embed: bool = True
+        self.xyz_freq, self.dir_freq, self.hyper_freq = xyz_fourier_dim, view_fourier_dim, hyper_fourier_dim
+        self.GLO_dim = GLO_dim
+
+        if self.use_nerf_embed and not (self.use_rgb_condition or self.use_alpha_condition):
+            raise ValueError('Template metadata is enabled but none of the condition'
+                             'branches are.')
+        if self.use_nerf_embed:
+            self.nerf_embed = self.nerf_embed_cls(num_embeddings=max(self.embeddings_dict[self.nerf_embed_key]) + 1)
+        if self.use_warp:
+            self.warp_embed = self.warp_embed_cls(num_embeddings=max(self.embeddings_dict[self.warp_embed_key]) + 1)
+        if self.hyper_slice_method == 'axis_aligned_plane':
+            self.hyper_embed = self.hyper_embed_cls(
+                num_embeddings=max(self.embeddings_dict[self.hyper_embed_key]) + 1)
+        elif self.hyper_slice_method == 'bendy_sheet':
+            if not self.hyper_use_warp_embed:
+                self.hyper_embed = self.hyper_embed_cls(
+                    num_embeddings=max(self.embeddings_dict[self.hyper_embed_key]) + 1)
+            self.hyper_sheet_mlp = self.hyper_sheet_mlp_cls(out_ch=self.hyper_sheet_out_dim, in_ch_embed=GLO_dim)
+        if self.use_warp:
+            self.warp_field = warping.TranslationField(in_ch=3, in_ch_embed=GLO_dim)
+        self.alpha_default = 0.0
+
+        self.nerf_in_ch_pos = model_utils.get_posenc_ch_orig(3, self.xyz_freq)
+        self.nerf_cond_ch_rgb = model_utils.get_posenc_ch_orig(3, self.dir_freq)
+        self.hyper_feat_ch = model_utils.get_posenc_ch_orig(self.hyper_sheet_out_dim, self.hyper_freq)
+        if self.use_warp:
+            self.nerf_in_ch_pos += self.hyper_feat_ch
+        if self.use_rgb_condition:
+            self.nerf_cond_ch_rgb += GLO_dim
+
+        def make_mlp():
+            return modules.NerfMLP(in_ch=self.nerf_in_ch_pos, trunk_depth=self.nerf_trunk_depth,
+                                   trunk_width=self.nerf_trunk_width, rgb_branch_depth=self.nerf_rgb_branch_depth,
+                                   rgb_branch_width=self.nerf_rgb_branch_width, hidden_activation=self.activation,
+                                   norm=None, skips=self.nerf_skips, alpha_channels=self.alpha_channels,
+                                   rgb_channels=self.rgb_channels, rgb_activation=self.rgb_activation,
+                                   alpha_condition_dim=GLO_dim if self.use_nerf_embed else 0,
+                                   rgb_condition_dim=self.nerf_cond_ch_rgb)
+
+        nerf_mlps_coarse = make_mlp()
+        if self.num_fine_samples > 0:
+            nerf_mlps_fine = make_mlp()
+        else:
+            raise UnboundLocalError("n_samples_fine=0 is not constructible in the reference (models.py:292-309): "
+                                    "local variable 'nerf_mlps_fine' referenced before assignment; use the legacy "
+                                    "render_rays(N_importance=0) path for coarse-only rendering")
+        self.nerf_mlps_coarse = nerf_mlps_coarse
+        self.nerf_mlps_fine = nerf_mlps_fine
+        self._template_calls: Dict[Any, F.ProgramCall] = {}
+        self.precision: Optional[str] = None   # None = package default (functional.set_precision)
+
+    # ---- properties of the reference ---------------------------------------------------------
+    @property
+    def num_nerf_embeds(self):
+        return max(self.embeddings_dict[self.nerf_embed_key]) + 1
+
+    @property
+    def num_warp_embeds(self):
+        return max(self.embeddings_dict[self.warp_embed_key]) + 1
+
+    @property
+    def num_hyper_embeds(self):
+        return max(self.embeddings_dict[self.hyper_embed_key]) + 1
+
+    @property
+    def nerf_embeds(self):
+        return torch.tensor(self.embeddings_dict[self.nerf_embed_key])
+
+    @property
+    def warp_embeds(self):
+        return torch.tensor(self.embeddings_dict[self.warp_embed_key])
+
+    @property
+    def hyper_embeds(self):
+        return torch.tensor(self.embeddings_dict[self.hyper_embed_key])
+
+    @property
+    def has_hyper(self):
+        return self.hyper_slice_method != 'none'
+
+    @property
+    def has_hyper_embed(self):
+        return self.has_hyper
+
+    @property
+    def has_embeds(self):
+        return self.has_hyper_embed or self.use_warp or self.use_nerf_embed
+
+    def encode_hyper_embed(self, metadata):
+        if self.hyper_slice_method in ('axis_aligned_plane', 'bendy_sheet'):
+            if self.hyper_use_warp_embed:
+                return self.warp_embed(metadata[self.warp_embed_key])
+            return self.hyper_embed(metadata[self.hyper_embed_key])
+        raise RuntimeError(f'Unknown hyper slice method {self.hyper_slice_method}.')
+
+    def encode_nerf_embed(self, metadata):
+        return self.nerf_embed(metadata[self.nerf_embed_key])
+
+    def encode_warp_embed(self, metadata):
+        return self.warp_embed(metadata[self.warp_embed_key])
+
+    def apply_warp(self, points, warp_embed, extra_params):
+        return self.warp_field(points, self.warp_embed(warp_embed), extra_params)
+
+    # ---- template program ----------------------------------------------------------------------
+    def _template_call(self, level: str, n_point_ch: int, xyz_grad: bool, hyper_grad: bool) -> F.ProgramCall:
+        """Program of query_template (models.py:447-493): sources 0 = (warped) points (P, 3+H),
+        1 = viewdirs (B,3), 2 = template GLO embedding (B,G)."""
+        key = (level, n_point_ch, xyz_grad, hyper_grad)
+        call = self._template_calls.get(key)
+        if call is None:
+            m = self.nerf_mlps_fine if level == 'fine' else self.nerf_mlps_coarse
+            feats = posenc_features(0, range(3), self.xyz_freq, xyz_grad)
+            if n_point_ch > 3:
+                feats += posenc_features(0, range(3, n_point_ch), self.hyper_freq, hyper_grad)
+            if len(feats) != m.in_ch:
+                raise RuntimeError(f"template input has {len(feats)} channels, the MLP expects {m.in_ch} "
+                                   "(the reference shape-errors the same way, e.g. axis_aligned_plane needs "
+                                   "hyper_slice_out_dim == GLO_dim)")
+            rgb_feats = posenc_features(1, range(3), self.dir_freq, False) if self.use_viewdirs else []
+            alpha_aux = None
+            if self.use_nerf_embed:
+                if self.use_alpha_condition:
+                    alpha_aux = AuxSpec(copy_features(2, range(self.GLO_dim), True))
+                if self.use_rgb_condition:
+                    rgb_feats += copy_features(2, range(self.GLO_dim), True)
+            layers = modules.nerf_mlp_layers(m, f"nerf_mlps_{level}", AuxSpec(feats), alpha_aux,
+                                             AuxSpec(rgb_feats) if rgb_feats else None)
+            call = F.ProgramCall(Program(layers, name=f"template_{level}"), [False, True, True], [3, 1],
+                                 [("g", 0), ("g", 1), ("y", 0)])
+            self._template_calls[key] = call
+        return call
+
+    def get_condition_inputs(self, viewdirs, metadata, metadata_encoded=False):
+        """The GLO part of the template conditions (reference: models.py:404-445); view-direction encoding is
+        generated inside the template machine."""
+        if not self.use_nerf_embed:
+            return None
+        if metadata_encoded:
+            return metadata['encoded_nerf']
+        if self.hyper_use_warp_embed:
+            return self.warp_embed(metadata[self.warp_embed_key])
+        return self.nerf_embed(metadata[self.nerf_embed_key])
+
+    def map_points(self, points, warp_embed, hyper_embed, extra_params, use_warp=True,
+                   return_warp_jacobian=False, hyper_point_override=None):
+        """points (B,S,3), per-ray embeddings (B,G) -> warped points (B,S,3+H) (reference: models.py:545-581)."""
+        if not use_warp:
+            return points, None
+        if return_warp_jacobian:
+            raise NotImplementedError
+        if hyper_point_override is not None:
+            raise NotImplementedError('hyper_point_override is not implemented.')
+        spatial = self.warp_field.warp(points, warp_embed, extra_params) if self.use_warp else points
+        if self.hyper_slice_method == 'axis_aligned_plane':
+            hyper = hyper_embed[:, None, :].expand(points.shape[0], points.shape[1], hyper_embed.shape[-1])
+        elif self.hyper_slice_method == 'bendy_sheet':
+            hyper = self.hyper_sheet_mlp(points, hyper_embed)
+        else:
+            hyper = None
+        warped = spatial if hyper is None else torch.cat([spatial, hyper], dim=-1)
+        return warped, None
+
+    def render_samples(self, level, points, z_vals, directions, viewdirs, metadata, extra_params, use_warp=True,
+                       metadata_encoded=False, return_warp_jacobian=False, use_sample_at_infinity=False,
+                       render_opts=None, noise=None):
+        """One level of the render (reference: models.py:587-671)."""
+        if render_opts is not None:
+            raise NotImplementedError("render_opts: density filtering happens inside the fused compositing kernel "
+                                      "and is not wired yet (None on every call the reference makes)")
+        b, s = points.shape[0], points.shape[1]
+        out = {'points': points}
+        if use_warp:
+            warp_embed = metadata['encoded_warp'] if metadata_encoded else self.warp_embed(metadata[self.warp_embed_key])
+        else:
+            warp_embed = None
+        if self.has_hyper_embed:
+            if metadata_encoded:
+                hyper_embed = metadata['encoded_hyper']
+            elif self.hyper_use_warp_embed:
+                hyper_embed = warp_embed
+            else:
+                hyper_embed = self.hyper_embed(metadata[self.hyper_embed_key])
+        else:
+            hyper_embed = None
+        warped, _ = self.map_points(points, warp_embed, hyper_embed, extra_params, use_warp=use_warp,
+                                    return_warp_jacobian=return_warp_jacobian,
+                                    hyper_point_override=metadata.get('hyper_point'))
+        nerf_embed = self.get_condition_inputs(viewdirs, metadata, metadata_encoded)
+        n_ch = warped.shape[-1]
+        ge = torch.is_grad_enabled() and warped.requires_grad
+        call = self._template_call(level, n_ch, ge, ge and n_ch > 3)
+        rgb, alpha = F.run_program(call, [warped.reshape(b * s, n_ch), viewdirs if self.use_viewdirs else None,
+                                          nerf_embed], s, self.precision)
+        if noise is None and (self.noise_std is not None) and self.noise_std > 0.0 and self.use_stratified_sampling:
+            noise = torch.randn((b, s, 1), device=points.device, dtype=torch.float32) * self.noise_std
+        res = F.composite(rgb.view(b, s, 3), alpha.view(b, s), noise, z_vals, directions, warped, variant=0,
+                          white_bg=self.use_white_background, sample_at_infinity=use_sample_at_infinity,
+                          want_median=True)
+        out['warped_points'] = warped
+        out['rgb'], out['depth'], out['acc'], out['weights'], out['med_depth'] = res[0], res[1], res[2], res[3], res[4]
+        out['med_points'] = res[5].view(b, 1, 1)
+        return out
+
+    def forward(self, rays_dict: Dict[str, Any], extra_params: Dict[str, Any], metadata_encoded=False,
+                use_warp=True, return_points=False, return_weights=False, return_warp_jacobian=False, near=None,
+                far=None, use_sample_at_infinity=None, render_opts=None, deterministic=False,
+                rng: Optional[Dict[str, torch.Tensor]] = None):
+        """Returns {'coarse': {...}, 'fine': {...}} with keys points, warped_points, rgb, depth, med_depth, acc,
+        weights, med_points (reference: models.py:673-780).  `rng` optionally supplies the random draws
+        ('t_rand' (B,Nc), 'u' (B,Nf), 'noise_coarse' (B,Nc,1), 'noise_fine' (B,Nc+Nf,1), noise already scaled);
+        otherwise they are drawn from torch's generator in the reference's order."""
+        rng = rng or {}
+        use_warp = self.use_warp and use_warp
+        origins, directions, metadata = rays_dict['origins'], rays_dict['directions'], rays_dict['metadata']
+        L.require_gpu(origins, directions)
+        viewdirs = rays_dict['viewdirs'] if rays_dict.get('viewdirs') is not None else directions
+        near = self.near if near is None else near
+        far = self.far if far is None else far
+        if use_sample_at_infinity is None:
+            use_sample_at_infinity = self.use_sample_at_infinity
+        b = origins.shape[0]
+        z_vals, points = model_utils.sample_along_rays(origins, directions, self.num_coarse_samples, near, far,
+                                                       self.use_stratified_sampling, self.use_linear_disparity,
+                                                       t_rand=rng.get('t_rand'))
+        coarse = self.render_samples('coarse', points, z_vals, directions, viewdirs, metadata, extra_params,
+                                     use_warp=use_warp, metadata_encoded=metadata_encoded,
+                                     return_warp_jacobian=return_warp_jacobian,
+                                     use_sample_at_infinity=self.use_sample_at_infinity,
+                                     noise=rng.get('noise_coarse'))
+        out = {'coarse': coarse}
+        if self.num_fine_samples > 0:
+            u = rng.get('u')
+            if u is None:
+                if self.use_stratified_sampling:
+                    u = torch.rand(b, self.num_fine_samples, device=origins.device)
+                else:
+                    u = torch.linspace(0, 1, self.num_fine_samples).to(origins.device).expand(b, -1).contiguous()
+            z_fine, pts_fine, inds, _ = F.sample_pdf(coarse['weights'], z_vals, u, origins, directions)
+            fine = self.render_samples('fine', pts_fine, z_fine, directions, viewdirs, metadata, extra_params,
+                                       use_warp=use_warp, metadata_encoded=metadata_encoded,
+                                       return_warp_jacobian=return_warp_jacobian,
+                                       use_sample_at_infinity=use_sample_at_infinity, render_opts=render_opts,
+                                       noise=rng.get('noise_fine'))
+            out['fine'] = fine
+            # not part of the reference's return value: kept for tests / debugging
+            self.last_sampling = {'z_coarse': z_vals, 'z_fine': z_fine, 'inds': inds, 'u': u}
+        return out

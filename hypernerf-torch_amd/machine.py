@@ -1,0 +1,587 @@
+"""Host side of the MLP machine: turns a stack of nn.Linear layers into the op programs, weight
+packing tables and weight-gradient job lists that the HIP kernels consume (include/hn_kernels.h).
+
+Everything here is pure Python/numpy "compilation" — it runs on a machine without a GPU (and is
+unit-tested there, including a lane-level emulation of the device data layouts).  The launch
+methods require a ROCm device and the built extension; there is no CPU execution path.
+
+Vocabulary
+  layer    one nn.Linear (+activation) of a network.  Its input is [main | aux]:
+           main = the running activation (`cur` on the device), aux = GENERATED features
+           (positional encodings / per-ray conditions), described by an `AuxSpec`.
+  head     a layer with <= 4 outputs whose result leaves the machine (rgb, alpha, warp offset...).
+  program  the forward op list, the backward op list, the packing tables of both weight streams,
+           the stash/mask slot table and the dW job list of one fused network.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+CHUNK = L.HN_CHUNK_UNITS
+
+
+def pow2ceil(n: int) -> int:
+    p = 1
+    while p < n:
+        p *= 2
+    return p
+
+
+def mode_consts(mode: int):
+    """(units per 32x32 weight block, bytes per stashed 32x32 tile)."""
+    return (2, 2048) if mode == L.HN_MODE_BF16 else (4, 4096)
+
+
+# --------------------------------------------------------------------------------------------
+# network description
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Feature:
+    src: int            # source array index (0..3)
+    comp: int           # column of the source row
+    kind: int           # HN_FEAT_*
+    freq: float = 1.0
+    need_grad: bool = False
+
+
+def posenc_features(src: int, comps: Sequence[int], n_freqs: int, need_grad: bool = False) -> List[Feature]:
+    """Feature list of posenc_orig (hypernerf/model_utils.py:234-246) over `comps` of source `src`."""
+    out = [Feature(src, c, L.HN_FEAT_ID, 1.0, need_grad) for c in comps]
+    for k in range(n_freqs):
+        f = float(2.0 ** k)
+        out += [Feature(src, c, L.HN_FEAT_SIN, f, need_grad) for c in comps]
+        out += [Feature(src, c, L.HN_FEAT_COS, f, need_grad) for c in comps]
+    return out
+
+
+def posenc_jax_features(src: int, comps: Sequence[int], min_deg: int, max_deg: int, use_identity: bool,
+                        need_grad: bool = False) -> List[Feature]:
+    """Feature list of model_utils.posenc (hypernerf/model_utils.py:255-274), quirks included."""
+    steps = max_deg - min_deg
+    scales = (2.0 ** torch.linspace(float(min_deg), float(max_deg), steps=steps)).tolist()
+    out = [Feature(src, c, L.HN_FEAT_ID, 1.0, need_grad) for c in comps] if use_identity else []
+    for s in scales:
+        out += [Feature(src, c, L.HN_FEAT_SIN, float(np.float32(s)), need_grad) for c in comps]
+        out += [Feature(src, c, L.HN_FEAT_SINP, float(np.float32(s)), need_grad) for c in comps]
+    return out
+
+
+def copy_features(src: int, comps: Sequence[int], need_grad: bool = False) -> List[Feature]:
+    return [Feature(src, c, L.HN_FEAT_ID, 1.0, need_grad) for c in comps]
+
+
+@dataclass
+class AuxSpec:
+    feats: List[Feature]
+    feat_off: int = -1      # set by the program
+    slot: int = -1          # stash slot of the transposed features (set by the program)
+
+    @property
+    def n(self):
+        return len(self.feats)
+
+    @property
+    def groups(self):
+        return (len(self.feats) + 63) // 64
+
+
+@dataclass
+class OutSpec:
+    dst: int
+    col: int = 0
+    act: str = "none"                       # 'none' | 'sigmoid'
+    residual: Optional[Tuple[int, int]] = None   # (src index, col)
+    wide: bool = False
+
+
+@dataclass
+class GradIn:
+    src: int                # backward source index (4..7) holding d(out) per point
+    col: int = 0
+    sigmoid_y: Optional[Tuple[int, int]] = None   # (src index, col) of the forward output y
+
+
+@dataclass
+class Layer:
+    name: str
+    weight: torch.nn.Parameter
+    bias: Optional[torch.nn.Parameter]
+    main: Optional[Tuple[int, int]] = None      # (first column, n columns) of W applied to `cur`
+    aux: Optional[AuxSpec] = None
+    aux_c0: int = 0
+    act: str = "none"                           # 'none' | 'relu'
+    commit: bool = True
+    out: Optional[OutSpec] = None
+    grad_in: Optional[GradIn] = None
+    # filled by Program
+    prev: Optional["Layer"] = None
+    n_out: int = 0
+    nt: int = 0
+    w_id: int = -1
+    b_id: int = -1
+    bias_off: int = 0
+    mask_slot: int = -1
+    out_slot: int = -1      # stash of the output activation
+    dz_slot: int = -1       # stash of dZ
+
+
+@dataclass
+class SlotInfo:
+    kind: str       # 'stash' | 'mask'
+    nt: int         # tiles (stash) or dwords per lane (mask) per block
+
+
+class Program:
+    """Compiles a list of `Layer`s (forward order) into device tables for both numeric modes."""
+
+    def __init__(self, layers: List[Layer], n_src: int = 4, name: str = "mlp"):
+        self.name = name
+        self.layers = layers
+        self.n_src = n_src
+        self.params: List[torch.nn.Parameter] = []
+        self.slots: List[SlotInfo] = []
+        self.feat_table: List[Feature] = []
+        self.dsrc_map: Dict[Tuple[int, int], int] = {}
+        self.bias_len = 0
+        self._link()
+        self.fwd_ops = self._build_fwd_ops()
+        self.bwd_ops = self._build_bwd_ops()
+        self.tables: Dict[int, dict] = {}
+
+    # ---- structure ----------------------------------------------------------------------------
+    def _new_slot(self, kind: str, nt: int) -> int:
+        self.slots.append(SlotInfo(kind, nt))
+        if len(self.slots) > L.HN_MAX_SLOTS:
+            raise ValueError(f"{self.name}: more than {L.HN_MAX_SLOTS} stash/mask slots")
+        return len(self.slots) - 1
+
+    def _link(self):
+        cur: Optional[Layer] = None
+        pid = {}
+        for ly in self.layers:
+            ly.n_out = ly.weight.shape[0]
+            nt_valid = (ly.n_out + 31) // 32
+            ly.nt = pow2ceil(nt_valid)
+            if ly.nt > 8:
+                raise NotImplementedError(f"{ly.name}: width {ly.n_out} > 256 is not supported by the MLP machine")
+            if ly.out is not None and not ly.out.wide and ly.n_out > 4:
+                raise ValueError(f"{ly.name}: narrow OUT needs <= 4 outputs")
+            for prm in (ly.weight, ly.bias):
+                if prm is not None and id(prm) not in pid:
+                    pid[id(prm)] = len(self.params)
+                    self.params.append(prm)
+            ly.w_id = pid[id(ly.weight)]
+            ly.b_id = pid[id(ly.bias)] if ly.bias is not None else -1
+            ly.bias_off = self.bias_len
+            self.bias_len += 32 * ly.nt
+            if ly.main is not None:
+                if cur is None:
+                    raise ValueError(f"{ly.name}: main input without a running activation")
+                if ly.main[1] != cur.n_out:
+                    raise ValueError(f"{ly.name}: main width {ly.main[1]} != previous output {cur.n_out}")
+                ly.prev = cur
+            if ly.aux is not None:
+                if ly.aux.groups > L.HN_AUXG_MAX:
+                    raise NotImplementedError(f"{ly.name}: more than {64 * L.HN_AUXG_MAX} generated input features")
+                if ly.aux.feat_off < 0:
+                    ly.aux.feat_off = len(self.feat_table)
+                    pad = ly.aux.groups * 64 - ly.aux.n
+                    self.feat_table += list(ly.aux.feats) + [Feature(0, 0, L.HN_FEAT_ZERO)] * pad
+                    ly.aux.slot = self._new_slot("stash", 2 * ly.aux.groups)
+                    for ft in ly.aux.feats:
+                        if ft.need_grad and (ft.src, ft.comp) not in self.dsrc_map:
+                            self.dsrc_map[(ft.src, ft.comp)] = len(self.dsrc_map)
+            if ly.main is None and ly.aux is None:
+                raise ValueError(f"{ly.name}: layer without input")
+            total_in = (ly.main[1] if ly.main else 0) + (ly.aux.n if ly.aux else 0)
+            if total_in != ly.weight.shape[1]:
+                raise ValueError(f"{ly.name}: inputs {total_in} != in_features {ly.weight.shape[1]}")
+            if ly.commit:
+                cur = ly
+        if len(self.dsrc_map) > L.HN_DSRC_COMPS:
+            raise NotImplementedError(f"{self.name}: more than {L.HN_DSRC_COMPS} source-gradient components")
+        consumers = {id(l.prev) for l in self.layers if l.prev is not None}
+        for ly in self.layers:
+            ly.dz_slot = self._new_slot("stash", ly.nt)
+            if id(ly) in consumers:
+                ly.out_slot = self._new_slot("stash", ly.nt)
+            if ly.act == "relu" and (id(ly) in consumers or (ly.out is not None and ly.out.wide)):
+                ly.mask_slot = self._new_slot("mask", (ly.nt + 1) // 2)
+        last = self.layers[-1]
+        if last.out is None:
+            raise ValueError("the last layer of a program must produce an output")
+
+    @property
+    def n_dsrc(self):
+        return len(self.dsrc_map)
+
+    # ---- forward ops --------------------------------------------------------------------------
+    def _build_fwd_ops(self) -> np.ndarray:
+        ops = []
+        stashed_aux = set()
+        for ly in self.layers:
+            k32 = ly.prev.nt if ly.main is not None else 0
+            ng = ly.aux.groups if ly.aux is not None else 0
+            act = L.HN_ACT_RELU if ly.act == "relu" else L.HN_ACT_NONE
+            flags = 0 if ly.commit else L.HN_LAYER_NO_COMMIT
+            aux_slot = -1
+            if ly.aux is not None and id(ly.aux) not in stashed_aux:
+                aux_slot = ly.aux.slot
+                stashed_aux.add(id(ly.aux))
+            ops.append([L.HN_OP_LAYER, k32 | ng << 8 | ly.nt << 16 | act << 24 | flags << 28, ly.bias_off,
+                        ly.aux.feat_off if ly.aux is not None else 0, ly.mask_slot, ly.out_slot, aux_slot, 0])
+            if ly.out is not None:
+                o = ly.out
+                if o.wide:
+                    if not ly.commit:
+                        raise ValueError("wide outputs are read from the committed activation")
+                    ops.append([L.HN_OP_OUT_WIDE, o.dst, o.col, ly.n_out, ly.nt, 0, 0, 0])
+                else:
+                    ops.append([L.HN_OP_OUT, o.dst, o.col, ly.n_out, 1 if o.act == "sigmoid" else 0,
+                                o.residual[0] if o.residual else -1, o.residual[1] if o.residual else 0, 0])
+        return np.asarray(ops, dtype=np.int32)
+
+    # ---- backward ops -------------------------------------------------------------------------
+    def _aux_grad_groups(self, ly: Layer) -> List[int]:
+        if ly.aux is None:
+            return []
+        return [g for g in range(ly.aux.groups) if any(f.need_grad for f in ly.aux.feats[64 * g:64 * g + 64])]
+
+    def _build_bwd_ops(self) -> np.ndarray:
+        """Reverse walk.  Records, next to the ops, the weight blocks each op streams (self.bwd_plan)."""
+        ops, plan = [], []
+        items = self.layers
+
+        def emit_load(ly: Layer, to2: bool):
+            gi = ly.grad_in
+            if gi is None:
+                raise ValueError(f"{ly.name}: output layer without a gradient source")
+            if ly.out.wide:
+                ops.append([L.HN_BOP_LOAD_WIDE, gi.src, gi.col, ly.n_out, ly.nt, ly.mask_slot, 0, ly.dz_slot])
+            else:
+                sy = gi.sigmoid_y
+                ops.append([L.HN_BOP_LOAD, gi.src, gi.col, ly.n_out | (256 if to2 else 0), 1 if sy else 0,
+                            sy[0] if sy else 0, sy[1] if sy else 0, ly.dz_slot])
+            plan.append(("load",))
+
+        def emit_aux(ly: Layer, from2: bool):
+            for g in self._aux_grad_groups(ly):
+                k32 = 0 if from2 else ly.nt
+                ops.append([L.HN_BOP_AUX, k32 | (1 if from2 else 0) << 8 | 1 << 16, 0, ly.aux.feat_off + 64 * g,
+                            0, 0, 0, 0])
+                plan.append(("aux", ly, g, from2))
+
+        final = items[-1]
+        emit_load(final, False)
+        emit_aux(final, False)
+        consumer = final
+        while consumer.prev is not None:
+            P = consumer.prev
+            heads = [h for h in items if (not h.commit) and h.prev is P and h is not consumer and h is not final]
+            if len(heads) > 1:
+                raise NotImplementedError("more than one side head on one activation")
+            head = heads[0] if heads else None
+            if head is not None:
+                emit_load(head, True)
+                emit_aux(head, True)
+            mask = P.mask_slot if P.act == "relu" else -1
+            ops.append([L.HN_BOP_LAYER, consumer.nt | (1 if head else 0) << 8 | P.nt << 16, 0, 0, mask, P.dz_slot,
+                        0, 0])
+            plan.append(("layer", consumer, head, P))
+            consumer = P
+            emit_aux(P, False)
+        # every head must have been visited
+        seen = {id(p[1]) for p in plan if p[0] == "layer"} | {id(p[2]) for p in plan if p[0] == "layer" and p[2]}
+        for ly in items:
+            if not ly.commit and ly is not final and id(ly) not in seen:
+                raise NotImplementedError(f"{ly.name}: head without a later consumer of its input")
+        self.bwd_plan = plan
+        return np.asarray(ops, dtype=np.int32)
+
+    # ---- weight streams -----------------------------------------------------------------------
+    @staticmethod
+    def _take(ctr: int, n: int) -> Tuple[int, int]:
+        if (ctr % CHUNK) + n > CHUNK:
+            ctr = (ctr + CHUNK - 1) // CHUNK * CHUNK
+        return ctr, ctr + n
+
+    def _stream_fwd(self, mode: int):
+        u32, _ = mode_consts(mode)
+        units: Dict[int, tuple] = {}
+        ctr = 0
+
+        def put(pos, w_id, ld, r0, c0, r_end, c_end, transposed):
+            for u in range(u32):
+                k0 = 16 * u if mode == L.HN_MODE_BF16 else 4 * u
+                units[pos + u] = (w_id, ld, r0, c0, r_end, c_end, k0, transposed)
+
+        for ly in self.layers:
+            ld = ly.weight.shape[1]
+            for t in range(ly.nt):
+                if ly.main is not None:
+                    k32 = ly.prev.nt
+                    pos, ctr = self._take(ctr, k32 * u32)
+                    for k in range(k32):
+                        put(pos + k * u32, ly.w_id, ld, 32 * t, ly.main[0] + 32 * k, ly.n_out,
+                            ly.main[0] + ly.main[1], 0)
+                if ly.aux is not None:
+                    for g in range(ly.aux.groups):
+                        pos, ctr = self._take(ctr, 2 * u32)
+                        for kk in range(2):
+                            put(pos + kk * u32, ly.w_id, ld, 32 * t, ly.aux_c0 + 64 * g + 32 * kk, ly.n_out,
+                                ly.aux_c0 + ly.aux.n, 0)
+        return units, ctr
+
+    def _stream_bwd(self, mode: int):
+        u32, _ = mode_consts(mode)
+        units: Dict[int, tuple] = {}
+        ctr = 0
+
+        def put(pos, ly: Layer, r0, c0, c_end):
+            for u in range(u32):
+                k0 = 16 * u if mode == L.HN_MODE_BF16 else 4 * u
+                units[pos + u] = (ly.w_id, ly.weight.shape[1], r0, c0, ly.n_out, c_end, k0, 1)
+
+        for step in self.bwd_plan:
+            if step[0] == "layer":
+                _, consumer, head, P = step
+                for t in range(P.nt):
+                    pos, ctr = self._take(ctr, consumer.nt * u32)
+                    for k in range(consumer.nt):
+                        put(pos + k * u32, consumer, 32 * k, consumer.main[0] + 32 * t,
+                            consumer.main[0] + consumer.main[1])
+                    if head is not None:
+                        pos, ctr = self._take(ctr, u32)
+                        put(pos, head, 0, head.main[0] + 32 * t, head.main[0] + head.main[1])
+            elif step[0] == "aux":
+                _, ly, g, from2 = step
+                for tt in range(2):
+                    c0 = ly.aux_c0 + 64 * g + 32 * tt
+                    if not from2:
+                        pos, ctr = self._take(ctr, ly.nt * u32)
+                        for k in range(ly.nt):
+                            put(pos + k * u32, ly, 32 * k, c0, ly.aux_c0 + ly.aux.n)
+                    else:
+                        pos, ctr = self._take(ctr, u32)
+                        put(pos, ly, 0, c0, ly.aux_c0 + ly.aux.n)
+        return units, ctr
+
+    def _units_array(self, units: Dict[int, tuple], ctr: int) -> Tuple[np.ndarray, int]:
+        n_chunks = max(1, (ctr + CHUNK - 1) // CHUNK)
+        arr = np.zeros(n_chunks * CHUNK, dtype=L.PACK_UNIT_DT)
+        arr["w_id"] = -1
+        for pos, v in units.items():
+            arr[pos] = v
+        return arr, n_chunks
+
+    def host_tables(self, mode: int) -> dict:
+        """All position-independent tables of one numeric mode (numpy, cached)."""
+        if mode in self.tables:
+            return self.tables[mode]
+        fu, fc = self._stream_fwd(mode)
+        bu, bc = self._stream_bwd(mode)
+        fwd_units, fwd_chunks = self._units_array(fu, fc)
+        bwd_units, bwd_chunks = self._units_array(bu, bc)
+        bias = np.zeros(len(self.layers), dtype=L.PACK_BIAS_DT)
+        for i, ly in enumerate(self.layers):
+            bias[i] = (ly.b_id, ly.n_out if ly.b_id >= 0 else 0, ly.bias_off, 32 * ly.nt)
+        feat = np.zeros(max(1, len(self.feat_table)), dtype=L.FEAT_DT)
+        for i, f in enumerate(self.feat_table):
+            slot = self.dsrc_map.get((f.src, f.comp), -1) + 1 if f.need_grad else 0
+            feat[i] = (f.comp | f.src << 8 | f.kind << 12 | slot << 16, np.float32(f.freq))
+        t = dict(fwd_units=fwd_units, fwd_chunks=fwd_chunks, bwd_units=bwd_units, bwd_chunks=bwd_chunks,
+                 bias=bias, feat=feat)
+        self.tables[mode] = t
+        return t
+
+    # ---- per-size layout ------------------------------------------------------------------------
+    def layout(self, mode: int, n_points: int):
+        """Byte offsets of every slot for `n_points` points: (slot structs, stash bytes, mask bytes)."""
+        _, tile_bytes = mode_consts(mode)
+        nblk = (n_points + 31) // 32
+        offs, stash_b, mask_b = [], 0, 0
+        for s in self.slots:
+            if s.kind == "stash":
+                offs.append((stash_b, s.nt))
+                stash_b += nblk * s.nt * tile_bytes
+            else:
+                offs.append((mask_b, s.nt))
+                mask_b += nblk * s.nt * 64 * 4
+        return offs, stash_b, mask_b
+
+    def grad_offsets(self) -> Tuple[List[int], int]:
+        offs, tot = [], 0
+        for p in self.params:
+            offs.append(tot)
+            tot += (p.numel() + 3) // 4 * 4
+        return offs, tot
+
+    def wgrad_jobs(self, mode: int, n_points: int, target_chunks: int = 48) -> np.ndarray:
+        offs, _, _ = self.layout(mode, n_points)
+        goffs, _ = self.grad_offsets()
+        nblk = (n_points + 31) // 32
+        per = max(8, (nblk + target_chunks - 1) // target_chunks)
+        chunks = [(b, min(nblk, b + per)) for b in range(0, nblk, per)]
+        jobs = []
+        for ly in self.layers:
+            segs = []
+            if ly.main is not None:
+                segs.append((offs[ly.prev.out_slot][0], ly.prev.nt, ly.main[0], ly.main[1]))
+            if ly.aux is not None:
+                segs.append((offs[ly.aux.slot][0], 2 * ly.aux.groups, ly.aux_c0, ly.aux.n))
+            z_off = offs[ly.dz_slot][0]
+            n_tiles = (ly.n_out + 31) // 32
+            ld = ly.weight.shape[1]
+            first = True
+            for (x_off, x_nt, c0, ncols) in segs:
+                k_tiles = (ncols + 31) // 32
+                for nt0 in range(0, n_tiles, 2):
+                    for kt0 in range(0, k_tiles, 4):
+                        with_bias = first and kt0 == 0 and ly.b_id >= 0
+                        for (b0, b1) in chunks:
+                            jobs.append((z_off, x_off, ly.nt, x_nt, nt0, kt0, min(2, n_tiles - nt0),
+                                         min(4, k_tiles - kt0), b0, b1, goffs[ly.w_id], ld, 32 * nt0,
+                                         c0 + 32 * kt0, ly.n_out, c0 + ncols,
+                                         goffs[ly.b_id] if with_bias else -1, 0))
+                first = False
+        arr = np.zeros(len(jobs), dtype=L.DWJOB_DT)
+        for i, j in enumerate(jobs):
+            arr[i] = j
+        return arr
+
+
+# --------------------------------------------------------------------------------------------
+# runtime
+# --------------------------------------------------------------------------------------------
+class _DevTables:
+    pass
+
+
+class MlpRunner:
+    """Owns the device copies of a Program's tables and launches the three kernels."""
+
+    def __init__(self, program: Program):
+        self.prog = program
+        self._dev: Dict[Tuple[str, int], _DevTables] = {}
+        self._jobs: Dict[Tuple[str, int, int], Tuple[torch.Tensor, int]] = {}
+
+    def _tables(self, device, mode) -> _DevTables:
+        key = (str(device), mode)
+        d = self._dev.get(key)
+        if d is None:
+            ht = self.prog.host_tables(mode)
+            d = _DevTables()
+            d.units = L.to_device_bytes(np.concatenate([ht["fwd_units"], ht["bwd_units"]]), device)
+            d.n_fwd_units = len(ht["fwd_units"])
+            d.n_units = d.n_fwd_units + len(ht["bwd_units"])
+            d.fwd_chunks, d.bwd_chunks = ht["fwd_chunks"], ht["bwd_chunks"]
+            d.bias_desc = L.to_device_bytes(ht["bias"], device)
+            d.n_bias = len(ht["bias"])
+            d.feat = L.to_device_bytes(ht["feat"], device)
+            d.fwd_ops = L.to_device_bytes(self.prog.fwd_ops, device)
+            d.bwd_ops = L.to_device_bytes(self.prog.bwd_ops, device)
+            d.wstream = torch.empty(d.n_units * 1024, dtype=torch.uint8, device=device)
+            d.bias = torch.zeros(max(32, self.prog.bias_len), dtype=torch.float32, device=device)
+            d.ptr_key, d.ptrs, d.pack_key = None, None, None
+            self._dev[key] = d
+        return d
+
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.prog.params)
+
+    def pack(self, device, mode):
+        """(Re)pack both weight streams if any parameter changed since the last pack."""
+        d = self._tables(device, mode)
+        key = self._param_key()
+        if d.pack_key == key:
+            return d
+        for p in self.prog.params:
+            L.require_gpu(p)
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise L.HnError("parameters must be contiguous fp32 tensors")
+        pk = tuple(p.data_ptr() for p in self.prog.params)
+        if d.ptr_key != pk:
+            d.ptrs = torch.tensor(list(pk), dtype=torch.int64).to(device)
+            d.ptr_key = pk
+        lib = L.load()
+        L.check(lib.hn_pack_units(C.c_int(mode), L.ptr(d.units), C.c_int(d.n_units), L.ptr(d.ptrs), L.ptr(d.wstream),
+                                  L.ptr(d.bias_desc), C.c_int(d.n_bias), L.ptr(d.bias), L.stream_handle()),
+                "hn_pack_units")
+        d.pack_key = key
+        return d
+
+    def _args(self, d, mode, n_points, samples_per_ray, training, ops, n_ops, wstream_ptr, n_chunks, srcs, dsts,
+              stash, masks, dsrc):
+        a = L.HnMlpArgs()
+        a.mode, a.n_points, a.samples_per_ray, a.training = mode, n_points, samples_per_ray, int(training)
+        a.n_ops, a.n_chunks, a.n_dsrc = n_ops, n_chunks, self.prog.n_dsrc if dsrc is not None else 0
+        a.ops, a.wstream, a.bias, a.feat = ops.data_ptr(), wstream_ptr, d.bias.data_ptr(), d.feat.data_ptr()
+        a.stash = stash.data_ptr() if stash is not None else 0
+        a.masks = masks.data_ptr() if masks is not None else 0
+        a.dsrc = dsrc.data_ptr() if dsrc is not None else 0
+        for i, s in enumerate(srcs):
+            if s is None:
+                continue
+            t, per_ray = s
+            L.require_gpu(t)
+            if t.dtype != torch.float32 or t.stride(-1) != 1:
+                raise L.HnError("sources must be fp32 with unit inner stride")
+            a.src[i].ptr, a.src[i].ld, a.src[i].per_ray = t.data_ptr(), t.stride(-2) if t.dim() > 1 else 1, int(per_ray)
+        for i, t in enumerate(dsts):
+            if t is None:
+                continue
+            L.require_gpu(t)
+            a.dst[i].ptr, a.dst[i].ld = t.data_ptr(), t.stride(-2) if t.dim() > 1 else 1
+        offs, _, _ = self.prog.layout(mode, n_points)
+        for i, (off, nt) in enumerate(offs):
+            a.slots[i].off, a.slots[i].nt = off, nt
+        return a
+
+    def forward(self, mode, n_points, samples_per_ray, srcs, dsts, training: bool):
+        """Launch the forward machine.  Returns (stash, masks) (None, None when not training)."""
+        device = dsts[0].device if dsts and dsts[0] is not None else srcs[0][0].device
+        d = self.pack(device, mode)
+        stash = masks = None
+        if training:
+            _, sb, mb = self.prog.layout(mode, n_points)
+            stash = torch.empty(max(sb, 16), dtype=torch.uint8, device=device)
+            masks = torch.empty(max(mb, 16), dtype=torch.uint8, device=device)
+        a = self._args(d, mode, n_points, samples_per_ray, training, d.fwd_ops, len(self.prog.fwd_ops),
+                       d.wstream.data_ptr(), d.fwd_chunks, srcs, dsts, stash, masks, None)
+        L.check(L.load().hn_mlp_forward(C.byref(a), L.stream_handle()), f"hn_mlp_forward[{self.prog.name}]")
+        return stash, masks
+
+    def backward(self, mode, n_points, samples_per_ray, srcs, stash, masks):
+        """Launch backward-data then the weight-gradient kernel.
+        Returns (dsrc [P, n_dsrc] or None, flat fp32 gradient buffer)."""
+        device = stash.device
+        d = self.pack(device, mode)
+        dsrc = None
+        if self.prog.n_dsrc > 0:
+            dsrc = torch.empty(n_points, self.prog.n_dsrc, dtype=torch.float32, device=device)
+        a = self._args(d, mode, n_points, samples_per_ray, True, d.bwd_ops, len(self.prog.bwd_ops),
+                       d.wstream.data_ptr() + d.n_fwd_units * 1024, d.bwd_chunks, srcs, [], stash, masks, dsrc)
+        lib = L.load()
+        L.check(lib.hn_mlp_backward(C.byref(a), L.stream_handle()), f"hn_mlp_backward[{self.prog.name}]")
+        jkey = (str(device), mode, n_points)
+        if jkey not in self._jobs:
+            jobs = self.prog.wgrad_jobs(mode, n_points)
+            self._jobs[jkey] = (L.to_device_bytes(jobs, device), len(jobs))
+        jobs_dev, n_jobs = self._jobs[jkey]
+        _, gtot = self.prog.grad_offsets()
+        grads = torch.zeros(gtot, dtype=torch.float32, device=device)
+        L.check(lib.hn_mlp_wgrad(C.c_int(mode), L.ptr(jobs_dev), C.c_int(n_jobs), L.ptr(stash), L.ptr(grads),
+                                 L.stream_handle()), f"hn_mlp_wgrad[{self.prog.name}]")
+        return dsrc, grads
+
+    def split_grads(self, flat: torch.Tensor) -> List[torch.Tensor]:
+        offs, _ = self.prog.grad_offsets()
+        return [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.prog.params)]

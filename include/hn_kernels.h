@@ -1,0 +1,256 @@
+/*
+ * hn_kernels.h — C ABI of the MI355X (gfx950) HyperNeRF render hot path.
+ *
+ * The reference (songrise/HyperNeRF-torch) has no FFI/plugin boundary: its hot path is plain
+ * PyTorch behind Python call signatures.  This header is the boundary a native
+ * replacement needs: plain pointers + sizes, caller-allocated buffers, launch on the caller's
+ * stream, int status (0 = ok, <0 = argument error, >0 = hipError_t).  No allocation, no host
+ * synchronisation, no global mutable state inside — every entry point is re-entrant and
+ * graph-capturable.  Random draws (t_rand, u, noise) are explicit input buffers.
+ *
+ * Each entry point cites the reference code it replaces (paths relative to the reference repo).
+ *
+ * The dense part of the path (modules.MLP and everything built from it) runs on a small
+ * "MLP machine": per 32-point block a wavefront keeps the hidden activation in registers with
+ * points on the lane axis and features on the register axis, so an MFMA accumulator tile is the
+ * next layer's B operand without touching LDS; weights are pre-packed into MFMA A-fragment order
+ * (hn_pack_units) and streamed through LDS by LDS-DMA.  The host describes a network as a short
+ * program of ops (HN_OP_* / HN_BOP_*), so every constructor configuration of the reference's
+ * modules maps onto the same three kernels (forward, backward-data, weight-gradient).
+ */
+#ifndef HN_KERNELS_H
+#define HN_KERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hnStream_t; /* hipStream_t */
+
+#define HN_VERSION 100
+
+/* numeric modes of the MLP machine */
+#define HN_MODE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode (<=1e-4 vs oracle) */
+#define HN_MODE_BF16 1 /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate, throughput mode   */
+
+#define HN_MAX_SRC 8 /* forward: feature sources 0-3 ; backward: 0-3 same, 4-7 gradient inputs */
+#define HN_MAX_DST 4
+#define HN_MAX_SLOTS 64
+#define HN_OP_WORDS 8
+#define HN_CHUNK_UNITS 32 /* weight stream is consumed in chunks of 32 units of 1 KiB */
+#define HN_DSRC_COMPS 16  /* per-point source-gradient accumulators in the backward machine */
+
+/* ---- forward ops: word0 = opcode ---------------------------------------------------------
+ * Machine state per wavefront (32 points): `cur` = current hidden activation (<= 256 features) as
+ * MFMA B fragments, `accL` = the last accumulator tile (pre-activation) for the OUT ops.
+ *
+ * HN_OP_LAYER: one Linear (+bias, +activation).  Input features = [cur (32*K32) | nG groups of 64
+ * GENERATED features (feature table)].  For every 32-row output tile t < NT, one at a time:
+ *     acc = bias[32t..] + W[32t.., main] . cur + W[32t.., aux] . generated ;  nxt[t] = act(acc)
+ * then cur <- nxt (unless NO_COMMIT).  Weight-stream order per tile: K32 main blocks, then 2*nG
+ * aux blocks (a "block" = 32 out x 32 in).  Training: relu bit mask -> mask_slot, transposed
+ * activation -> stash_out (X of the next layer's dW), transposed generated features -> stash_aux. */
+#define HN_OP_LAYER 1    /* w1 = K32 | nG<<8 | NT<<16 | act<<24 | flags<<28 ; w2=bias_off w3=feat_off
+                            w4=mask_slot|-1 w5=stash_out|-1 w6=stash_aux|-1                          */
+#define HN_ACT_NONE 0
+#define HN_ACT_RELU 1
+#define HN_LAYER_NO_COMMIT 1 /* flags bit0: leave cur untouched (head layers read by an OUT op)      */
+/* dst[w1][p*ld + w2 + i] = act(accL row i) (+ residual src[w5][.. + w6 + i]), i < w3 <= 4           */
+#define HN_OP_OUT 4      /* w1=dst  w2=col  w3=n  w4=act(0 none,1 sigmoid)  w5=res_src|-1  w6=res_col */
+#define HN_OP_OUT_WIDE 5 /* w1=dst  w2=col  w3=n (<= 32*NT)  w4=NT   (cur features -> dst)            */
+
+/* ---- backward ops ---------------------------------------------------------------------------
+ * State: `cur` = dZ of the layer being differentiated, `cur2` = a second, 32-feature dZ (heads).
+ * HN_BOP_LAYER: dH = W^T . dZ for every 32-feature tile t < NT of the layer INPUT, one at a time:
+ *     acc = W[:, 32t..]^T . cur (32*K32 dZ features) + W2[:, 32t..]^T . cur2 (if K32b) ;
+ *     nxt[t] = acc * relu'(mask) ; then cur <- nxt.  Stream order per tile: K32 blocks, K32b blocks. */
+#define HN_BOP_LOAD 1      /* w1=src w2=col w3=n(<=4) w4=act'(1 sigmoid: y from src w5 col w6)
+                              w7=stash|-1 ; w3 bit 8 set: destination cur2 instead of cur          */
+#define HN_BOP_LOAD_WIDE 2 /* w1=src  w2=col  w3=n  w4=NT  w5=relu mask slot|-1  w7=stash_slot|-1      */
+#define HN_BOP_LAYER 3     /* w1 = K32 | K32b<<8 | NT<<16 ; w4=mask_slot|-1 w5=stash|-1            */
+/* gradient w.r.t. GENERATED input features: per 32-feature tile of nG*64 features,
+ * tmp = W_aux^T . (cur | cur2), then the chain rule through the feature table into the per-point
+ * source-gradient accumulators (LDS), written to `dsrc` at the end of the program.               */
+#define HN_BOP_AUX 4       /* w1 = K32 | K32b<<8 | nG<<16 ; w3=feat_off                            */
+
+/* feature table entry (8 bytes).  value(p) = kind(freq * x[src][p or ray(p)][comp]) */
+typedef struct {
+  int32_t packed; /* bits 0-7 comp | 8-11 src | 12-15 kind | 16-23 grad slot + 1 (0 = no gradient) */
+  float freq;
+} HnFeat;
+#define HN_FEAT_ZERO 0
+#define HN_FEAT_ID 1
+#define HN_FEAT_SIN 2  /* sin(freq*x)                                                        */
+#define HN_FEAT_COS 3  /* cos(freq*x)                                                        */
+#define HN_FEAT_SINP 4 /* sin(freq*x + 0.5*3.1415926): the reference's cosine in model_utils.posenc:262 */
+
+typedef struct {
+  const float* ptr;
+  int32_t ld;      /* row stride in floats */
+  int32_t per_ray; /* 1: row index = point / samples_per_ray, 0: row index = point */
+} HnSrc;
+
+typedef struct {
+  float* ptr;
+  int32_t ld;
+  int32_t pad;
+} HnDst;
+
+typedef struct {
+  uint64_t off; /* byte offset from the stash / mask base for block 0 */
+  int32_t nt;   /* stash: 32-feature tiles per block ; mask: dwords per lane per block */
+  int32_t pad;
+} HnSlot;
+
+/* One launch of the forward or backward machine over n_points points.
+ * Replaces, per launch: modules.MLP.forward (hypernerf/modules.py:116-127) and the modules
+ * composed from it — TranslationField.warp (hypernerf/warping.py:90-96), HyperSheetMLP.forward
+ * (hypernerf/modules.py:331-337), NerfMLP.forward (hypernerf/modules.py:266-298), the encoders
+ * model_utils.posenc_orig / posenc (hypernerf/model_utils.py:234-274) fused as generated input
+ * features, legacy models/nerf.py:83-124 — and, for the backward machine, their autograd. */
+typedef struct {
+  int32_t mode;            /* HN_MODE_* */
+  int32_t n_points;        /* P */
+  int32_t samples_per_ray; /* S (ray(p) = p / S) */
+  int32_t training;        /* 0: skip mask/stash writes */
+  int32_t n_ops;
+  int32_t n_chunks; /* weight stream length in chunks of HN_CHUNK_UNITS KiB */
+  int32_t n_dsrc;   /* backward: number of source-gradient components written per point (<=16) */
+  int32_t pad0;
+  const int32_t* ops;    /* device, n_ops * HN_OP_WORDS */
+  const void* wstream;   /* device, packed weight units (hn_pack_units) */
+  const float* bias;     /* device, packed biases (fp32) */
+  const HnFeat* feat;    /* device, feature table */
+  void* stash;           /* device, activation / dZ stash (training) */
+  uint32_t* masks;       /* device, relu bit masks (training) */
+  float* dsrc;           /* backward: [P][n_dsrc] source gradients */
+  HnSrc src[HN_MAX_SRC]; /* forward: feature sources ; backward: same + gradient inputs */
+  HnDst dst[HN_MAX_DST];
+  HnSlot slots[HN_MAX_SLOTS];
+} HnMlpArgs;
+
+/* weight packing: one descriptor per 1-KiB unit of a stream */
+typedef struct {
+  int32_t w_id;       /* index into the pointer table ; -1 = all-zero unit */
+  int32_t ld;         /* source row stride (in_features) */
+  int32_t r0, c0;     /* source row / col of A-operand (row 0, k 0) */
+  int32_t r_end;      /* valid source rows  [.., r_end)  */
+  int32_t c_end;      /* valid source cols  [.., c_end)  */
+  int32_t k0;         /* first k feature of this unit within the 32-block (bf16: 0/16 ; f32: 4*g steps) */
+  int32_t transposed; /* 0: A[row][k] = W[r0+row][c0+k] ; 1: A[row][k] = W[r0+k][c0+row] */
+} HnPackUnit;
+
+typedef struct {
+  int32_t w_id; /* bias vector id or -1 */
+  int32_t n;    /* valid length */
+  int32_t off;  /* destination offset (floats) */
+  int32_t len;  /* padded length */
+} HnPackBias;
+
+/* weight-gradient job: one wavefront accumulates  dW[n-tiles x k-tiles] over a block range */
+typedef struct {
+  uint64_t z_off, x_off;  /* stash byte offsets (block 0) of dZ and X slots */
+  int32_t z_nt, x_nt;     /* tiles per block of the two slots */
+  int32_t z_t0, x_t0;     /* first tile used */
+  int32_t n_nt, n_kt;     /* 1..2 n-tiles, 0..4 k-tiles */
+  int32_t blk0, blk1;     /* block range [blk0, blk1) */
+  int32_t w_off;          /* offset (floats) of the gradient matrix (row-major (out,in)) in the flat
+                             gradient buffer, -1 = none */
+  int32_t ld;
+  int32_t r0, c0;         /* destination row / col of (tile 0, tile 0) */
+  int32_t r_end, c_end;   /* valid bounds */
+  int32_t b_off;          /* offset of the bias gradient or -1 (db[r] += sum_p dZ[p][r]) */
+  int32_t pad;
+} HnDwJob;
+
+int hn_version(void);
+/* sizeof() of the ABI structs, in the order HnMlpArgs, HnPackUnit, HnPackBias, HnDwJob,
+ * HnCompositeArgs, HnFeat, HnSlot, HnSrc — lets a foreign-language binding verify its mirror. */
+int hn_abi_sizes(int32_t* out, int n);
+
+/* Pack fp32 nn.Linear weights (row-major (out,in), reference layout hypernerf/modules.py:99-102)
+ * into MFMA A-fragment order.  ptrs: device array of source pointers. */
+int hn_pack_units(int mode, const HnPackUnit* units_dev, int n_units, const float* const* ptrs_dev,
+                  void* wstream_dev, const HnPackBias* bias_dev, int n_bias, float* bias_out_dev,
+                  hnStream_t stream);
+
+int hn_mlp_forward(const HnMlpArgs* args, hnStream_t stream);
+int hn_mlp_backward(const HnMlpArgs* args, hnStream_t stream);
+
+/* dW/db for every Linear of a program: grads (fp32) are ACCUMULATED with float atomics. */
+int hn_mlp_wgrad(int mode, const HnDwJob* jobs_dev, int n_jobs, const void* stash_dev,
+                 float* grad_base_dev, hnStream_t stream);
+
+/* ---- per-ray kernels --------------------------------------------------------------------- */
+
+/* Stratified coarse samples + points.  model_utils.sample_along_rays (hypernerf/model_utils.py:6-41),
+ * legacy models/rendering.py:189-207.  lower/upper: (n) per-bin bounds or (B,n) when per_ray_bounds;
+ * t_rand (B,n) or NULL (z = lower).  Unfused fp32 ops in the reference's order (bit-exact z). */
+int hn_sample_along_rays(const float* origins, const float* dirs, int ray_ld, const float* lower,
+                         const float* upper, int per_ray_bounds, const float* t_rand, float scale,
+                         int n_rays, int n, float* z_out, float* pts_out, hnStream_t stream);
+
+/* Softplus/relu density + alpha compositing.  model_utils.volumetric_rendering
+ * (hypernerf/model_utils.py:43-107, 319-362) with NerfModel.query_template's noise+softplus
+ * (hypernerf/models.py:485-491); legacy variant models/rendering.py:144-170.
+ * variant 0 = hypernerf (softplus, last dist 1e7|1e-7, eps 1e-5 in cumprod, acc drops last sample)
+ * variant 1 = legacy    (relu(sigma+noise), last dist 1e10, eps 1e-10, opacity = full sum)
+ * variant 2 = hypernerf constants, `raw` is an already activated density (stand-alone
+ *             model_utils.volumetric_rendering) */
+typedef struct {
+  int32_t variant, n_rays, n_samples, white_bg, sample_at_infinity, warped_ld, pad0, pad1;
+  const float* rgb;    /* (B,S,3) */
+  const float* raw;    /* (B,S) raw density */
+  const float* noise;  /* (B,S) already scaled, or NULL */
+  const float* z;      /* (B,S) */
+  const float* dirs;   /* (B,3) row stride ray_ld */
+  int64_t ray_ld;
+  const float* warped; /* (B,S,warped_ld) or NULL */
+  float* out_rgb;      /* (B,3) */
+  float* out_depth;    /* (B) */
+  float* out_acc;      /* (B) */
+  float* out_weights;  /* (B,S) */
+  float* out_med_depth;  /* (B) or NULL */
+  float* out_med_points; /* (B) or NULL */
+  /* backward only */
+  const float* g_rgb;     /* (B,3) or NULL */
+  const float* g_depth;   /* (B) or NULL */
+  const float* g_acc;     /* (B) or NULL */
+  const float* g_weights; /* (B,S) or NULL */
+  float* d_rgb;           /* (B,S,3) */
+  float* d_raw;           /* (B,S) */
+} HnCompositeArgs;
+int hn_composite_forward(const HnCompositeArgs* a, hnStream_t stream);
+int hn_composite_backward(const HnCompositeArgs* a, hnStream_t stream);
+
+/* Inverse-CDF hierarchical sampling + merge-sort + points.  model_utils.piecewise_constant_pdf /
+ * sample_pdf (hypernerf/model_utils.py:160-232) == legacy models/rendering.py:14-55,225-233.
+ * weights: first used column of a (B, *) array with row stride w_ld, n_bins columns used;
+ * bins: (B, n_bins+1) bin edges, or NULL = midpoints of z (then n_bins == n_coarse-2, and the caller
+ * passes weights+1, i.e. coarse weights[:, 1:-1], as hypernerf/models.py:752-755 does);
+ * z: (B, n_coarse) sorted coarse depths merged with the new samples, or NULL = no merge;
+ * u: (B, n_fine).  Outputs (each may be NULL): z_all (B, n_coarse+n_fine) sorted, pts (.., 3),
+ * inds (B, n_fine) int64 = searchsorted(cdf, u, right=True), z_samples (B, n_fine) unsorted.
+ * The pdf normaliser is an fp64 sequential sum rounded once to fp32 and the cdf an fp64 sequential
+ * prefix sum rounded per entry (== CPU torch.cumsum), so indices are bit-reproducible. */
+int hn_sample_pdf(const float* weights, int w_ld, const float* bins, int n_bins, const float* z,
+                  int n_coarse, const float* u, const float* origins, const float* dirs, int ray_ld,
+                  int n_rays, int n_fine, float* z_all, float* pts, int64_t* inds, float* z_samples,
+                  hnStream_t stream);
+
+/* GLO embedding lookup (modules.GLOEmbed, hypernerf/modules.py:155-167) and its gradient:
+ * d_table[idx[b]] += sum_s d_embed[b, s, col0 : col0+dim]. */
+int hn_embed_gather(const float* table, const int64_t* idx, int n_rays, int dim, int n_rows,
+                    float* out, hnStream_t stream);
+int hn_embed_backward(const float* d_points, int ld, int col0, const int64_t* idx, int n_rays,
+                      int n_samples, int dim, int n_rows, float* d_table, hnStream_t stream);
+
+/* Debug/probe: runs one MFMA of each kind on identifiable data (layout self-test on real hardware). */
+int hn_probe_mfma(float* out_bf16_acc, float* out_f32_acc, float* out_glds, hnStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

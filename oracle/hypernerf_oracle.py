@@ -124,7 +124,8 @@ def hyper_sheet(p: Params, prefix: str, pts: Tensor, embed: Tensor) -> Tensor:
 
 
 def nerf_mlp(p: Params, prefix: str, x: Tensor, alpha_cond: Optional[Tensor],
-             rgb_cond: Optional[Tensor], trunk_depth: int = 8, rgb_depth: int = 4):
+             rgb_cond: Optional[Tensor], trunk_depth: int = 8, rgb_depth: int = 4,
+             skips: Sequence[int] = (4,)):
     """NerfMLP.forward, hypernerf/modules.py:266-298.
 
     trunk MLP (logit 256->256 + ReLU) -> bottleneck Linear (no activation) ->
@@ -132,14 +133,14 @@ def nerf_mlp(p: Params, prefix: str, x: Tensor, alpha_cond: Optional[Tensor],
     sigmoid inside (hypernerf/models.py:164,288).  Conditions are (B,C), repeated over S.
     """
     s = x.shape[1]
-    t = mlp(p, f"{prefix}.trunk_mlp", x, depth=trunk_depth, out_act="relu")
+    t = mlp(p, f"{prefix}.trunk_mlp", x, depth=trunk_depth, skips=skips, out_act="relu")
     b = _linear(p, f"{prefix}.bottleneck_mlp", t)
     a_in = b if alpha_cond is None else torch.cat(
         [b, alpha_cond[:, None, :].expand(-1, s, -1)], dim=-1)
     alpha = _linear(p, f"{prefix}.alpha_mlp", a_in)
     r_in = b if rgb_cond is None else torch.cat(
         [b, rgb_cond[:, None, :].expand(-1, s, -1)], dim=-1)
-    rgb = mlp(p, f"{prefix}.rgb_mlp", r_in, depth=rgb_depth, out_act="sigmoid")
+    rgb = mlp(p, f"{prefix}.rgb_mlp", r_in, depth=rgb_depth, skips=skips, out_act="sigmoid")
     return rgb, alpha
 
 

@@ -1,0 +1,451 @@
+"""Lane-level numpy emulation of the MLP machine (hn_mlp.hip) — test infrastructure.
+
+It re-implements, with the MFMA operand/accumulator lane maps documented for gfx950, exactly what
+the device code does with the HOST tables (packing descriptors, op lists, slot layout, dW jobs):
+weight packing, the forward machine, the transposed stashes, the backward-data machine and the
+weight-gradient kernel.  Values stay in float64 (no bf16 rounding) so results must equal a plain
+numpy MLP to ~1e-12: any layout / ordering mistake in the host compiler shows up as O(1) error
+without needing a GPU.
+"""
+import numpy as np
+
+CHUNK = 32
+LANES = np.arange(64)
+R = LANES & 31
+H = LANES >> 5
+
+
+def rho(i, h):
+    return (i & 3) + 8 * (i >> 2) + 4 * h
+
+
+def pi16(h, j):
+    return 8 * (j >> 2) + 4 * h + (j & 3)
+
+
+# ---- MFMA semantics ---------------------------------------------------------------------------
+def mfma_bf16(a, b, c):
+    """a,b: (64,8); c: (64,16).  A[i][k=8h+j] = a[lane(i,h)][j]; B[k][n] = b[lane(n,h)][j]."""
+    A = np.zeros((32, 16)); B = np.zeros((16, 32))
+    for l in range(64):
+        for j in range(8):
+            A[l & 31, 8 * (l >> 5) + j] = a[l, j]
+            B[8 * (l >> 5) + j, l & 31] = b[l, j]
+    D = A @ B
+    out = c.copy()
+    for l in range(64):
+        for q in range(16):
+            out[l, q] += D[rho(q, l >> 5), l & 31]
+    return out
+
+
+def mfma_f32(a, b, c):
+    """a,b: (64,) ; A[i][k=h], B[k=h][n]."""
+    A = np.zeros((32, 2)); B = np.zeros((2, 32))
+    for l in range(64):
+        A[l & 31, l >> 5] = a[l]
+        B[l >> 5, l & 31] = b[l]
+    D = A @ B
+    out = c.copy()
+    for l in range(64):
+        for q in range(16):
+            out[l, q] += D[rho(q, l >> 5), l & 31]
+    return out
+
+
+class Mode:
+    def __init__(self, bf16):
+        self.bf16 = bf16
+        self.steps32 = 2 if bf16 else 16
+        self.units32 = 2 if bf16 else 4
+        self.tile_units = 2 if bf16 else 4
+        self.elems = 8 if bf16 else 4     # values per lane per 1-KiB unit
+
+    def zero_frags(self, n):
+        return np.zeros((n, 64, 8)) if self.bf16 else np.zeros((n, 64))
+
+
+# ---- pack kernel ---------------------------------------------------------------------------------
+def pack_units(mode, units, params):
+    out = np.zeros((len(units), 64, mode.elems))
+    for ui, u in enumerate(units):
+        if u["w_id"] < 0:
+            continue
+        W = params[u["w_id"]]
+        for l in range(64):
+            row, h = l & 31, l >> 5
+            for e in range(mode.elems):
+                k = u["k0"] + pi16(h, e) if mode.bf16 else rho(u["k0"] + e, h)
+                if u["transposed"]:
+                    sr, sc = u["r0"] + k, u["c0"] + row
+                else:
+                    sr, sc = u["r0"] + row, u["c0"] + k
+                if 0 <= sr < u["r_end"] and 0 <= sc < u["c_end"]:
+                    out[ui, l, e] = W.reshape(-1)[sr * u["ld"] + sc]
+    return out
+
+
+def pack_bias(descs, params, total):
+    out = np.zeros(total)
+    for d in descs:
+        if d["w_id"] >= 0:
+            out[d["off"]:d["off"] + d["n"]] = params[d["w_id"]].reshape(-1)[:d["n"]]
+    return out
+
+
+class WStream:
+    def __init__(self, units):
+        self.units = units
+        self.ctr = 0
+
+    def take(self, n):
+        if (self.ctr % CHUNK) + n > CHUNK:
+            self.ctr = (self.ctr + CHUNK - 1) // CHUNK * CHUNK
+        p = self.ctr
+        self.ctr += n
+        return self.units[p:p + n]
+
+
+def mma_block32(mode, acc, units, frags):
+    """acc (64,16) += W[32x32] . in ; units: UNITS32 packed units ; frags: STEPS32 fragments."""
+    if mode.bf16:
+        for u in range(2):
+            acc = mfma_bf16(units[u], frags[u], acc)
+    else:
+        for u in range(4):
+            for e in range(4):
+                acc = mfma_f32(units[u][:, e], frags[4 * u + e], acc)
+    return acc
+
+
+def gemm_blocks(mode, acc, ws, frags, k32):
+    if k32 == 0:
+        return acc
+    un = ws.take(k32 * mode.units32)
+    for k in range(k32):
+        acc = mma_block32(mode, acc, un[k * mode.units32:(k + 1) * mode.units32],
+                          frags[k * mode.steps32:(k + 1) * mode.steps32])
+    return acc
+
+
+def acc_to_frags(mode, acc):
+    if mode.bf16:
+        return np.stack([acc[:, 0:8], acc[:, 8:16]])       # (2,64,8)
+    return acc.T.copy()                                     # (16,64)
+
+
+def transpose_tile(mode, frags):
+    z = np.zeros((64, 16))
+    if mode.bf16:
+        for u in range(2):
+            ident = np.zeros((64, 8))
+            for l in range(64):
+                for j in range(8):
+                    ident[l, j] = 1.0 if (l & 31) == 16 * u + pi16(l >> 5, j) else 0.0
+            z = mfma_bf16(frags[u], ident, z)
+    else:
+        for q in range(16):
+            ident = np.array([1.0 if (l & 31) == rho(q, l >> 5) else 0.0 for l in range(64)])
+            z = mfma_f32(frags[q], ident, z)
+    return z
+
+
+def store_tile(mode, z):
+    """-> (TILE_UNITS, 64, elems) as written to the stash."""
+    if mode.bf16:
+        return np.stack([z[:, 0:8], z[:, 8:16]])
+    return np.stack([z[:, 4 * g:4 * g + 4] for g in range(4)])
+
+
+# ---- features ---------------------------------------------------------------------------------------
+def feature_value(e, srcs, p, ray):
+    kind = (e["packed"] >> 12) & 15
+    if kind == 0:
+        return 0.0
+    sid, comp = (e["packed"] >> 8) & 15, e["packed"] & 255
+    arr, per_ray = srcs[sid]
+    x = arr[ray if per_ray else p, comp]
+    if kind == 1:
+        return x
+    arg = e["freq"] * x
+    if kind == 4:
+        arg = arg + 0.5 * 3.1415926
+    return np.cos(arg) if kind == 3 else np.sin(arg)
+
+
+def feature_grad(e, srcs, p, ray):
+    kind = (e["packed"] >> 12) & 15
+    if kind == 1:
+        return 1.0
+    sid, comp = (e["packed"] >> 8) & 15, e["packed"] & 255
+    arr, per_ray = srcs[sid]
+    x = arr[ray if per_ray else p, comp]
+    arg = e["freq"] * x
+    if kind == 4:
+        arg = arg + 0.5 * 3.1415926
+    return -e["freq"] * np.sin(arg) if kind == 3 else e["freq"] * np.cos(arg)
+
+
+def make_group(mode, ft, srcs, p_of_lane, ray_of_lane, valid):
+    fr = mode.zero_frags(2 * mode.steps32)
+    for l in range(64):
+        h = l >> 5
+        if mode.bf16:
+            for s in range(4):
+                for j in range(8):
+                    v = feature_value(ft[16 * s + pi16(h, j)], srcs, p_of_lane[l], ray_of_lane[l])
+                    fr[s, l, j] = v if valid[l] else 0.0
+        else:
+            for s in range(32):
+                v = feature_value(ft[32 * (s >> 4) + rho(s & 15, h)], srcs, p_of_lane[l], ray_of_lane[l])
+                fr[s, l] = v if valid[l] else 0.0
+    return fr
+
+
+class Stash:
+    def __init__(self, mode, prog, n_points):
+        self.mode = mode
+        self.offs, sb, mb = prog.layout(1 if mode.bf16 else 0, n_points)
+        self.tile_bytes = 2048 if mode.bf16 else 4096
+        self.tiles = {}     # (byte offset) -> (TILE_UNITS,64,elems)
+        self.masks = {}
+
+    def put_tile(self, slot, blk, t, z):
+        off, nt = self.offs[slot]
+        self.tiles[off + (blk * nt + t) * self.tile_bytes] = store_tile(self.mode, z)
+
+    def get_tile(self, byte_off):
+        return self.tiles[byte_off]
+
+    def put_mask(self, slot, blk, d, bits):
+        off, nt = self.offs[slot]
+        self.masks[(off, blk * nt + d)] = bits.copy()
+
+    def get_mask(self, slot, blk, d):
+        off, nt = self.offs[slot]
+        return self.masks[(off, blk * nt + d)]
+
+
+def bias_acc(bias, off, t):
+    acc = np.zeros((64, 16))
+    for l in range(64):
+        for i in range(16):
+            acc[l, i] = bias[off + 32 * t + rho(i, l >> 5)]
+    return acc
+
+
+def run_forward(prog, mode, tables, params, srcs, n_points, spr, dst_widths, training=True):
+    units = pack_units(mode, tables["fwd_units"], params)
+    bias = pack_bias(tables["bias"], params, prog.bias_len)
+    feat = tables["feat"]
+    outs = [np.zeros((n_points, w)) for w in dst_widths]
+    stash = Stash(mode, prog, n_points)
+    nblk = (n_points + 31) // 32
+    for blk in range(nblk):
+        p0 = blk * 32 + R
+        valid = p0 < n_points
+        p = np.where(valid, p0, n_points - 1)
+        ray = p // spr
+        ws = WStream(units)
+        cur = mode.zero_frags(8 * mode.steps32)
+        accL = None
+        for w in prog.fwd_ops:
+            code = w[0]
+            if code == 1:
+                k32, ng, nt = w[1] & 255, (w[1] >> 8) & 255, (w[1] >> 16) & 255
+                act, flags = (w[1] >> 24) & 15, (w[1] >> 28) & 15
+                aux = []
+                for g in range(ng):
+                    fr = make_group(mode, feat[w[3] + 64 * g: w[3] + 64 * g + 64], srcs, p, ray, valid)
+                    aux.append(fr)
+                    if training and w[6] >= 0:
+                        stash.put_tile(w[6], blk, 2 * g, transpose_tile(mode, fr[:mode.steps32]))
+                        stash.put_tile(w[6], blk, 2 * g + 1, transpose_tile(mode, fr[mode.steps32:]))
+                nxt = mode.zero_frags(8 * mode.steps32)
+                bits = np.zeros(64, dtype=np.uint64)
+                for t in range(nt):
+                    acc = bias_acc(bias, w[2], t)
+                    acc = gemm_blocks(mode, acc, ws, cur, k32)
+                    for g in range(ng):
+                        acc = gemm_blocks(mode, acc, ws, aux[g], 2)
+                    accL = acc.copy()
+                    pos = acc > 0
+                    for i in range(16):
+                        bits |= (pos[:, i].astype(np.uint64) << np.uint64(16 * (t & 1) + i))
+                    if act == 1:
+                        acc = np.where(pos, acc, 0.0)
+                    acc = np.where(valid[:, None], acc, 0.0)
+                    nxt[t * mode.steps32:(t + 1) * mode.steps32] = acc_to_frags(mode, acc)
+                    if (t & 1) or t == nt - 1:
+                        if training and w[4] >= 0:
+                            stash.put_mask(w[4], blk, t >> 1, bits)
+                        bits = np.zeros(64, dtype=np.uint64)
+                    if training and w[5] >= 0:
+                        stash.put_tile(w[5], blk, t, transpose_tile(mode, nxt[t * mode.steps32:(t + 1) * mode.steps32]))
+                if not (flags & 1):
+                    cur[:nt * mode.steps32] = nxt[:nt * mode.steps32]
+            elif code == 4:
+                for l in range(32):          # h == 0 lanes
+                    if not valid[l]:
+                        continue
+                    for i in range(w[3]):
+                        y = accL[l, i]
+                        if w[4] == 1:
+                            y = 1.0 / (1.0 + np.exp(-y))
+                        if w[5] >= 0:
+                            arr, per_ray = srcs[w[5]]
+                            y = y + arr[ray[l] if per_ray else p[l], w[6] + i]
+                        outs[w[1]][p[l], w[2] + i] = y
+            elif code == 5:
+                n, nt = w[3], w[4]
+                for l in range(64):
+                    if not valid[l]:
+                        continue
+                    h = l >> 5
+                    for t in range(nt):
+                        if mode.bf16:
+                            for s in range(2):
+                                for j in range(8):
+                                    row = 32 * t + 16 * s + pi16(h, j)
+                                    if row < n:
+                                        outs[w[1]][p[l], w[2] + row] = cur[2 * t + s, l, j]
+                        else:
+                            for q in range(16):
+                                row = 32 * t + rho(q, h)
+                                if row < n:
+                                    outs[w[1]][p[l], w[2] + row] = cur[16 * t + q, l]
+    return outs, stash
+
+
+def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
+    units = pack_units(mode, tables["bwd_units"], params)
+    feat = tables["feat"]
+    dsrc = np.zeros((n_points, max(1, prog.n_dsrc)))
+    nblk = (n_points + 31) // 32
+    for blk in range(nblk):
+        p0 = blk * 32 + R
+        valid = p0 < n_points
+        p = np.where(valid, p0, n_points - 1)
+        ray = p // spr
+        ws = WStream(units)
+        cur = mode.zero_frags(8 * mode.steps32)
+        cur2 = mode.zero_frags(mode.steps32)
+        for w in prog.bwd_ops:
+            code = w[0]
+            if code == 1:
+                n, to2 = w[3] & 255, (w[3] >> 8) & 1
+                tmp = mode.zero_frags(mode.steps32)
+                arr, _ = srcs[w[1]]
+                for l in range(32):
+                    if not valid[l]:
+                        continue
+                    for i in range(n):
+                        g = arr[p[l], w[2] + i]
+                        if w[4] == 1:
+                            y = srcs[w[5]][0][p[l], w[6] + i]
+                            g = g * y * (1.0 - y)
+                        if mode.bf16:
+                            tmp[0, l, i] = g
+                        else:
+                            tmp[i, l] = g
+                if w[7] >= 0:
+                    stash.put_tile(w[7], blk, 0, transpose_tile(mode, tmp))
+                if to2:
+                    cur2 = tmp
+                else:
+                    cur[:mode.steps32] = tmp
+            elif code == 2:
+                n, nt = w[3], w[4]
+                arr, _ = srcs[w[1]]
+                for t in range(nt):
+                    v = np.zeros((64, 16))
+                    bits = stash.get_mask(w[5], blk, t >> 1) if w[5] >= 0 else None
+                    for l in range(64):
+                        for i in range(16):
+                            row = 32 * t + rho(i, l >> 5)
+                            keep = True if bits is None else bool((int(bits[l]) >> (16 * (t & 1) + i)) & 1)
+                            if valid[l] and keep and row < n:
+                                v[l, i] = arr[p[l], w[2] + row]
+                    cur[t * mode.steps32:(t + 1) * mode.steps32] = acc_to_frags(mode, v)
+                    if w[7] >= 0:
+                        stash.put_tile(w[7], blk, t, transpose_tile(mode, cur[t * mode.steps32:(t + 1) * mode.steps32]))
+            elif code == 3:
+                k32, k32b, nt = w[1] & 255, (w[1] >> 8) & 255, (w[1] >> 16) & 255
+                nxt = mode.zero_frags(8 * mode.steps32)
+                for t in range(nt):
+                    acc = np.zeros((64, 16))
+                    acc = gemm_blocks(mode, acc, ws, cur, k32)
+                    if k32b:
+                        acc = gemm_blocks(mode, acc, ws, cur2, 1)
+                    if w[4] >= 0:
+                        bits = stash.get_mask(w[4], blk, t >> 1)
+                        for l in range(64):
+                            for i in range(16):
+                                if not ((int(bits[l]) >> (16 * (t & 1) + i)) & 1):
+                                    acc[l, i] = 0.0
+                    acc = np.where(valid[:, None], acc, 0.0)
+                    nxt[t * mode.steps32:(t + 1) * mode.steps32] = acc_to_frags(mode, acc)
+                    if w[5] >= 0:
+                        stash.put_tile(w[5], blk, t, transpose_tile(mode, nxt[t * mode.steps32:(t + 1) * mode.steps32]))
+                cur[:nt * mode.steps32] = nxt[:nt * mode.steps32]
+            elif code == 4:
+                k32, k32b, ng = w[1] & 255, (w[1] >> 8) & 255, (w[1] >> 16) & 255
+                for tt in range(2 * ng):
+                    acc = np.zeros((64, 16))
+                    acc = gemm_blocks(mode, acc, ws, cur, k32)
+                    if k32b:
+                        acc = gemm_blocks(mode, acc, ws, cur2, 1)
+                    ft = feat[w[3] + 32 * tt: w[3] + 32 * tt + 32]
+                    for l in range(64):
+                        if not valid[l]:
+                            continue
+                        for i in range(16):
+                            e = ft[rho(i, l >> 5)]
+                            slot = ((e["packed"] >> 16) & 255) - 1
+                            if slot >= 0:
+                                dsrc[p[l], slot] += acc[l, i] * feature_grad(e, srcs, p[l], ray[l])
+    return dsrc
+
+
+def run_wgrad(prog, mode, jobs, stash, n_grad):
+    grads = np.zeros(n_grad)
+    tb = 2048 if mode.bf16 else 4096
+    for jb in jobs:
+        acc = [[np.zeros((64, 16)) for _ in range(4)] for _ in range(2)]
+        accb = [np.zeros((64, 16)) for _ in range(2)]
+        for b in range(jb["blk0"], jb["blk1"]):
+            za = [stash.get_tile(int(jb["z_off"]) + (b * jb["z_nt"] + jb["z_t0"] + n) * tb) for n in range(jb["n_nt"])]
+            xb = [stash.get_tile(int(jb["x_off"]) + (b * jb["x_nt"] + jb["x_t0"] + k) * tb) for k in range(jb["n_kt"])]
+            for n in range(jb["n_nt"]):
+                for k in range(jb["n_kt"]):
+                    if mode.bf16:
+                        for v in range(2):
+                            acc[n][k] = mfma_bf16(za[n][v], xb[k][v], acc[n][k])
+                    else:
+                        for g in range(4):
+                            for e in range(4):
+                                acc[n][k] = mfma_f32(za[n][g][:, e], xb[k][g][:, e], acc[n][k])
+                if jb["b_off"] >= 0:
+                    if mode.bf16:
+                        for v in range(2):
+                            accb[n] = mfma_bf16(za[n][v], np.ones((64, 8)), accb[n])
+                    else:
+                        for g in range(4):
+                            for e in range(4):
+                                accb[n] = mfma_f32(za[n][g][:, e], np.ones(64), accb[n])
+        for n in range(jb["n_nt"]):
+            for k in range(jb["n_kt"]):
+                for l in range(64):
+                    c, h = l & 31, l >> 5
+                    for q in range(16):
+                        row = jb["r0"] + 32 * n + rho(q, h)
+                        col = jb["c0"] + 32 * k + c
+                        if 0 <= row < jb["r_end"] and 0 <= col < jb["c_end"] and jb["w_off"] >= 0:
+                            grads[jb["w_off"] + row * jb["ld"] + col] += acc[n][k][l, q]
+            if jb["b_off"] >= 0:
+                for l in (0, 32):
+                    for q in range(16):
+                        row = jb["r0"] + 32 * n + rho(q, l >> 5)
+                        if 0 <= row < jb["r_end"]:
+                            grads[jb["b_off"] + row] += accb[n][l, q]
+    return grads

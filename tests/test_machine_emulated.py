@@ -1,0 +1,141 @@
+"""Host "compiler" of the MLP machine checked WITHOUT a GPU: the op programs, packing tables, slot layout
+and dW job lists produced by hypernerf_torch_amd.machine are executed by a lane-level numpy emulation of the
+device algorithms (tests/emulator.py, documented gfx950 MFMA lane maps) and compared with the CPU oracle
+and torch autograd.  Both numeric modes' LAYOUTS are emulated (values stay fp64, so tolerance is 1e-9)."""
+import numpy as np
+import pytest
+import torch
+
+import emulator as E
+import hashprng as H
+import hypernerf_torch_amd  # noqa: F401
+from hypernerf_torch_amd.hypernerf import modules, warping
+from oracle import hypernerf_oracle as O
+
+
+def load_hash(module, seed):
+    sd = module.state_dict()
+    module.load_state_dict(H.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed))
+    return {k: v.double() for k, v in module.state_dict().items()}
+
+
+def np_params(prog):
+    return [p.detach().double().numpy() for p in prog.params]
+
+
+def check_grads(prog, flat, torch_params, named):
+    offs, _ = prog.grad_offsets()
+    for prm, off in zip(prog.params, offs):
+        name = [k for k, v in named.items() if v is prm][0]
+        ref = torch_params[name].grad
+        got = flat[off:off + prm.numel()].reshape(prm.shape)
+        ref = np.zeros(prm.shape) if ref is None else ref.numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10, err_msg=name)
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+def test_translation_field_emulated(bf16):
+    torch.manual_seed(0)
+    tf = warping.TranslationField(in_ch=3, in_ch_embed=8, depth=6, hidden_channels=64)
+    sd = load_hash(tf, 11)
+    b, s = 5, 8
+    n = b * s
+    pts = H.uniform(1, "pts", (n, 3), -1, 1).double()
+    emb = H.uniform(1, "emb", (b, 8), -0.5, 0.5).double()
+    call = tf._call(True, False, True)
+    prog = call.program
+    mode = E.Mode(bf16)
+    tables = prog.host_tables(1 if bf16 else 0)
+    params = np_params(prog)
+    srcs = [(pts.numpy(), False), (emb.numpy(), True), None, None]
+    outs, stash = E.run_forward(prog, mode, tables, params, srcs, n, s, [3])
+    # oracle
+    tp = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    embt = emb.clone().requires_grad_(True)
+    y = O.translation_field({"w." + k: v for k, v in tp.items()}, "w", pts.view(b, s, 3),
+                            embt[:, None, :].expand(b, s, 8))
+    np.testing.assert_allclose(outs[0].reshape(b, s, 3), y.detach().numpy(), rtol=1e-9, atol=1e-11)
+    g = H.uniform(2, "g", (n, 3), -1, 1).double()
+    (y.reshape(n, 3) * g).sum().backward()
+    bsrcs = srcs + [(g.numpy(), False)]
+    dsrc = E.run_backward(prog, mode, tables, params, bsrcs, n, s, stash)
+    # embed gradient: dsrc columns -> per-ray sums
+    cols = {c: sl for (si, c), sl in prog.dsrc_map.items() if si == 1}
+    got = np.stack([dsrc[:, cols[c]].reshape(b, s).sum(1) for c in range(8)], axis=1)
+    np.testing.assert_allclose(got, embt.grad.numpy(), rtol=1e-8, atol=1e-10)
+    jobs = prog.wgrad_jobs(1 if bf16 else 0, n)
+    _, gtot = prog.grad_offsets()
+    flat = E.run_wgrad(prog, mode, jobs, stash, gtot)
+    check_grads(prog, flat, tp, dict(tf.named_parameters()))
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+def test_nerf_mlp_emulated(bf16):
+    torch.manual_seed(0)
+    nm = modules.NerfMLP(in_ch=6, trunk_depth=4, trunk_width=64, rgb_branch_depth=2, rgb_branch_width=32,
+                         hidden_activation=torch.nn.ReLU(), skips=[2], rgb_activation=torch.nn.Sigmoid(),
+                         alpha_condition_dim=4, rgb_condition_dim=5, alpha_brach_width=32)
+    # bottleneck is trunk_width//2 = 32 = rgb_branch_width
+    sd = load_hash(nm, 5)
+    b, s = 3, 12
+    n = b * s          # 36 points: one full block + a partial one
+    x = H.uniform(3, "x", (b, s, 6), -1, 1).double()
+    ac = H.uniform(3, "ac", (b, 4), -0.5, 0.5).double()
+    rc = H.uniform(3, "rc", (b, 5), -1, 1).double()
+    call = nm._call(True, 4, True, 5, True)
+    prog = call.program
+    mode = E.Mode(bf16)
+    tables = prog.host_tables(1 if bf16 else 0)
+    params = np_params(prog)
+    srcs = [(x.reshape(n, 6).numpy(), False), (ac.numpy(), True), (rc.numpy(), True), None]
+    outs, stash = E.run_forward(prog, mode, tables, params, srcs, n, s, [3, 1])
+    tp = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xt, act, rct = (t.clone().requires_grad_(True) for t in (x, ac, rc))
+    rgb, alpha = O.nerf_mlp({"n." + k: v for k, v in tp.items()}, "n", xt, act, rct, trunk_depth=4, rgb_depth=2,
+                            skips=(2,))
+    np.testing.assert_allclose(outs[0].reshape(b, s, 3), rgb.detach().numpy(), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(outs[1].reshape(b, s, 1), alpha.detach().numpy(), rtol=1e-9, atol=1e-11)
+    g_rgb = H.uniform(4, "g_rgb", (n, 3), -1, 1).double()
+    g_a = H.uniform(4, "g_a", (n, 1), -1, 1).double()
+    ((rgb.reshape(n, 3) * g_rgb).sum() + (alpha.reshape(n, 1) * g_a).sum()).backward()
+    bsrcs = srcs + [(g_rgb.numpy(), False), (g_a.numpy(), False), (outs[0], False)]
+    dsrc = E.run_backward(prog, mode, tables, params, bsrcs, n, s, stash)
+    cx = {c: sl for (si, c), sl in prog.dsrc_map.items() if si == 0}
+    got_x = np.stack([dsrc[:, cx[c]] for c in range(6)], axis=1)
+    np.testing.assert_allclose(got_x, xt.grad.reshape(n, 6).numpy(), rtol=1e-8, atol=1e-10)
+    for si, ref, width in ((1, act.grad, 4), (2, rct.grad, 5)):
+        cols = {c: sl for (s2, c), sl in prog.dsrc_map.items() if s2 == si}
+        got = np.stack([dsrc[:, cols[c]].reshape(b, s).sum(1) for c in range(width)], axis=1)
+        np.testing.assert_allclose(got, ref.numpy(), rtol=1e-8, atol=1e-10)
+    jobs = prog.wgrad_jobs(1 if bf16 else 0, n)
+    _, gtot = prog.grad_offsets()
+    flat = E.run_wgrad(prog, mode, jobs, stash, gtot)
+    check_grads(prog, flat, tp, dict(nm.named_parameters()))
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+def test_wide_output_mlp_emulated(bf16):
+    m = modules.MLP(in_ch=10, out_ch=40, depth=3, width=32, skips=[0], output_activation=torch.nn.ReLU())
+    sd = load_hash(m, 9)
+    n = 33
+    x = H.uniform(5, "x", (n, 10), -1, 1).double()
+    call = m._call(True)
+    prog = call.program
+    mode = E.Mode(bf16)
+    tables = prog.host_tables(1 if bf16 else 0)
+    params = np_params(prog)
+    srcs = [(x.numpy(), False), None, None, None]
+    outs, stash = E.run_forward(prog, mode, tables, params, srcs, n, 1, [40])
+    tp = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xt = x.clone().requires_grad_(True)
+    y = O.mlp({"m." + k: v for k, v in tp.items()}, "m", xt, depth=3, skips=(0,), out_act="relu")
+    np.testing.assert_allclose(outs[0], y.detach().numpy(), rtol=1e-9, atol=1e-11)
+    g = H.uniform(6, "g", (n, 40), -1, 1).double()
+    (y * g).sum().backward()
+    dsrc = E.run_backward(prog, mode, tables, params, srcs + [(g.numpy(), False), (outs[0], False)], n, 1, stash)
+    cx = {c: sl for (si, c), sl in prog.dsrc_map.items() if si == 0}
+    np.testing.assert_allclose(np.stack([dsrc[:, cx[c]] for c in range(10)], axis=1), xt.grad.numpy(),
+                               rtol=1e-8, atol=1e-10)
+    jobs = prog.wgrad_jobs(1 if bf16 else 0, n)
+    _, gtot = prog.grad_offsets()
+    check_grads(prog, E.run_wgrad(prog, mode, jobs, stash, gtot), tp, dict(m.named_parameters()))
