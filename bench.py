@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Benchmark of the HyperNeRF render hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+(N>1: launched by torch.distributed.run, one rank per GPU, RCCL).  A "step" = one training step of the
+reference's hot loop on one synthetic ray batch already resident in HBM: NerfModel forward (coarse + fine),
+MSE loss, backward, gradient all-reduce (N>1), Adam step.  Workload at N=1 = BASELINE configs[1]:
+use_warp + bendy_sheet, 1024 rays x (64+64) samples, bf16 MFMA operands / fp32 accumulate.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=1024)
+    ap.add_argument("--nc", type=int, default=64)
+    ap.add_argument("--nf", type=int, default=64)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def macs_per_point(prog):
+    return sum(ly.weight.shape[0] * ly.weight.shape[1] for ly in prog.layers)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import hypernerf_torch_amd as HN
+    from hypernerf_torch_amd import _lib as L
+    from hypernerf_torch_amd.dist import GradBucket, all_gather_pixels
+    from hypernerf_torch_amd.hypernerf import model_utils
+    from hypernerf_torch_amd.hypernerf.models import NerfModel
+    from hypernerf_torch_amd.losses import MSELoss, psnr
+    from gpu_common import EMB
+
+    HN.set_precision(a.precision)
+    torch.manual_seed(0)     # identical weights on every rank
+    model = NerfModel(EMB, near=0.0, far=1.0, n_samples_coarse=a.nc, n_samples_fine=a.nf, noise_std=1.0,
+                      hyper_slice_method="bendy_sheet", use_warp=True, use_nerf_embed=True, use_alpha_cond=True,
+                      view_fourier_dim=6).to(dev)
+    params = [p for p in model.parameters()]
+    try:
+        opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8, fused=True)
+    except Exception:
+        opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8, foreach=True)
+    bucket = GradBucket(params)
+    loss_fn = MSELoss()
+
+    # synthetic rays (B,9): origins U(-1,1)^3, unit-ish directions, near/far 0/1, image id; rgb targets
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    b = a.rays
+    o = torch.rand(b, 3, generator=g) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(b, 3, generator=g), dim=-1)
+    ids = torch.randint(0, 100, (b, 1), generator=g).float()
+    rays = torch.cat([o, d, torch.zeros(b, 1), torch.ones(b, 1), ids], dim=1).to(dev)
+    target = torch.rand(b, 3, generator=g).to(dev)
+    extra = {'nerf_alpha': None, 'warp_alpha': None, 'hyper_alpha': None, 'hyper_sheet_alpha': None}
+
+    def step():
+        rd = model_utils.prepare_ray_dict(rays)
+        out = model(rd, extra)
+        loss = loss_fn(out, target)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if world > 1:
+            bucket.all_reduce_mean()
+        opt.step()
+        return out, loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out, loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        all_gather_pixels(out['fine']['rgb'].detach())     # eval-style pixel assembly works on this topology
+    samples = world * b * (a.nc + a.nf) * a.steps
+    value = samples / dt
+
+    res = {
+        "metric": "ray-samples/sec (fwd+bwd+Adam), whole job; per-GPU = value/n_gpus",
+        "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.precision, "data": "synthetic",
+        "config": {"workload": f"NerfModel use_warp bendy_sheet nerf_embed+alpha_cond, {b} rays x ({a.nc}+{a.nf}) "
+                               f"samples per GPU, fwd+bwd+Adam", "rays_per_gpu": b, "n_samples": a.nc,
+                   "n_importance": a.nf, "parallelism": f"dp{world}"},
+        "per_gpu": value / world, "final_loss": float(loss),
+    }
+
+    if rank == 0 and not a.no_roofline:
+        # second pass: the same steps with HIP events around every C-ABI launch (on the launch stream)
+        L.KERNEL_TIMES = {}
+        for _ in range(a.steps):
+            step()
+        times = L.collect_kernel_times()
+        L.KERNEL_TIMES = None
+        tot = {k: sum(v) for k, v in times.items()}
+        dom = max(tot, key=tot.get)
+        avg_ms = tot[dom] / len(times[dom])
+        lvl = "fine" if "fine" in dom else "coarse"
+        call = [c for k, c in model._template_calls.items() if k[0] == lvl]
+        pts = b * (a.nc + a.nf if lvl == "fine" else a.nc)
+        flops = 0.0
+        if "template" in dom and call:
+            flops = 2.0 * macs_per_point(call[0].program) * pts
+        elif "TranslationField" in dom:
+            flops = 2.0 * macs_per_point(model.warp_field._calls[next(iter(model.warp_field._calls))].program) * pts
+        ach = flops / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+        step_ms = sum(tot.values()) / a.steps
+        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": PEAK[a.precision] / 1e12,
+                           "unit": "TFLOP/s", "frac": ach / PEAK[a.precision], "traffic": None,
+                           "avg_launch_ms": avg_ms, "algorithmic_flops_per_launch": flops,
+                           "kernel_ms_per_step": {k: tot[k] / a.steps for k in sorted(tot, key=tot.get, reverse=True)},
+                           "sum_kernel_ms_per_step": step_ms}
+        # whole-step algorithmic rate (3x forward MACs over all three MLPs and both levels)
+        mac_pt = macs_per_point(call[0].program) if call else 0
+        for m in (model.warp_field, model.hyper_sheet_mlp):
+            mac_pt += macs_per_point(m._calls[next(iter(m._calls))].program)
+        step_flops = 6.0 * mac_pt * b * (2 * a.nc + a.nf)
+        res["step_tflops"] = step_flops / (dt / a.steps) / 1e12
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(a)
+
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a):
+    """The CPU oracle (oracle/hypernerf_oracle.py, validated against the reference's own outputs) timed on
+    this node's host cores on a bounded sample of the same workload, fp32."""
+    import hashprng as H
+    from gpu_common import EMB, rays_for
+    from hypernerf_torch_amd.hypernerf.models import NerfModel
+    from oracle import hypernerf_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b = 64
+    kw = dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True)
+    m = NerfModel(EMB, n_samples_coarse=a.nc, n_samples_fine=a.nf, noise_std=1.0, view_fourier_dim=6, **kw)
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    cfg = O.ModelCfg(n_samples_coarse=a.nc, n_samples_fine=a.nf, noise_std=1.0, view_fourier_dim=6, **kw)
+    o, d, idx = rays_for(1, b)
+    gt = H.uniform(1, "gt", (b, 3), 0, 1)
+
+    def one():
+        rng = {"t_rand": torch.rand(b, a.nc), "noise_coarse": torch.randn(b, a.nc, 1),
+               "u": torch.rand(b, a.nf), "noise_fine": torch.randn(b, a.nc + a.nf, 1)}
+        for v in p.values():
+            v.grad = None
+        out = O.nerf_model_forward(p, cfg, o, d, idx, rng)
+        O.mse_loss(out, gt).backward()
+
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 50):
+        one()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": b * (a.nc + a.nf) / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{b} rays x ({a.nc}+{a.nf}) samples, fp32, fwd+bwd (no optimizer), "
+                                      f"{n} timed iterations after 1 warm-up"}
+
+
+if __name__ == "__main__":
+    main()

@@ -77,7 +77,7 @@ DWJOB_DT = np.dtype([("z_off", "<u8"), ("x_off", "<u8"), ("z_nt", "<i4"), ("x_nt
                      ("c_end", "<i4"), ("b_off", "<i4"), ("pad", "<i4")])
 
 EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
-           "hn_sample_along_rays", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf",
+           "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf",
            "hn_embed_gather", "hn_embed_backward", "hn_probe_mfma"]
 
 _lib = None
@@ -132,6 +132,35 @@ def load():
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
+
+
+# Optional per-launch timing (bench.py's roofline leg): when KERNEL_TIMES is a dict, every launch made
+# through `launch()` is bracketed by HIP events on the launch stream; `collect_kernel_times()` resolves them.
+KERNEL_TIMES = None
+_PENDING = []
+
+
+def launch(name: str, *args, tag: str = ""):
+    """Call one C-ABI entry point on the current stream and check its status."""
+    fn = getattr(load(), name)
+    if KERNEL_TIMES is None:
+        check(fn(*args), name + (f"[{tag}]" if tag else ""))
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    _PENDING.append((name + (f"[{tag}]" if tag else ""), e0, e1))
+    check(rc, name)
+
+
+def collect_kernel_times():
+    """ms per launch, grouped by name: {name: [ms, ...]} (synchronises)."""
+    torch.cuda.synchronize()
+    for name, e0, e1 in _PENDING:
+        KERNEL_TIMES.setdefault(name, []).append(e0.elapsed_time(e1))
+    _PENDING.clear()
+    return KERNEL_TIMES
 
 
 def check(rc: int, what: str):

@@ -69,6 +69,104 @@ extern "C" int hn_sample_along_rays(const float* origins, const float* dirs, int
   return 0;
 }
 
+// legacy nerf_pl sampling: per-ray near/far (models/rendering.py:189-207)
+__global__ void hn_sample_legacy_kernel(const float* __restrict__ rays, int ray_ld, const float* __restrict__ t_vals,
+                                        const float* __restrict__ omt_vals, int use_disp,
+                                        const float* __restrict__ t_rand, float scale, int n_rays, int n,
+                                        float* __restrict__ z_out, float* __restrict__ pts_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_rays * n) return;
+  const int b = (int)(i / n), s = (int)(i % n);
+  const float* ray = rays + (size_t)b * ray_ld;
+  const float near = ray[6], far = ray[7];
+  auto zlin = [&](int k) -> float {
+    if (!use_disp) return __fadd_rn(__fmul_rn(near, omt_vals[k]), __fmul_rn(far, t_vals[k]));
+    const float den = __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), omt_vals[k]), __fmul_rn(__fdiv_rn(1.0f, far), t_vals[k]));
+    return __fdiv_rn(1.0f, den);
+  };
+  float z = zlin(s);
+  if (t_rand != nullptr) {
+    const float lower = s == 0 ? z : __fmul_rn(0.5f, __fadd_rn(zlin(s - 1), z));
+    const float upper = s == n - 1 ? z : __fmul_rn(0.5f, __fadd_rn(z, zlin(s + 1)));
+    const float t = __fmul_rn(scale, t_rand[i]);
+    z = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t));
+  }
+  z_out[i] = z;
+  if (pts_out != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pts_out[i * 3 + c] = __fadd_rn(ray[c], __fmul_rn(ray[3 + c], z));
+  }
+}
+
+extern "C" int hn_sample_legacy(const float* rays, int ray_ld, const float* t_vals, const float* one_minus_t,
+                                int use_disp, const float* t_rand, float scale, int n_rays, int n, float* z_out,
+                                float* pts_out, hnStream_t stream) {
+  if (n_rays <= 0 || n <= 0 || ray_ld < 8) return -2;
+  if (rays == nullptr || t_vals == nullptr || one_minus_t == nullptr || z_out == nullptr) return -3;
+  const size_t total = (size_t)n_rays * n;
+  hipLaunchKernelGGL(hn_sample_legacy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     rays, ray_ld, t_vals, one_minus_t, use_disp, t_rand, scale, n_rays, n, z_out, pts_out);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone positional encoders (the fused path generates these features inside the MLP machine)
+// ------------------------------------------------------------------------------------------------
+__global__ void hn_posenc_kernel(const float* __restrict__ x, size_t n, int c, const float* __restrict__ freqs,
+                                 int n_freqs, int identity, int jax_cos, float* __restrict__ out,
+                                 const float* __restrict__ g_out, float* __restrict__ g_x) {
+  const int width = c * (2 * n_freqs + (identity ? 1 : 0));
+  if (g_out == nullptr) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * (size_t)width) return;
+    const size_t row = i / width;
+    int f = (int)(i % width);
+    float v;
+    if (identity && f < c) {
+      v = x[row * c + f];
+    } else {
+      if (identity) f -= c;
+      const int k = f / (2 * c), rem = f % (2 * c), sc = rem / c, ch = rem % c;
+      float arg = __fmul_rn(freqs[k], x[row * c + ch]);
+      if (sc == 0) v = sinf(arg);
+      else v = jax_cos ? sinf(__fadd_rn(arg, 0.5f * 3.1415926f)) : cosf(arg);
+    }
+    out[i] = v;
+  } else {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * (size_t)c) return;
+    const size_t row = i / c;
+    const int ch = (int)(i % c);
+    const float xv = x[i];
+    const float* g = g_out + row * width;
+    float acc = identity ? g[ch] : 0.0f;
+    const int base = identity ? c : 0;
+    for (int k = 0; k < n_freqs; ++k) {
+      const float fr = freqs[k];
+      const float arg = __fmul_rn(fr, xv);
+      acc += g[base + k * 2 * c + ch] * fr * cosf(arg);
+      if (jax_cos) acc += g[base + k * 2 * c + c + ch] * fr * cosf(__fadd_rn(arg, 0.5f * 3.1415926f));
+      else acc -= g[base + k * 2 * c + c + ch] * fr * sinf(arg);
+    }
+    g_x[i] = acc;
+  }
+}
+
+extern "C" int hn_posenc(const float* x, int64_t n, int c, const float* freqs, int n_freqs, int identity, int jax_cos,
+                         float* out, const float* g_out, float* g_x, hnStream_t stream) {
+  if (n <= 0 || c <= 0 || n_freqs < 0) return -2;
+  if (x == nullptr || (n_freqs > 0 && freqs == nullptr)) return -3;
+  if ((g_out == nullptr) == (out == nullptr)) return -3;   // exactly one of forward / backward
+  if (g_out != nullptr && g_x == nullptr) return -3;
+  const int width = c * (2 * n_freqs + (identity ? 1 : 0));
+  const size_t total = g_out == nullptr ? (size_t)n * width : (size_t)n * c;
+  hipLaunchKernelGGL(hn_posenc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (size_t)n, c, freqs, n_freqs, identity, jax_cos, out, g_out, g_x);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // compositing
 // ------------------------------------------------------------------------------------------------

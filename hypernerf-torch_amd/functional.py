@@ -51,7 +51,7 @@ class ProgramCall:
 
 class _ProgramFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, call: ProgramCall, mode: int, samples_per_ray: int, n_src: int, *tensors):
+    def forward(ctx, call: ProgramCall, mode: int, samples_per_ray: int, n_src: int, training: bool, *tensors):
         srcs = list(tensors[:n_src])
         L.require_gpu(*[s for s in srcs if s is not None])
         first = next(s for s in srcs if s is not None)
@@ -70,7 +70,6 @@ class _ProgramFn(torch.autograd.Function):
             flat_srcs.append((s2, per_ray))
         if n_points is None:
             raise L.HnError("a program needs at least one per-point source")
-        training = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
         outs = [torch.empty(n_points, w, dtype=torch.float32, device=device) for w in call.dst_widths]
         stash, masks = call.runner.forward(mode, n_points, samples_per_ray, flat_srcs, outs, training)
         ctx.call, ctx.mode, ctx.spr, ctx.n_src, ctx.n_points = call, mode, samples_per_ray, n_src, n_points
@@ -99,7 +98,7 @@ class _ProgramFn(torch.autograd.Function):
         src_grads: List[Optional[torch.Tensor]] = []
         prog = call.program
         for i, shp in enumerate(ctx.src_shapes):
-            if shp is None or not ctx.needs_input_grad[4 + i]:
+            if shp is None or not ctx.needs_input_grad[5 + i]:
                 src_grads.append(None)
                 continue
             cols = {c: s for (si, c), s in prog.dsrc_map.items() if si == i}
@@ -120,20 +119,23 @@ class _ProgramFn(torch.autograd.Function):
         n_par = len(prog.params)
         out_p = []
         for j in range(n_par):
-            out_p.append(pgrads[j] if ctx.needs_input_grad[4 + ctx.n_src + j] else None)
-        return (None, None, None, None, *src_grads, *out_p)
+            out_p.append(pgrads[j] if ctx.needs_input_grad[5 + ctx.n_src + j] else None)
+        return (None, None, None, None, None, *src_grads, *out_p)
 
 
 def run_program(call: ProgramCall, srcs: Sequence[Optional[torch.Tensor]], samples_per_ray: int,
                 precision: Optional[str] = None) -> Tuple[torch.Tensor, ...]:
     L.load()
-    return _ProgramFn.apply(call, mode_of(precision), int(samples_per_ray), len(srcs), *srcs, *call.program.params)
+    params = call.program.params
+    training = torch.is_grad_enabled() and (any(s is not None and s.requires_grad for s in srcs) or
+                                            any(p.requires_grad for p in params))
+    return _ProgramFn.apply(call, mode_of(precision), int(samples_per_ray), len(srcs), training, *srcs, *params)
 
 
 def sum_samples_into(d_points: torch.Tensor, cols: Dict[int, int], n_rays: int, n_samples: int, out: torch.Tensor):
     """out[b, c] += sum_s d_points[b*S + s, slot]  for every (c -> slot) — HIP reduction kernel.
     Consecutive (c, slot) pairs are reduced by one launch."""
-    lib = L.load()
+    L.load()
     idx = torch.arange(n_rays, dtype=torch.int64, device=out.device)
     items = sorted(cols.items())
     i = 0
@@ -143,9 +145,9 @@ def sum_samples_into(d_points: torch.Tensor, cols: Dict[int, int], n_rays: int, 
             j += 1
         c0, s0, run = items[i][0], items[i][1], j - i + 1
         tmp = torch.zeros(n_rays, run, dtype=torch.float32, device=out.device)
-        L.check(lib.hn_embed_backward(L.ptr(d_points), C.c_int(d_points.shape[1]), C.c_int(s0), L.ptr(idx),
+        L.launch("hn_embed_backward", L.ptr(d_points), C.c_int(d_points.shape[1]), C.c_int(s0), L.ptr(idx),
                                       C.c_int(n_rays), C.c_int(n_samples), C.c_int(run), C.c_int(n_rays), L.ptr(tmp),
-                                      L.stream_handle()), "hn_embed_backward")
+                                      L.stream_handle())
         out[:, c0:c0 + run] += tmp
         i = j + 1
 
@@ -157,24 +159,23 @@ class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table: torch.Tensor, idx: torch.Tensor):
         L.require_gpu(table, idx)
-        lib = L.load()
+        L.load()
         idx = idx.reshape(-1).to(torch.int64).contiguous()
         n, dim = idx.numel(), table.shape[1]
         out = torch.empty(n, dim, dtype=torch.float32, device=table.device)
-        L.check(lib.hn_embed_gather(L.ptr(table.detach().contiguous()), L.ptr(idx), C.c_int(n), C.c_int(dim),
-                                    C.c_int(table.shape[0]), L.ptr(out), L.stream_handle()), "hn_embed_gather")
+        L.launch("hn_embed_gather", L.ptr(table.detach().contiguous()), L.ptr(idx), C.c_int(n), C.c_int(dim),
+                                    C.c_int(table.shape[0]), L.ptr(out), L.stream_handle())
         ctx.idx, ctx.shape = idx, table.shape
         return out
 
     @staticmethod
     def backward(ctx, g):
-        lib = L.load()
+        L.load()
         g = g.contiguous()
         d_table = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
         n, dim = g.shape
-        L.check(lib.hn_embed_backward(L.ptr(g), C.c_int(dim), C.c_int(0), L.ptr(ctx.idx), C.c_int(n), C.c_int(1),
-                                      C.c_int(dim), C.c_int(ctx.shape[0]), L.ptr(d_table), L.stream_handle()),
-                "hn_embed_backward")
+        L.launch("hn_embed_backward", L.ptr(g), C.c_int(dim), C.c_int(0), L.ptr(ctx.idx), C.c_int(n), C.c_int(1),
+                                      C.c_int(dim), C.c_int(ctx.shape[0]), L.ptr(d_table), L.stream_handle())
         return d_table, None
 
 
@@ -188,7 +189,7 @@ def embed_lookup(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 def sample_along_rays(origins, directions, lower, upper, t_rand, scale: float = 1.0, want_points=True):
     """z = lower + (upper-lower)*(scale*t_rand), pts = o + z*d.  lower/upper: (n,) or (B,n)."""
     L.require_gpu(origins, directions, lower)
-    lib = L.load()
+    L.load()
     b = origins.shape[0]
     n = lower.shape[-1]
     if origins.stride(-1) != 1 or directions.stride(-1) != 1 or origins.stride(0) != directions.stride(0):
@@ -198,10 +199,10 @@ def sample_along_rays(origins, directions, lower, upper, t_rand, scale: float = 
     lower = lower.contiguous()
     upper = upper.contiguous() if upper is not None else None
     t_rand = t_rand.contiguous() if t_rand is not None else None
-    L.check(lib.hn_sample_along_rays(L.ptr(origins), L.ptr(directions), C.c_int(origins.stride(0)), L.ptr(lower),
+    L.launch("hn_sample_along_rays", L.ptr(origins), L.ptr(directions), C.c_int(origins.stride(0)), L.ptr(lower),
                                      L.ptr(upper), C.c_int(1 if lower.dim() == 2 else 0), L.ptr(t_rand),
                                      C.c_float(scale), C.c_int(b), C.c_int(n), L.ptr(z), L.ptr(pts),
-                                     L.stream_handle()), "hn_sample_along_rays")
+                                     L.stream_handle())
     return z, pts
 
 
@@ -212,7 +213,7 @@ def sample_pdf(weights, z, u, origins=None, directions=None, want_points=True, b
     midpoints of z (B,S) as bin edges.  General form: `bins` (B,n+1) and `weights` (B,n) given.
     Returns (z_all | None, pts | None, inds (B,Nf) int64, z_samples (B,Nf))."""
     L.require_gpu(weights, u)
-    lib = L.load()
+    L.load()
     nf = u.shape[1]
     dev = u.device
     weights = weights.detach()
@@ -237,11 +238,11 @@ def sample_pdf(weights, z, u, origins=None, directions=None, want_points=True, b
     pts = torch.empty(b, nc + nf, 3, dtype=torch.float32, device=dev) if want_points else None
     inds = torch.empty(b, nf, dtype=torch.int64, device=dev)
     zs = torch.empty(b, nf, dtype=torch.float32, device=dev)
-    L.check(lib.hn_sample_pdf(w_ptr, C.c_int(weights.stride(0)), L.ptr(bins), C.c_int(nb),
+    L.launch("hn_sample_pdf", w_ptr, C.c_int(weights.stride(0)), L.ptr(bins), C.c_int(nb),
                               L.ptr(z if (do_merge or bins is None) else None), C.c_int(nc), L.ptr(u.contiguous()),
                               L.ptr(origins if want_points else None), L.ptr(directions if want_points else None),
                               C.c_int(origins.stride(0) if want_points else 0), C.c_int(b), C.c_int(nf),
-                              L.ptr(z_all), L.ptr(pts), L.ptr(inds), L.ptr(zs), L.stream_handle()), "hn_sample_pdf")
+                              L.ptr(z_all), L.ptr(pts), L.ptr(inds), L.ptr(zs), L.stream_handle())
     return z_all, pts, inds, zs
 
 
@@ -252,7 +253,7 @@ class _CompositeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median):
         L.require_gpu(rgb, raw, z, dirs)
-        lib = L.load()
+        L.load()
         b, s = z.shape
         dev = z.device
         rgb_c, raw_c, z_c = rgb.detach().contiguous(), raw.detach().reshape(b, s).contiguous(), z.contiguous()
@@ -275,7 +276,7 @@ class _CompositeFn(torch.autograd.Function):
         a.out_rgb, a.out_depth, a.out_acc, a.out_weights = o_rgb.data_ptr(), o_depth.data_ptr(), o_acc.data_ptr(), o_w.data_ptr()
         a.out_med_depth = o_md.data_ptr() if o_md is not None else 0
         a.out_med_points = o_mp.data_ptr() if o_mp is not None else 0
-        L.check(lib.hn_composite_forward(C.byref(a), L.stream_handle()), "hn_composite_forward")
+        L.launch("hn_composite_forward", C.byref(a), L.stream_handle())
         ctx.saved = (rgb_c, raw_c, noise_c, z_c, dirs_c)
         ctx.cfg = (variant, int(white_bg), int(sample_at_infinity), b, s)
         ctx.raw_shape = raw.shape
@@ -290,7 +291,7 @@ class _CompositeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_acc, g_w, *unused):
-        lib = L.load()
+        L.load()
         rgb_c, raw_c, noise_c, z_c, dirs_c = ctx.saved
         variant, white_bg, sai, b, s = ctx.cfg
         a = L.HnCompositeArgs()
@@ -306,7 +307,7 @@ class _CompositeFn(torch.autograd.Function):
         d_rgb = torch.empty_like(rgb_c)
         d_raw = torch.empty_like(raw_c)
         a.d_rgb, a.d_raw = d_rgb.data_ptr(), d_raw.data_ptr()
-        L.check(lib.hn_composite_backward(C.byref(a), L.stream_handle()), "hn_composite_backward")
+        L.launch("hn_composite_backward", C.byref(a), L.stream_handle())
         return d_rgb, d_raw.view(ctx.raw_shape), None, None, None, None, None, None, None, None
 
 
@@ -314,3 +315,56 @@ def composite(rgb, raw, noise, z, dirs, warped=None, variant=0, white_bg=False, 
               want_median=True):
     """Returns (rgb (B,3), depth (B), acc (B), weights (B,S)[, med_depth (B)[, med_points (B)]])."""
     return _CompositeFn.apply(rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median)
+
+
+# --------------------------------------------------------------------------------------------
+# stand-alone positional encoders
+# --------------------------------------------------------------------------------------------
+class _PosencFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, freqs, identity, jax_cos):
+        L.require_gpu(x, freqs)
+        L.load()
+        c = x.shape[-1]
+        xf = x.detach().reshape(-1, c).contiguous().float()
+        n, nf = xf.shape[0], freqs.numel()
+        width = c * (2 * nf + (1 if identity else 0))
+        out = torch.empty(n, width, dtype=torch.float32, device=x.device)
+        L.launch("hn_posenc", L.ptr(xf), C.c_int64(n), C.c_int(c), L.ptr(freqs), C.c_int(nf), C.c_int(int(identity)),
+                              C.c_int(int(jax_cos)), L.ptr(out), None, None, L.stream_handle())
+        ctx.save_for_backward(xf, freqs)
+        ctx.cfg = (identity, jax_cos, x.shape)
+        return out.view(*x.shape[:-1], width)
+
+    @staticmethod
+    def backward(ctx, g):
+        L.load()
+        xf, freqs = ctx.saved_tensors
+        identity, jax_cos, shp = ctx.cfg
+        n, c = xf.shape
+        g = g.reshape(n, -1).contiguous()
+        gx = torch.empty_like(xf)
+        L.launch("hn_posenc", L.ptr(xf), C.c_int64(n), C.c_int(c), L.ptr(freqs), C.c_int(freqs.numel()),
+                              C.c_int(int(identity)), C.c_int(int(jax_cos)), None, L.ptr(g), L.ptr(gx),
+                              L.stream_handle())
+        return gx.view(shp), None, None, None
+
+
+def posenc(x, freqs: torch.Tensor, identity: bool, jax_cos: bool = False):
+    return _PosencFn.apply(x, freqs, identity, jax_cos)
+
+
+def sample_legacy(rays, t_vals, one_minus_t, use_disp, t_rand, scale):
+    """nerf_pl coarse sampling with per-ray near/far (columns 6,7 of the ray rows)."""
+    L.require_gpu(rays)
+    L.load()
+    if rays.stride(-1) != 1:
+        rays = rays.contiguous()
+    b, n = rays.shape[0], t_vals.numel()
+    z = torch.empty(b, n, dtype=torch.float32, device=rays.device)
+    pts = torch.empty(b, n, 3, dtype=torch.float32, device=rays.device)
+    t_rand = t_rand.contiguous() if t_rand is not None else None
+    L.launch("hn_sample_legacy", L.ptr(rays), C.c_int(rays.stride(0)), L.ptr(t_vals), L.ptr(one_minus_t),
+                                 C.c_int(int(use_disp)), L.ptr(t_rand), C.c_float(scale), C.c_int(b), C.c_int(n),
+                                 L.ptr(z), L.ptr(pts), L.stream_handle())
+    return z, pts

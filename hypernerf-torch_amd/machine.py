@@ -511,10 +511,8 @@ class MlpRunner:
         if d.ptr_key != pk:
             d.ptrs = torch.tensor(list(pk), dtype=torch.int64).to(device)
             d.ptr_key = pk
-        lib = L.load()
-        L.check(lib.hn_pack_units(C.c_int(mode), L.ptr(d.units), C.c_int(d.n_units), L.ptr(d.ptrs), L.ptr(d.wstream),
-                                  L.ptr(d.bias_desc), C.c_int(d.n_bias), L.ptr(d.bias), L.stream_handle()),
-                "hn_pack_units")
+        L.launch("hn_pack_units", C.c_int(mode), L.ptr(d.units), C.c_int(d.n_units), L.ptr(d.ptrs), L.ptr(d.wstream),
+                 L.ptr(d.bias_desc), C.c_int(d.n_bias), L.ptr(d.bias), L.stream_handle(), tag=self.prog.name)
         d.pack_key = key
         return d
 
@@ -556,7 +554,7 @@ class MlpRunner:
             masks = torch.empty(max(mb, 16), dtype=torch.uint8, device=device)
         a = self._args(d, mode, n_points, samples_per_ray, training, d.fwd_ops, len(self.prog.fwd_ops),
                        d.wstream.data_ptr(), d.fwd_chunks, srcs, dsts, stash, masks, None)
-        L.check(L.load().hn_mlp_forward(C.byref(a), L.stream_handle()), f"hn_mlp_forward[{self.prog.name}]")
+        L.launch("hn_mlp_forward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         return stash, masks
 
     def backward(self, mode, n_points, samples_per_ray, srcs, stash, masks):
@@ -569,8 +567,7 @@ class MlpRunner:
             dsrc = torch.empty(n_points, self.prog.n_dsrc, dtype=torch.float32, device=device)
         a = self._args(d, mode, n_points, samples_per_ray, True, d.bwd_ops, len(self.prog.bwd_ops),
                        d.wstream.data_ptr() + d.n_fwd_units * 1024, d.bwd_chunks, srcs, [], stash, masks, dsrc)
-        lib = L.load()
-        L.check(lib.hn_mlp_backward(C.byref(a), L.stream_handle()), f"hn_mlp_backward[{self.prog.name}]")
+        L.launch("hn_mlp_backward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         jkey = (str(device), mode, n_points)
         if jkey not in self._jobs:
             jobs = self.prog.wgrad_jobs(mode, n_points)
@@ -578,8 +575,8 @@ class MlpRunner:
         jobs_dev, n_jobs = self._jobs[jkey]
         _, gtot = self.prog.grad_offsets()
         grads = torch.zeros(gtot, dtype=torch.float32, device=device)
-        L.check(lib.hn_mlp_wgrad(C.c_int(mode), L.ptr(jobs_dev), C.c_int(n_jobs), L.ptr(stash), L.ptr(grads),
-                                 L.stream_handle()), f"hn_mlp_wgrad[{self.prog.name}]")
+        L.launch("hn_mlp_wgrad", C.c_int(mode), L.ptr(jobs_dev), C.c_int(n_jobs), L.ptr(stash), L.ptr(grads),
+                 L.stream_handle(), tag=self.prog.name)
         return dsrc, grads
 
     def split_grads(self, flat: torch.Tensor) -> List[torch.Tensor]:

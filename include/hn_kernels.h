@@ -192,6 +192,20 @@ int hn_sample_along_rays(const float* origins, const float* dirs, int ray_ld, co
                          const float* upper, int per_ray_bounds, const float* t_rand, float scale,
                          int n_rays, int n, float* z_out, float* pts_out, hnStream_t stream);
 
+/* Legacy nerf_pl sampling with per-ray near/far taken from columns 6,7 of the (B,>=8) ray rows
+ * (models/rendering.py:189-207): z = near*(1-t)+far*t (or the disparity form), optional perturbation
+ * z = lower + (upper-lower)*(scale*t_rand), pts = o + d*z.  t_vals / one_minus_t: (n) from the host. */
+int hn_sample_legacy(const float* rays, int ray_ld, const float* t_vals, const float* one_minus_t,
+                     int use_disp, const float* t_rand, float scale, int n_rays, int n, float* z_out,
+                     float* pts_out, hnStream_t stream);
+
+/* Stand-alone positional encoders: model_utils.posenc_orig (hypernerf/model_utils.py:234-246),
+ * models/nerf.py:4-38 Embedding, and model_utils.posenc (:255-274, jax_cos=1: cos taken as
+ * sin(x + 0.5*3.1415926)).  out = [x if identity][sin(f_k x), cos(f_k x)]_k, blocks of c channels.
+ * Forward: out != NULL, g_out == NULL.  Backward: g_out != NULL, g_x receives d/dx. */
+int hn_posenc(const float* x, int64_t n, int c, const float* freqs, int n_freqs, int identity, int jax_cos,
+              float* out, const float* g_out, float* g_x, hnStream_t stream);
+
 /* Softplus/relu density + alpha compositing.  model_utils.volumetric_rendering
  * (hypernerf/model_utils.py:43-107, 319-362) with NerfModel.query_template's noise+softplus
  * (hypernerf/models.py:485-491); legacy variant models/rendering.py:144-170.

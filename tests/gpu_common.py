@@ -1,0 +1,54 @@
+"""Helpers shared by the GPU parity tests."""
+import numpy as np
+import torch
+
+import hashprng as H
+
+DEV = "cuda:0"
+EMB = {"warp": list(range(100)), "camera": [0], "appearance": list(range(100)), "time": list(range(100))}
+
+
+def rays_for(seed, b, n_img=100):
+    o = H.uniform(seed, "rays_o", (b, 3), -1.0, 1.0)
+    d = H.uniform(seed, "rays_d", (b, 3), -1.0, 1.0)
+    d = d / d.norm(dim=-1, keepdim=True) * H.uniform(seed, "rays_dn", (b, 1), 0.7, 1.6)
+    idx = (H.uniform01(seed, "rays_idx", b) * n_img).astype(np.int64)
+    return o, d, torch.from_numpy(idx)
+
+
+def load_hash(module, seed):
+    sd = module.state_dict()
+    new = H.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed)
+    module.load_state_dict(new)
+    return new
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def assert_close(a, b, tol, what):
+    """max |a-b| <= tol * max(1, max|b|): the north-star's '<=1e-4 rel' read against the tensor's scale."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = float((a - b).abs().max())
+    scale = max(1.0, float(b.abs().max()))
+    assert np.isfinite(err), what
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:.1e} * {scale:.3g}"
+
+
+def assert_grad_close(g, ref, tol, what):
+    """gradients: error measured against the largest reference entry of the tensor."""
+    if ref is None:
+        assert g is None or float(g.abs().max()) == 0.0, what
+        return
+    assert g is not None, what + " missing"
+    g = g.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    err = float((g - ref).abs().max())
+    scale = float(ref.abs().max()) + 1e-12
+    assert np.isfinite(err), what
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:.1e} * {scale:.3g}"

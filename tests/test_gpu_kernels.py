@@ -1,0 +1,171 @@
+"""GPU parity tests (MI355X) for the per-ray kernels and the hardware layout probe.  HIP path vs the CPU
+oracle on identical seeded inputs; bit-exact for sample depths and searchsorted indices."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hashprng as H
+import hypernerf_torch_amd  # noqa: F401
+from gpu_common import DEV, assert_close, assert_grad_close, rays_for
+from hypernerf_torch_amd import _lib as L
+from hypernerf_torch_amd import functional as F
+from hypernerf_torch_amd.hypernerf import model_utils as MU
+from oracle import hypernerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rho(i, h):
+    return (i & 3) + 8 * (i >> 2) + 4 * h
+
+
+def test_probe_mfma_layout():
+    """The MFMA lane maps and the LDS-DMA addressing the kernels are built on, checked on real hardware."""
+    lib = L.load()
+    o1 = torch.zeros(2048, device=DEV)
+    o2 = torch.zeros(1024, device=DEV)
+    o3 = torch.zeros(512, device=DEV)
+    o3[256:] = torch.arange(256, device=DEV, dtype=torch.float32) * 3.0 + 1.0
+    L.check(lib.hn_probe_mfma(L.ptr(o1), L.ptr(o2), L.ptr(o3), L.stream_handle()), "probe")
+    torch.cuda.synchronize()
+    a = o1.cpu().numpy()
+    d1, d2 = a[:1024].reshape(64, 16), a[1024:].reshape(64, 16)
+    f = o2.cpu().numpy().reshape(64, 16)
+    for l in range(64):
+        col, h = l & 31, l >> 5
+        for q in range(16):
+            i = rho(q, h)
+            assert d1[l, q] == i, ("bf16 C/D row map", l, q, d1[l, q], i)
+            assert d2[l, q] == (col & 15), ("bf16 A/B k pairing", l, q, d2[l, q])
+            assert abs(f[l, q] - (i + (i + 1000) * 0.5 * col)) < 1e-3, ("f32 mfma", l, q, f[l, q])
+    g = o3.cpu().numpy()
+    assert np.array_equal(g[:256], g[256:]), "global_load_lds: LDS image must be lane-linear"
+
+
+def test_sample_along_rays_bitexact():
+    o, d, _ = rays_for(3, 37)
+    t = H.uniform(3, "t", (37, 64), 0, 1)
+    z_ref, p_ref = O.sample_along_rays(o, d, 64, 0.0, 1.0, t)
+    z, p = MU.sample_along_rays(o.to(DEV), d.to(DEV), 64, 0.0, 1.0, True, False, t_rand=t.to(DEV))
+    assert torch.equal(z.cpu(), z_ref), "stratified z must be bit-exact"
+    assert torch.equal(p.cpu(), p_ref), "points must be bit-exact"
+    z_ref, p_ref = O.sample_along_rays(o, d, 16, 0.5, 4.0, t[:, :16].contiguous(), lindisp=True)
+    z, p = MU.sample_along_rays(o.to(DEV), d.to(DEV), 16, 0.5, 4.0, True, True, t_rand=t[:, :16].contiguous().to(DEV))
+    assert torch.equal(z.cpu(), z_ref) and torch.equal(p.cpu(), p_ref)
+    z_ref, _ = O.sample_along_rays(o, d, 16, 0.0, 1.0, None)
+    z, _ = MU.sample_along_rays(o.to(DEV), d.to(DEV), 16, 0.0, 1.0, False, False)
+    assert torch.equal(z.cpu(), z_ref)
+
+
+def test_golden_g08(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g08_sample.npz"))
+    o, d = torch.from_numpy(g["o"]).to(DEV), torch.from_numpy(g["d"]).to(DEV)
+    z, p = MU.sample_along_rays(o, d, 16, 0.0, 1.0, True, False, t_rand=torch.from_numpy(g["t_rand"]).to(DEV))
+    assert np.array_equal(z.cpu().numpy(), g["z_strat"]) and np.array_equal(p.cpu().numpy(), g["p_strat"])
+
+
+@pytest.mark.parametrize("s", [8, 64, 128, 192, 70])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_composite_vs_oracle(s, variant):
+    b = 19
+    o, d, _ = rays_for(5, b)
+    rgb = H.uniform(5, "rgb", (b, s, 3), 0, 1)
+    raw = H.uniform(5, "raw", (b, s), -3, 6)
+    raw[0] = -30.0
+    raw[1] = 25.0
+    noise = H.normal(5, "noise", (b, s)) * 0.5
+    z, _ = torch.sort(H.uniform(5, "z", (b, s), 0, 1), dim=-1)
+    warped = H.uniform(5, "wp", (b, s, 7), -1, 1)
+    rgb_t, raw_t = rgb.clone().requires_grad_(True), raw.clone().requires_grad_(True)
+    if variant == 0:
+        ref = O.volumetric_rendering(rgb_t, torch.nn.functional.softplus(raw_t + noise), z, d, white_bg=False)
+        refs = [ref["rgb"], ref["depth"], ref["acc"], ref["weights"], ref["med_depth"]]
+    else:
+        deltas = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1) * torch.norm(d[:, None, :], dim=-1)
+        alphas = 1 - torch.exp(-deltas * torch.relu(raw_t + noise))
+        shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
+        w = alphas * torch.cumprod(shifted, -1)[:, :-1]
+        refs = [(w[..., None] * rgb_t).sum(-2) + 1 - w.sum(1)[:, None], (w * z).sum(-1), w.sum(1), w]
+    rgb_g = rgb.to(DEV).requires_grad_(True)
+    raw_g = raw.to(DEV).requires_grad_(True)
+    outs = F.composite(rgb_g, raw_g, noise.to(DEV), z.to(DEV), d.to(DEV), warped.to(DEV) if variant == 0 else None,
+                       variant=variant, white_bg=(variant == 1), sample_at_infinity=True, want_median=(variant == 0))
+    names = ["rgb", "depth", "acc", "weights", "med_depth"]
+    for i, r in enumerate(refs):
+        assert_close(outs[i], r, 2e-5, f"composite {names[i]} S={s} v={variant}")
+    if variant == 0:
+        _, di = O.median_depth_index(ref["weights"])
+        mp = torch.gather(warped, -2, di[..., None, None])[:, 0, 0]
+        assert_close(outs[5], mp, 1e-6, "med_points")
+    gr = [H.uniform(6, f"g{i}", tuple(refs[i].shape), -1, 1) for i in range(4)]
+    sum((r * g).sum() for r, g in zip(refs[:4], gr)).backward()
+    sum((outs[i] * gr[i].to(DEV)).sum() for i in range(4)).backward()
+    assert_grad_close(rgb_g.grad, rgb_t.grad, 5e-5, "d rgb")
+    assert_grad_close(raw_g.grad, raw_t.grad, 5e-5, "d raw")
+
+
+def test_sample_pdf_bitexact_indices():
+    b, nc, nf = 333, 64, 128
+    o, d, _ = rays_for(7, b)
+    z, _ = torch.sort(H.uniform(7, "z", (b, nc), 0, 1), dim=-1)
+    w = H.uniform(7, "w", (b, nc), 0, 1) ** 4
+    w[0] = 0.0
+    w[1] = 0.0
+    w[1, 20] = 1.0
+    u = H.uniform(7, "u", (b, nf), 0, 1)
+    u[2, 0] = 0.0
+    mid = 0.5 * (z[:, 1:] + z[:, :-1])
+    z_ref, p_ref, inds_ref = O.sample_pdf(mid, w[:, 1:-1], o, d, z, u)
+    zs_ref, _ = O.piecewise_constant_pdf(mid, w[:, 1:-1], u)
+    z_all, pts, inds, zs = F.sample_pdf(w.to(DEV), z.to(DEV), u.to(DEV), o.to(DEV), d.to(DEV))
+    assert torch.equal(inds.cpu(), inds_ref), "searchsorted indices must be bit-exact"
+    assert torch.equal(zs.cpu(), zs_ref), "fine samples must be bit-exact"
+    assert torch.equal(z_all.cpu(), z_ref), "merged sorted depths must be bit-exact"
+    assert torch.equal(pts.cpu(), p_ref)
+    # general form (explicit bins / weights), no merge
+    zs2 = MU.piecewise_constant_pdf(mid.to(DEV), w[:, 1:-1].contiguous().to(DEV), nf, True, u=u.to(DEV))
+    assert torch.equal(zs2.cpu(), zs_ref)
+
+
+def test_golden_g10(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g10_pdf.npz"))
+    T = lambda k: torch.from_numpy(g[k]).to(DEV)
+    z_all, pts = MU.sample_pdf(T("bins"), T("w"), T("o"), T("d"), T("z"), 16, True, u=T("u"))
+    _, _, inds, zs = F.sample_pdf(T("w"), T("z"), T("u"), bins=T("bins"), merge=False)
+    assert np.array_equal(inds.cpu().numpy(), g["inds"]), "indices vs the reference itself"
+    np.testing.assert_allclose(zs.cpu().numpy(), g["z_samples"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(z_all.cpu().numpy(), g["z_all"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(pts.cpu().numpy(), g["pts"], rtol=1e-6, atol=1e-6)
+
+
+def test_embed_and_posenc():
+    tab = H.uniform(9, "tab", (100, 8), -1, 1)
+    idx = torch.from_numpy((H.uniform01(9, "i", 57) * 100).astype(np.int64))
+    tg = tab.to(DEV).requires_grad_(True)
+    out = F.embed_lookup(tg, idx.to(DEV))
+    assert torch.equal(out.cpu(), tab[idx])
+    g = H.uniform(9, "g", (57, 8), -1, 1)
+    (out * g.to(DEV)).sum().backward()
+    tr = tab.clone().requires_grad_(True)
+    (tr[idx] * g).sum().backward()
+    assert_grad_close(tg.grad, tr.grad, 1e-6, "embedding grad")
+    x = H.uniform(9, "x", (11, 5, 3), -2, 2)
+    xg = x.to(DEV).requires_grad_(True)
+    freqs = (2.0 ** torch.arange(10)).float().to(DEV)
+    y = F.posenc(xg, freqs, True)
+    xr = x.clone().requires_grad_(True)
+    yr = O.posenc_orig(xr, 10)
+    assert_close(y, yr, 2e-6, "posenc_orig")
+    gy = H.uniform(9, "gy", tuple(yr.shape), -1, 1)
+    (y * gy.to(DEV)).sum().backward()
+    (yr * gy).sum().backward()
+    assert_grad_close(xg.grad, xr.grad, 1e-5, "posenc grad")
+
+
+def test_cpu_tensor_fails_loudly():
+    o, d, _ = rays_for(1, 4)
+    with pytest.raises(L.HnError):
+        MU.sample_along_rays(o, d, 8, 0.0, 1.0, True, False)

@@ -1,0 +1,302 @@
+"""GPU parity tests (MI355X): the fused MLP machine and the full render path against the CPU oracle and the
+committed golden fixtures (outputs of the reference itself).
+
+Tolerances.  fp32 mode (v_mfma_f32_32x32x2_f32, exact fp32 products): the north-star's 1e-4, measured as
+max|a-b| <= 1e-4 * max(1, max|ref|) per tensor.  bf16 mode (bf16 operands, fp32 accumulate): 3e-2 on rgb-like
+outputs — bf16 has 8 significand bits and the template stacks 14 layers; its acceptance criterion is PSNR
+(bench.py reports the bf16-vs-fp32 PSNR gap), this test only guards against structural errors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hashprng as H
+import hypernerf_torch_amd as HN
+from gpu_common import DEV, EMB, assert_close, assert_grad_close, load_hash, rays_for
+from hypernerf_torch_amd import _lib as L
+from hypernerf_torch_amd.hypernerf import models, modules, warping
+from hypernerf_torch_amd.models import nerf as legacy_nerf
+from hypernerf_torch_amd.models import rendering as legacy_rendering
+from oracle import hypernerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 1e-4, "bf16": 3e-2}
+GTOL = {"fp32": 2e-3, "bf16": 1.5e-1}
+
+
+@pytest.fixture(params=["fp32", "bf16"])
+def precision(request):
+    old = HN.get_precision()
+    HN.set_precision(request.param)
+    yield request.param
+    HN.set_precision(old)
+
+
+def test_mlp_standalone(precision):
+    m = modules.MLP(in_ch=20, out_ch=3, depth=6, width=128)
+    sd = load_hash(m, 3)
+    x = H.uniform(3, "x", (7, 9, 20), -1, 1)
+    y_ref = O.mlp({"m." + k: v.clone().requires_grad_(True) for k, v in sd.items()}, "m", x, depth=6)
+    m = m.to(DEV)
+    y = m(x.to(DEV))
+    assert_close(y, y_ref, TOL[precision], "MLP forward")
+
+
+@pytest.mark.parametrize("n", [64, 100, 1000])
+def test_translation_field(precision, n):
+    tf = warping.TranslationField(in_ch=3, in_ch_embed=8)
+    sd = load_hash(tf, 5)
+    b, s = n // 4 if n % 4 == 0 else n, 4 if n % 4 == 0 else 1
+    pts = H.uniform(5, "pts", (b, s, 3), -1.2, 1.2)
+    emb = H.uniform(5, "emb", (b, 8), -0.5, 0.5)
+    tp = {"w." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    er = emb.clone().requires_grad_(True)
+    y_ref = O.translation_field(tp, "w", pts, er[:, None, :].expand(b, s, 8))
+    tf = tf.to(DEV)
+    eg = emb.to(DEV).requires_grad_(True)
+    y = tf.warp(pts.to(DEV), eg, None)
+    assert_close(y, y_ref, TOL[precision], "warp forward")
+    g = H.uniform(6, "g", (b, s, 3), -1, 1)
+    (y_ref * g).sum().backward()
+    (y * g.to(DEV)).sum().backward()
+    assert_grad_close(eg.grad, er.grad, GTOL[precision], "d embed")
+    for k, prm in tf.named_parameters():
+        assert_grad_close(prm.grad, tp["w." + k].grad, GTOL[precision], "d " + k)
+
+
+def test_hyper_sheet_and_broadcast_embed(precision):
+    hs = modules.HyperSheetMLP(out_ch=4, in_ch_embed=8)
+    sd = load_hash(hs, 6)
+    b, s = 6, 16
+    pts = H.uniform(5, "pts", (b, s, 3), -1.2, 1.2)
+    emb = H.uniform(5, "emb", (b, 8), -0.5, 0.5)
+    y_ref = O.hyper_sheet({"h." + k: v for k, v in sd.items()}, "h", pts, emb[:, None, :].expand(b, s, 8))
+    hs = hs.to(DEV)
+    y1 = hs(pts.to(DEV), emb.to(DEV))                                   # per-ray embedding
+    y2 = hs(pts.to(DEV), emb.to(DEV)[:, None, :].expand(b, s, 8))       # the reference's broadcast form
+    assert_close(y1, y_ref, TOL[precision], "sheet (per-ray)")
+    assert_close(y2, y_ref, TOL[precision], "sheet (broadcast)")
+
+
+def test_golden_fields(golden_dir, precision):
+    g = np.load(os.path.join(golden_dir, "g05_fields.npz"))
+    pts, emb = torch.from_numpy(g["pts"]).to(DEV), torch.from_numpy(g["emb"]).to(DEV)
+    tf = warping.TranslationField(in_ch=3, in_ch_embed=8); load_hash(tf, 5)
+    hs = modules.HyperSheetMLP(out_ch=4, in_ch_embed=8); load_hash(hs, 6)
+    assert_close(tf.to(DEV)(pts, emb, None)["warped_points"], torch.from_numpy(g["y_warp"]), TOL[precision], "G5")
+    assert_close(hs.to(DEV)(pts, emb), torch.from_numpy(g["y_sheet"]), TOL[precision], "G6")
+
+
+def test_golden_nerfmlp(golden_dir, precision):
+    g = np.load(os.path.join(golden_dir, "g07_nerfmlp.npz"))
+    for tag, acd in (("cond", 8), ("nocond", 0)):
+        nm = modules.NerfMLP(in_ch=115, trunk_depth=8, trunk_width=256, rgb_branch_depth=4, rgb_branch_width=128,
+                             hidden_activation=torch.nn.ReLU(), skips=[4], rgb_activation=torch.nn.Sigmoid(),
+                             alpha_condition_dim=acd, rgb_condition_dim=39)
+        load_hash(nm, 7)
+        nm = nm.to(DEV)
+        ac = torch.from_numpy(g["ac"]).to(DEV) if acd else None
+        y = nm(torch.from_numpy(g["x"]).to(DEV), alpha_condition=ac, rgb_condition=torch.from_numpy(g["rc"]).to(DEV))
+        assert_close(y["rgb"], torch.from_numpy(g["rgb_" + tag]), TOL[precision], "G7 rgb " + tag)
+        assert_close(y["alpha"], torch.from_numpy(g["alpha_" + tag]), TOL[precision], "G7 alpha " + tag)
+
+
+CASES = {
+    "bendy": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=False, use_alpha_cond=False),
+    "bendy_cond": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True),
+    "bendy_rgbcond": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True,
+                          use_rgb_cond=True),
+    "nowarp": dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=False, use_alpha_cond=False),
+    "nowarp_cond": dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=True, use_alpha_cond=True),
+    "warp_noslice": dict(use_warp=True, hyper_slice_method=None, use_nerf_embed=False, use_alpha_cond=False,
+                         hyper_slice_out_dim=0),
+    "axis": dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_nerf_embed=False,
+                 use_alpha_cond=False),
+}
+
+
+def fixtures(golden_dir):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(golden_dir, "g11_model_*.npz")))
+
+
+def rng_from_fixture(g):
+    kinds = g["draw_kinds"].tolist()
+    draws = [torch.from_numpy(g[f"draw{i}"]) for i in range(len(kinds))]
+    rng, it = {}, iter(zip(kinds, draws))
+    k, t = next(it); rng["t_rand"] = t
+    k, t = next(it)
+    if k == "randn":
+        rng["noise_coarse"] = t * float(g["noise_std"]); k, t = next(it)
+    rng["u"] = t
+    rest = list(it)
+    if rest:
+        rng["noise_fine"] = rest[0][1] * float(g["noise_std"])
+    return rng
+
+
+def grad_stats_close(named_grads, g, prefix, tol):
+    """Compare with the reference's gradient summaries (sum / abs-sum / L2 + 16 sampled entries)."""
+    for name, grad in named_grads.items():
+        if prefix + name + "/none" in g:
+            assert grad is None or float(grad.abs().sum()) == 0.0, name
+            continue
+        stats = g[prefix + name + "/stats"]
+        gd = grad.detach().double().cpu().reshape(-1)
+        mine = np.array([gd.sum().item(), gd.abs().sum().item(), gd.pow(2).sum().sqrt().item()])
+        assert abs(mine[2] - stats[2]) <= tol * max(stats[2], 1e-12), (name, "L2", mine, stats)
+        assert abs(mine[1] - stats[1]) <= tol * max(stats[1], 1e-12), (name, "abs-sum", mine, stats)
+        idx = torch.from_numpy(g[prefix + name + "/idx"])
+        ref = g[prefix + name + "/val"]
+        assert float(np.abs(gd[idx].numpy() - ref).max()) <= tol * float(gd.abs().max()) + 1e-12, (name, "samples")
+
+
+@pytest.mark.parametrize("fixture", fixtures(os.path.join(os.path.dirname(__file__), "golden")))
+def test_golden_model_fp32(golden_dir, fixture):
+    """Full NerfModel forward + loss + backward in fp32 mode vs the outputs of the reference itself."""
+    HN.set_precision("fp32")
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    case = [c for c in sorted(CASES, key=len, reverse=True) if fixture.startswith("g11_model_" + c + "_")][0]
+    nc, nf, b, seed = int(g["nc"]), int(g["nf"]), int(g["b"]), int(g["seed"])
+    m = models.NerfModel(EMB, near=0.0, far=1.0, n_samples_coarse=nc, n_samples_fine=nf,
+                         noise_std=float(g["noise_std"]) or None, view_fourier_dim=6, **CASES[case])
+    assert sorted(m.state_dict().keys()) == g["keys"].tolist()
+    load_hash(m, seed)
+    m = m.to(DEV)
+    o, d, idx = rays_for(seed, b)
+    rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+            "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+    rng = {k: v.to(DEV) for k, v in rng_from_fixture(g).items()}
+    out = m(rays, {}, rng=rng)
+    inds = m.last_sampling["inds"].cpu().numpy()
+    flips = int((inds != g["fine/inds"]).sum())
+    assert flips == 0, f"{flips} fine-sample indices differ from the reference (tie margin of the fixture is 1e-5)"
+    for lvl in ("coarse", "fine"):
+        for k in ("points", "warped_points", "rgb", "depth", "med_depth", "acc", "weights", "med_points"):
+            tol = 1e-4 if not (lvl == "fine" and k in ("warped_points",)) else 2e-4
+            assert_close(out[lvl][k], torch.from_numpy(g[f"{lvl}/{k}"]), tol, f"{fixture} {lvl}/{k}")
+    gt = H.uniform(seed, "gt", (b, 3), 0.0, 1.0).to(DEV)
+    loss = ((out["coarse"]["rgb"] - gt) ** 2).mean() + ((out["fine"]["rgb"] - gt) ** 2).mean()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * max(1.0, float(g["loss"]))
+    loss.backward()
+    grad_stats_close({k: v.grad for k, v in m.named_parameters()}, g, "grad/", 5e-3)
+
+
+@pytest.mark.parametrize("case", ["bendy_cond", "nowarp", "axis"])
+def test_model_vs_oracle_larger(case, precision):
+    """B=96 rays x (32+32): full tensors and full gradients against the oracle (same draws)."""
+    kw = CASES[case]
+    nc = nf = 32
+    b, seed = 96, 77
+    m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, view_fourier_dim=6, **kw)
+    sd = load_hash(m, seed)
+    m = m.to(DEV)
+    o, d, idx = rays_for(seed, b)
+    rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1),
+           "noise_coarse": H.normal(seed, "n1", (b, nc, 1)) * 0.5, "noise_fine": H.normal(seed, "n2", (b, nc + nf, 1)) * 0.5}
+    cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, view_fourier_dim=6, **kw)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.nerf_model_forward(p, cfg, o, d, idx, rng)
+    gt = H.uniform(seed, "gt", (b, 3), 0, 1)
+    O.mse_loss(ref, gt).backward()
+    rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+            "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+    out = m(rays, {}, rng={k: v.to(DEV) for k, v in rng.items()})
+    tol = TOL[precision]
+    for k in ("rgb", "depth", "acc", "weights", "warped_points"):
+        assert_close(out["coarse"][k], ref["coarse"][k], tol, f"{case} coarse/{k}")
+    if precision == "fp32":
+        same = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).float().mean().item()
+        assert same > 0.999, f"only {same:.4f} of fine-sample indices agree"
+        for k in ("rgb", "depth", "acc", "weights"):
+            assert_close(out["fine"][k], ref["fine"][k], 5e-4, f"{case} fine/{k}")
+    loss = ((out["coarse"]["rgb"] - gt.to(DEV)) ** 2).mean() + ((out["fine"]["rgb"] - gt.to(DEV)) ** 2).mean()
+    loss.backward()
+    for k, prm in m.named_parameters():
+        assert_grad_close(prm.grad, p[k].grad, GTOL[precision] * (1 if precision == "fp32" else 2), f"{case} d {k}")
+
+
+LEGACY = {
+    "c_only": dict(N_samples=16, N_importance=0, perturb=0, noise_std=0),
+    "c_only_pert_noise": dict(N_samples=16, N_importance=0, perturb=1, noise_std=1),
+    "cf_det": dict(N_samples=16, N_importance=16, perturb=0, noise_std=0),
+    "cf_pert_noise": dict(N_samples=16, N_importance=16, perturb=1, noise_std=1),
+    "cf_white": dict(N_samples=16, N_importance=16, perturb=1, noise_std=0, white_back=True),
+    "cf_test_time": dict(N_samples=16, N_importance=16, perturb=0, noise_std=0, test_time=True),
+    "cf_disp": dict(N_samples=16, N_importance=8, perturb=1, noise_std=1, use_disp=True),
+    "c64": dict(N_samples=64, N_importance=0, perturb=1, noise_std=1),
+}
+
+
+def legacy_rng(g, kw):
+    kinds = g["draw_kinds"].tolist()
+    draws = [torch.from_numpy(g[f"draw{i}"]) for i in range(len(kinds))]
+    rng, i = {}, 0
+    if kw["perturb"] > 0:
+        rng["perturb_rand"] = draws[i]; i += 1
+    rng["noise_coarse"] = draws[i]; i += 1
+    if kw["N_importance"] > 0:
+        if kw["perturb"] > 0:
+            rng["u"] = draws[i]; i += 1
+        rng["noise_fine"] = draws[i]; i += 1
+    return rng
+
+
+@pytest.mark.parametrize("name", sorted(LEGACY))
+def test_golden_legacy_render_rays(golden_dir, name):
+    """nerf_pl render_rays (BASELINE config 1 family) in fp32 mode vs the reference's outputs."""
+    HN.set_precision("fp32")
+    g = np.load(os.path.join(golden_dir, "g12_legacy_" + name + ".npz"))
+    kw = LEGACY[name]
+    seed = int(g["seed"])
+    coarse, fine = legacy_nerf.NeRF(), legacy_nerf.NeRF()
+    assert sorted(coarse.state_dict().keys()) == g["keys"].tolist()
+    load_hash(coarse, seed); load_hash(fine, seed + 1)
+    coarse, fine = coarse.to(DEV), fine.to(DEV)
+    emb = [legacy_nerf.Embedding(3, 10), legacy_nerf.Embedding(3, 4)]
+    rays = torch.from_numpy(g["rays"]).to(DEV)
+    rng = {k: v.to(DEV) for k, v in legacy_rng(g, kw).items()}
+    res = legacy_rendering.render_rays([coarse, fine], emb, rays, rng=rng, **kw)
+    for k in [k for k in g.files if k.startswith("out/")]:
+        assert_close(res[k[4:]], torch.from_numpy(g[k]), 1e-4 if k.endswith("coarse") else 3e-4, f"{name} {k}")
+    if "loss" in g.files:
+        b = rays.shape[0]
+        gt = H.uniform(seed, "gt", (b, 3), 0.0, 1.0).to(DEV)
+        loss = ((res["rgb_coarse"] - gt) ** 2).mean()
+        if "rgb_fine" in res:
+            loss = loss + ((res["rgb_fine"] - gt) ** 2).mean()
+        assert abs(float(loss) - float(g["loss"])) <= 1e-4
+        loss.backward()
+        grad_stats_close({k: v.grad for k, v in coarse.named_parameters()}, g, "gradc/", 5e-3)
+        if "rgb_fine" in res:
+            grad_stats_close({k: v.grad for k, v in fine.named_parameters()}, g, "gradf/", 5e-3)
+
+
+def test_config2_full_size_properties():
+    """BASELINE config 2 (1024 rays x (64+64), bendy sheet, bf16): size-independent properties of the result."""
+    HN.set_precision("bf16")
+    torch.manual_seed(0)
+    m = models.NerfModel(EMB, n_samples_coarse=64, n_samples_fine=64, noise_std=1.0,
+                         hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True,
+                         view_fourier_dim=6).to(DEV)
+    o, d, idx = rays_for(11, 1024)
+    rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+            "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+    out = m(rays, {})
+    for lvl, s in (("coarse", 64), ("fine", 128)):
+        r = out[lvl]
+        assert r["rgb"].shape == (1024, 3) and r["weights"].shape == (1024, s)
+        assert r["warped_points"].shape == (1024, s, 7) and r["med_points"].shape == (1024, 1, 1)
+        assert torch.isfinite(r["rgb"]).all() and (r["rgb"] >= 0).all() and (r["rgb"] <= 1.0 + 1e-3).all()
+        assert (r["weights"] >= 0).all() and (r["weights"].sum(-1) <= 1.0 + 1e-2).all()
+        assert torch.allclose(r["acc"], r["weights"][:, :-1].sum(-1), atol=1e-5)
+    z = m.last_sampling["z_fine"]
+    assert (z[:, 1:] >= z[:, :-1]).all(), "merged fine depths must be sorted"
+    loss = (out["coarse"]["rgb"] ** 2).mean() + (out["fine"]["rgb"] ** 2).mean()
+    loss.backward()
+    for k, prm in m.named_parameters():
+        if k.startswith("nerf_embed"):
+            continue    # unused when GLO tables are shared
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
