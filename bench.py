@@ -125,7 +125,7 @@ def main():
         "config": {"workload": f"NerfModel use_warp bendy_sheet nerf_embed+alpha_cond, {b} rays x ({a.nc}+{a.nf}) "
                                f"samples per GPU, fwd+bwd+Adam", "rays_per_gpu": b, "n_samples": a.nc,
                    "n_importance": a.nf, "parallelism": f"dp{world}"},
-        "per_gpu": value / world, "final_loss": float(loss),
+        "per_gpu": value / world, "final_loss": float(loss.detach()),
     }
 
     if rank == 0 and not a.no_roofline:
@@ -176,7 +176,11 @@ def cpu_baseline(a):
     from gpu_common import EMB, rays_for
     from hypernerf_torch_amd.hypernerf.models import NerfModel
     from oracle import hypernerf_oracle as O
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))        # cores this process may actually use (cgroup-aware)
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
     b = 64
     kw = dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True)

@@ -106,7 +106,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into csrc/libhn_hip.so (cross-compiles without a GPU)."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
            "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:

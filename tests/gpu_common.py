@@ -40,15 +40,21 @@ def assert_close(a, b, tol, what):
     assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:.1e} * {scale:.3g}"
 
 
-def assert_grad_close(g, ref, tol, what):
-    """gradients: error measured against the largest reference entry of the tensor."""
+def assert_grad_close(g, ref, tol, what, frobenius=False):
+    """gradients: max error measured against the largest reference entry of the tensor; with
+    frobenius=True the relative L2 error of the whole tensor (bf16 mode: a single ReLU that flips under
+    bf16 rounding moves one summand of a small-batch gradient by O(1), so max-norm is meaningless there)."""
     if ref is None:
         assert g is None or float(g.abs().max()) == 0.0, what
         return
     assert g is not None, what + " missing"
     g = g.detach().double().cpu()
     ref = ref.detach().double().cpu()
+    assert torch.isfinite(g).all(), what
+    if frobenius:
+        err = float((g - ref).norm() / (ref.norm() + 1e-30))
+        assert err <= tol, f"{what}: relative L2 err {err:.3e} > {tol:.1e}"
+        return
     err = float((g - ref).abs().max())
     scale = float(ref.abs().max()) + 1e-12
-    assert np.isfinite(err), what
     assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:.1e} * {scale:.3g}"
