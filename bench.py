@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     return ap.parse_args()
 
 
@@ -68,10 +69,10 @@ def main():
                       hyper_slice_method="bendy_sheet", use_warp=True, use_nerf_embed=True, use_alpha_cond=True,
                       view_fourier_dim=6).to(dev)
     params = [p for p in model.parameters()]
-    try:
-        opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8, fused=True)
-    except Exception:
-        opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8, foreach=True)
+    use_graph = not a.no_graph
+    # the optimizer step is part of the captured graph on one GPU; with N>1 the gradient all-reduce sits between
+    # the captured forward+backward and an eager fused Adam
+    opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8, fused=True, capturable=(use_graph and world == 1))
     bucket = GradBucket(params)
     loss_fn = MSELoss()
 
@@ -85,16 +86,40 @@ def main():
     target = torch.rand(b, 3, generator=g).to(dev)
     extra = {'nerf_alpha': None, 'warp_alpha': None, 'hyper_alpha': None, 'hyper_sheet_alpha': None}
 
-    def step():
+    def fwd_bwd():
         rd = model_utils.prepare_ray_dict(rays)
         out = model(rd, extra)
         loss = loss_fn(out, target)
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        return out, loss
+
+    def eager_step():
+        out, loss = fwd_bwd()
         if world > 1:
             bucket.all_reduce_mean()
         opt.step()
         return out, loss
+
+    def whole_step():
+        out, loss = fwd_bwd()
+        opt.step()
+        return out, loss
+
+    if use_graph:
+        from hypernerf_torch_amd.graphs import GraphedStep
+        if world == 1:
+            step = GraphedStep(whole_step, warmup=3)
+        else:
+            gfb = GraphedStep(fwd_bwd, warmup=3)
+
+            def step():
+                res = gfb()
+                bucket.all_reduce_mean()
+                opt.step()
+                return res
+    else:
+        step = eager_step
 
     def barrier():
         if world > 1:
@@ -124,7 +149,7 @@ def main():
         "dtype": a.precision, "data": "synthetic",
         "config": {"workload": f"NerfModel use_warp bendy_sheet nerf_embed+alpha_cond, {b} rays x ({a.nc}+{a.nf}) "
                                f"samples per GPU, fwd+bwd+Adam", "rays_per_gpu": b, "n_samples": a.nc,
-                   "n_importance": a.nf, "parallelism": f"dp{world}"},
+                   "n_importance": a.nf, "parallelism": f"dp{world}", "hip_graph": use_graph},
         "per_gpu": value / world, "final_loss": float(loss.detach()),
     }
 
@@ -132,7 +157,7 @@ def main():
         # second pass: the same steps with HIP events around every C-ABI launch (on the launch stream)
         L.KERNEL_TIMES = {}
         for _ in range(a.steps):
-            step()
+            eager_step()
         times = L.collect_kernel_times()
         L.KERNEL_TIMES = None
         tot = {k: sum(v) for k, v in times.items()}

@@ -169,6 +169,13 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   Frag nxt[8 * M::STEPS32];
   f32x16 accL;
 
+  // biases and the feature table live in LDS for the whole kernel: no global loads inside the MFMA loops
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * HN_CHUNK_UNITS * 1024);
+  HnFeat* feat_lds = reinterpret_cast<HnFeat*>(bias_lds + ((a.n_bias + 3) & ~3));
+  for (int i = threadIdx.x; i < a.n_bias; i += blockDim.x) bias_lds[i] = a.bias[i];
+  for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
+  __syncthreads();
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int blk = tile * M::WAVES + wave;  // 32-point block of this wave
     const int p0 = blk * 32 + r;
@@ -184,14 +191,14 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
       if (code == HN_OP_LAYER) {
         const int K32 = w[1] & 255, nG = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
         const int act = (w[1] >> 24) & 15, flags = (w[1] >> 28) & 15;
-        const float* bias = a.bias + w[2];
+        const float* bias = bias_lds + w[2];
         const bool do_mask = a.training && w[4] >= 0 && wave_valid;
         const bool do_stash = a.training && w[5] >= 0 && wave_valid;
         Frag aux[HN_AUXG_MAX * 2 * M::STEPS32];
 #pragma unroll
         for (int g = 0; g < HN_AUXG_MAX; ++g) {
           if (g < nG) {
-            hn_make_group(aux + g * 2 * M::STEPS32, a.feat + w[3] + 64 * g, a, p, ray, valid, lane);
+            hn_make_group(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, a, p, ray, valid, lane);
             if (a.training && w[6] >= 0 && wave_valid) {
               hn_stash<BF16>(aux + g * 2 * M::STEPS32, a, w[6], blk, 2 * g, lane);
               hn_stash<BF16>(aux + (g * 2 + 1) * M::STEPS32, a, w[6], blk, 2 * g + 1, lane);
@@ -295,7 +302,10 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   const int r = lane & 31, h = lane >> 5;
   constexpr int PTS = M::WAVES * 32;
   const int ntiles = (a.n_points + PTS - 1) / PTS;
-  float* dsrc_lds = reinterpret_cast<float*>(smem + 2 * HN_CHUNK_UNITS * 1024) + wave * (32 * HN_DSRC_COMPS);
+  HnFeat* feat_lds = reinterpret_cast<HnFeat*>(smem + 2 * HN_CHUNK_UNITS * 1024);
+  float* dsrc_lds = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (32 * HN_DSRC_COMPS);
+  for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
+  __syncthreads();
 
   WStream<M::WAVES> ws;
   ws.g = reinterpret_cast<const char*>(a.wstream);
@@ -382,6 +392,14 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const bool has_mask = w[4] >= 0;
         const bool do_stash = a.training && w[5] >= 0 && wave_valid;
         unsigned bits = 0xffffffffu;
+        unsigned mbits[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        if (has_mask) {   // all relu masks of the layer up front: one VMEM wait per layer, none per tile
+          const HnSlot sl = a.slots[w[4]];
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd)
+            if (2 * dd < NT)
+              mbits[dd] = wave_valid ? a.masks[sl.off / 4 + ((size_t)blk * sl.nt + dd) * 64 + lane] : 0u;
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           if (t < NT) {
@@ -389,10 +407,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             hn_init_acc(acc, nullptr, t, h);
             hn_gemm_k<BF16>(acc, cur, K32, ws);
             if (K32b) hn_gemm_blocks<BF16, 1>(acc, cur2, ws);
-            if (has_mask && !(t & 1)) {
-              const HnSlot sl = a.slots[w[4]];
-              bits = wave_valid ? a.masks[sl.off / 4 + ((size_t)blk * sl.nt + (t >> 1)) * 64 + lane] : 0u;
-            }
+            if (!(t & 1)) bits = mbits[t >> 1];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               const bool keep = ((bits >> (16 * (t & 1) + i)) & 1u) != 0u;
@@ -415,7 +430,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
           hn_init_acc(acc, nullptr, 0, h);
           hn_gemm_k<BF16>(acc, cur, K32, ws);
           if (K32b) hn_gemm_blocks<BF16, 1>(acc, cur2, ws);
-          const HnFeat* ft = a.feat + w[3] + 32 * tt;
+          const HnFeat* ft = feat_lds + w[3] + 32 * tt;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const HnFeat e = ft[hn_rho(i, h)];
@@ -616,7 +631,7 @@ static void hn_allow_big_lds() {
   static bool done = false;
   if (done) return;
   done = true;
-  const int big = 96 * 1024;
+  const int big = 160 * 1024;
   (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -647,6 +662,7 @@ static int hn_check_args(const HnMlpArgs* a) {
   if (a->ops == nullptr || a->wstream == nullptr) return -3;
   if (a->mode != HN_MODE_BF16 && a->mode != HN_MODE_F32) return -4;
   if (a->n_dsrc < 0 || a->n_dsrc > HN_DSRC_COMPS) return -5;
+  if (a->n_bias < 0 || a->n_feat < 0) return -5;
   return 0;
 }
 
@@ -654,7 +670,8 @@ extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
   int rc = hn_check_args(a);
   if (rc) return rc;
   hn_allow_big_lds();
-  const size_t lds = 2 * HN_CHUNK_UNITS * 1024;
+  const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + (size_t)((a->n_bias + 3) & ~3) * 4 + (size_t)a->n_feat * 8;
+  if (lds > 150 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
     hipLaunchKernelGGL(hn_mlp_fwd_kernel<true>, dim3(hn_grid_for(a->n_points, 256)), dim3(512), lds,
                        (hipStream_t)stream, *a);
@@ -670,12 +687,14 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
   int rc = hn_check_args(a);
   if (rc) return rc;
   hn_allow_big_lds();
+  const size_t flds = (size_t)((a->n_feat + 1) & ~1) * 8;
+  if (flds > 64 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
-    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + 8 * 32 * HN_DSRC_COMPS * 4;
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 8 * 32 * HN_DSRC_COMPS * 4;
     hipLaunchKernelGGL(hn_mlp_bwd_kernel<true>, dim3(hn_grid_for(a->n_points, 256)), dim3(512), lds,
                        (hipStream_t)stream, *a);
   } else {
-    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + 4 * 32 * HN_DSRC_COMPS * 4;
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 4 * 32 * HN_DSRC_COMPS * 4;
     hipLaunchKernelGGL(hn_mlp_bwd_kernel<false>, dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
                        (hipStream_t)stream, *a);
   }

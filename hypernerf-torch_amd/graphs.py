@@ -1,0 +1,31 @@
+"""HIP-graph capture of a whole render / training step.
+
+One step of the hot path is ~45 kernel launches with fixed shapes; launched eagerly from Python the host
+costs more than the GPU work.  `GraphedStep` runs the step a few times eagerly on a side stream (first-use
+uploads of tables, hipFuncSetAttribute, allocator warm-up), captures it once into a HIP graph through
+torch.cuda.graphs (the C-ABI kernels are launched on torch's current stream, so they are captured like any
+other work) and then replays it.  Inputs must live in fixed tensors that the caller updates in place.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+
+
+class GraphedStep:
+    def __init__(self, fn: Callable[[], object], warmup: int = 3):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out

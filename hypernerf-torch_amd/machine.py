@@ -522,6 +522,7 @@ class MlpRunner:
         a.mode, a.n_points, a.samples_per_ray, a.training = mode, n_points, samples_per_ray, int(training)
         a.n_ops, a.n_chunks, a.n_dsrc = n_ops, n_chunks, self.prog.n_dsrc if dsrc is not None else 0
         a.ops, a.wstream, a.bias, a.feat = ops.data_ptr(), wstream_ptr, d.bias.data_ptr(), d.feat.data_ptr()
+        a.n_bias, a.n_feat = max(32, self.prog.bias_len), max(1, len(self.prog.feat_table))
         a.stash = stash.data_ptr() if stash is not None else 0
         a.masks = masks.data_ptr() if masks is not None else 0
         a.dsrc = dsrc.data_ptr() if dsrc is not None else 0

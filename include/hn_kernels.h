@@ -118,6 +118,8 @@ typedef struct {
   int32_t n_ops;
   int32_t n_chunks; /* weight stream length in chunks of HN_CHUNK_UNITS KiB */
   int32_t n_dsrc;   /* backward: number of source-gradient components written per point (<=16) */
+  int32_t n_bias;   /* floats in `bias` (staged into LDS once per workgroup) */
+  int32_t n_feat;   /* entries in `feat` (staged into LDS once per workgroup) */
   int32_t pad0;
   const int32_t* ops;    /* device, n_ops * HN_OP_WORDS */
   const void* wstream;   /* device, packed weight units (hn_pack_units) */
