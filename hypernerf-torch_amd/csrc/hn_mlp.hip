@@ -536,45 +536,101 @@ struct DwFrag<false> {
   }
 };
 
+HN_DEV void hn_wait_vmcnt(int n) {
+  // s_waitcnt needs an immediate: wait until at most n of this wave's vector-memory ops are outstanding
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// One workgroup (4 waves, one per SIMD, 512 registers each) = one job = the whole dW tile grid
+// (<= 8x8 tiles in bf16, 4x4 in fp32) of one Linear-layer input segment over a range of point blocks.
+// Per block the dZ and X stash tiles are fetched ONCE by LDS-DMA into a 3-stage ring (2 stages in flight,
+// counted vmcnt, one barrier per block) and shared by the 4 waves, which own a gn x gk grid of
+// tn x tk tile rectangles.  HBM-bound: each stash byte is read exactly once.
 template <bool BF16>
 __global__ __launch_bounds__(256, 1) void hn_wgrad_kernel(const HnDwJob* jobs, int n_jobs, const char* stash,
                                                           float* grads) {
   using M = ModeT<BF16>;
-  constexpr size_t TB = M::TILE_UNITS * 1024;
+  constexpr int TU = M::TILE_UNITS;
+  constexpr size_t TB = TU * 1024;
+  constexpr int STAGES = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= n_jobs) return;
-  const HnDwJob jb = jobs[wid];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if ((int)blockIdx.x >= n_jobs) return;
+  const HnDwJob jb = jobs[blockIdx.x];
   const int c = lane & 31, h = lane >> 5;
-  f32x16 acc[2][4];
-  f32x16 accb[2];
+  const int gn = jb.pad & 255, gk = (jb.pad >> 8) & 255;
+  const int tn = (jb.n_nt + gn - 1) / gn, tk = (jb.n_kt + gk - 1) / gk;   // tiles per wave (<= 4 each)
+  const int wn = wave / gk, wk = wave % gk;
+  const int n0 = wn * tn, k0 = wk * tk;
+  const int my_n = min(tn, jb.n_nt - n0), my_k = min(tk, jb.n_kt - k0);   // may be <= 0
+  const int U = TU * (jb.n_nt + jb.n_kt);        // 1-KiB units per stage
+  const size_t stage_bytes = (size_t)U * 1024;
+  int my_loads = 0;
+  for (int q = wave; q < U; q += 4) ++my_loads;
+
+  f32x16 acc[4][4];
+  f32x16 accb[4];
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) accb[n][i] = 0.0f;
+    for (int e = 0; e < 16; ++e) accb[i][e] = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[n][k][i] = 0.0f;
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
   }
-  const bool do_bias = jb.b_off >= 0;
-  for (int b = jb.blk0; b < jb.blk1; ++b) {
-    DwFrag<BF16> za[2], xb[4];
-    const char* zt = stash + jb.z_off + ((size_t)b * jb.z_nt + jb.z_t0) * TB;
-    const char* xt = stash + jb.x_off + ((size_t)b * jb.x_nt + jb.x_t0) * TB;
+  const bool do_bias = jb.b_off >= 0 && wk == 0;
+
+  auto issue = [&](int b) {
+    char* dst = smem + (size_t)(b % STAGES) * stage_bytes;
+    for (int q = wave; q < U; q += 4) {
+      const int tile = q / TU, u = q % TU;
+      const char* src = tile < jb.n_nt
+                            ? stash + jb.z_off + ((size_t)b * jb.z_nt + jb.z_t0 + tile) * TB
+                            : stash + jb.x_off + ((size_t)b * jb.x_nt + jb.x_t0 + (tile - jb.n_nt)) * TB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + (size_t)q * 1024), 16, 0, 0);
+    }
+  };
+
+  const int nb = jb.blk1 - jb.blk0;
+  if (nb > 0) issue(jb.blk0);
+  if (nb > 1) issue(jb.blk0 + 1);
+  for (int ib = 0; ib < nb; ++ib) {
+    const int b = jb.blk0 + ib;
+    hn_wait_vmcnt(ib + 1 < nb ? my_loads : 0);   // stage of block b landed (the next one may still fly)
+    // raw barrier: __syncthreads() would make hipcc drain vmcnt(0) and with it the stage still in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // ... for every wave; everyone finished block b-1
+    __builtin_amdgcn_sched_barrier(0);
+    if (ib + 2 < nb) issue(b + 2);               // refill the stage block b-1 used
+    const char* st = smem + (size_t)(b % STAGES) * stage_bytes;
+    DwFrag<BF16> za[4], xb[4];
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
-      if (n < jb.n_nt) za[n].load(zt + n * TB, lane);
+    for (int i = 0; i < 4; ++i)
+      if (i < my_n) za[i].load(st + (size_t)(n0 + i) * TB, lane);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k < jb.n_kt) xb[k].load(xt + k * TB, lane);
+    for (int j = 0; j < 4; ++j)
+      if (j < my_k) xb[j].load(st + (size_t)(jb.n_nt + k0 + j) * TB, lane);
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      if (n < jb.n_nt) {
+    for (int i = 0; i < 4; ++i) {
+      if (i < my_n) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (k < jb.n_kt) DwFrag<BF16>::mma(acc[n][k], za[n], xb[k]);
-        if (do_bias) DwFrag<BF16>::mma_ones(accb[n], za[n]);
+        for (int j = 0; j < 4; ++j)
+          if (j < my_k) DwFrag<BF16>::mma(acc[i][j], za[i], xb[j]);
+        if (do_bias) DwFrag<BF16>::mma_ones(accb[i], za[i]);
       }
     }
   }
@@ -582,28 +638,28 @@ __global__ __launch_bounds__(256, 1) void hn_wgrad_kernel(const HnDwJob* jobs, i
   if (jb.w_off >= 0) {
     float* G = grads + jb.w_off;
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
-      if (n < jb.n_nt)
+    for (int i = 0; i < 4; ++i)
+      if (i < my_n)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (k < jb.n_kt)
+        for (int j = 0; j < 4; ++j)
+          if (j < my_k)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-              const int row = jb.r0 + 32 * n + hn_rho(q, h);
-              const int col = jb.c0 + 32 * k + c;
+              const int row = jb.r0 + 32 * (n0 + i) + hn_rho(q, h);
+              const int col = jb.c0 + 32 * (k0 + j) + c;
               if (row >= 0 && col >= 0 && row < jb.r_end && col < jb.c_end)
-                atomicAdd(G + (size_t)row * jb.ld + col, acc[n][k][q]);
+                atomicAdd(G + (size_t)row * jb.ld + col, acc[i][j][q]);
             }
   }
   if (do_bias && c == 0) {
     float* gb = grads + jb.b_off;
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
-      if (n < jb.n_nt)
+    for (int i = 0; i < 4; ++i)
+      if (i < my_n)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int row = jb.r0 + 32 * n + hn_rho(q, h);
-          if (row >= 0 && row < jb.r_end) atomicAdd(gb + row, accb[n][q]);
+          const int row = jb.r0 + 32 * (n0 + i) + hn_rho(q, h);
+          if (row >= 0 && row < jb.r_end) atomicAdd(gb + row, accb[i][q]);
         }
   }
 }
@@ -636,6 +692,8 @@ static void hn_allow_big_lds() {
   (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
 }
 
 extern "C" int hn_pack_units(int mode, const HnPackUnit* units, int n_units, const float* const* ptrs, void* wstream,
@@ -707,12 +765,14 @@ extern "C" int hn_mlp_wgrad(int mode, const HnDwJob* jobs, int n_jobs, const voi
   if (n_jobs < 0) return -1;
   if (n_jobs == 0) return 0;
   if (jobs == nullptr || stash == nullptr || grads == nullptr) return -3;
-  const int grid = (n_jobs + 3) / 4;
+  hn_allow_big_lds();
+  // 3 stages x (<= 16 tiles) : bf16 16 x 2 KiB, fp32 8 x 4 KiB  => 96 KiB
+  const size_t lds = 3 * 32 * 1024;
   if (mode == HN_MODE_BF16)
-    hipLaunchKernelGGL(hn_wgrad_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs,
+    hipLaunchKernelGGL(hn_wgrad_kernel<true>, dim3(n_jobs), dim3(256), lds, (hipStream_t)stream, jobs, n_jobs,
                        (const char*)stash, grads);
   else if (mode == HN_MODE_F32)
-    hipLaunchKernelGGL(hn_wgrad_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs,
+    hipLaunchKernelGGL(hn_wgrad_kernel<false>, dim3(n_jobs), dim3(256), lds, (hipStream_t)stream, jobs, n_jobs,
                        (const char*)stash, grads);
   else
     return -2;

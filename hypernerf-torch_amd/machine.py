@@ -424,12 +424,25 @@ class Program:
             tot += (p.numel() + 3) // 4 * 4
         return offs, tot
 
-    def wgrad_jobs(self, mode: int, n_points: int, target_chunks: int = 48) -> np.ndarray:
+    @staticmethod
+    def _wave_grid(n_nt: int, n_kt: int) -> Tuple[int, int]:
+        """(gn, gk), gn*gk == 4, every wave's rectangle <= 4x4 tiles, as little idle work as possible."""
+        best, cost = None, None
+        for gn, gk in ((2, 2), (1, 4), (4, 1)):
+            tn, tk = -(-n_nt // gn), -(-n_kt // gk)
+            if tn > 4 or tk > 4:
+                continue
+            c = gn * gk * tn * max(tk, 1)           # MFMA slots incl. idle waves
+            if cost is None or c < cost:
+                best, cost = (gn, gk), c
+        return best
+
+    def wgrad_jobs(self, mode: int, n_points: int, target_tile_blocks: int = 1536) -> np.ndarray:
+        """One job per (layer input segment, <=max x max tile rectangle, block chunk)."""
         offs, _, _ = self.layout(mode, n_points)
         goffs, _ = self.grad_offsets()
         nblk = (n_points + 31) // 32
-        per = max(8, (nblk + target_chunks - 1) // target_chunks)
-        chunks = [(b, min(nblk, b + per)) for b in range(0, nblk, per)]
+        tmax = 8 if mode == L.HN_MODE_BF16 else 4
         jobs = []
         for ly in self.layers:
             segs = []
@@ -443,15 +456,22 @@ class Program:
             first = True
             for (x_off, x_nt, c0, ncols) in segs:
                 k_tiles = (ncols + 31) // 32
-                for nt0 in range(0, n_tiles, 2):
-                    for kt0 in range(0, k_tiles, 4):
+                for nt0 in range(0, n_tiles, tmax):
+                    n_nt = min(tmax, n_tiles - nt0)
+                    for kt0 in range(0, k_tiles, tmax):
+                        n_kt = min(tmax, k_tiles - kt0)
+                        gn, gk = self._wave_grid(n_nt, n_kt)
                         with_bias = first and kt0 == 0 and ly.b_id >= 0
-                        for (b0, b1) in chunks:
-                            jobs.append((z_off, x_off, ly.nt, x_nt, nt0, kt0, min(2, n_tiles - nt0),
-                                         min(4, k_tiles - kt0), b0, b1, goffs[ly.w_id], ld, 32 * nt0,
-                                         c0 + 32 * kt0, ly.n_out, c0 + ncols,
-                                         goffs[ly.b_id] if with_bias else -1, 0))
+                        per = max(4, min(nblk, target_tile_blocks // (n_nt + n_kt)))
+                        nchunk = max(1, round(nblk / per))
+                        per = -(-nblk // nchunk)
+                        for b0 in range(0, nblk, per):
+                            jobs.append((z_off, x_off, ly.nt, x_nt, nt0, kt0, n_nt, n_kt, b0, min(nblk, b0 + per),
+                                         goffs[ly.w_id], ld, 32 * nt0, c0 + 32 * kt0, ly.n_out, c0 + ncols,
+                                         goffs[ly.b_id] if with_bias else -1, gn | gk << 8))
                 first = False
+        # heaviest jobs first: the tail of the launch is then made of short jobs
+        jobs.sort(key=lambda j: -(j[6] + j[7]) * (j[9] - j[8]))
         arr = np.zeros(len(jobs), dtype=L.DWJOB_DT)
         for i, j in enumerate(jobs):
             arr[i] = j

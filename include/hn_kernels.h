@@ -151,12 +151,14 @@ typedef struct {
   int32_t len;  /* padded length */
 } HnPackBias;
 
-/* weight-gradient job: one wavefront accumulates  dW[n-tiles x k-tiles] over a block range */
+/* weight-gradient job: one workgroup (4 waves) accumulates the dW tile grid n_nt x n_kt of one Linear input
+ * segment over a block range; pad = gn | gk<<8 is the wave grid (gn*gk == 4), each wave owns a
+ * ceil(n_nt/gn) x ceil(n_kt/gk) (<= 4x4) tile rectangle.  n_nt + n_kt <= 16 tiles (bf16) / 8 tiles (fp32). */
 typedef struct {
   uint64_t z_off, x_off;  /* stash byte offsets (block 0) of dZ and X slots */
   int32_t z_nt, x_nt;     /* tiles per block of the two slots */
   int32_t z_t0, x_t0;     /* first tile used */
-  int32_t n_nt, n_kt;     /* 1..2 n-tiles, 0..4 k-tiles */
+  int32_t n_nt, n_kt;     /* n-tiles of dZ, k-tiles of X handled by this job */
   int32_t blk0, blk1;     /* block range [blk0, blk1) */
   int32_t w_off;          /* offset (floats) of the gradient matrix (row-major (out,in)) in the flat
                              gradient buffer, -1 = none */

@@ -408,44 +408,56 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
 
 
 def run_wgrad(prog, mode, jobs, stash, n_grad):
+    """hn_wgrad_kernel: per job, 4 waves on a gn x gk grid, each owning a tn x tk tile rectangle."""
     grads = np.zeros(n_grad)
     tb = 2048 if mode.bf16 else 4096
     for jb in jobs:
-        acc = [[np.zeros((64, 16)) for _ in range(4)] for _ in range(2)]
-        accb = [np.zeros((64, 16)) for _ in range(2)]
-        for b in range(jb["blk0"], jb["blk1"]):
-            za = [stash.get_tile(int(jb["z_off"]) + (b * jb["z_nt"] + jb["z_t0"] + n) * tb) for n in range(jb["n_nt"])]
-            xb = [stash.get_tile(int(jb["x_off"]) + (b * jb["x_nt"] + jb["x_t0"] + k) * tb) for k in range(jb["n_kt"])]
-            for n in range(jb["n_nt"]):
-                for k in range(jb["n_kt"]):
-                    if mode.bf16:
-                        for v in range(2):
-                            acc[n][k] = mfma_bf16(za[n][v], xb[k][v], acc[n][k])
-                    else:
-                        for g in range(4):
-                            for e in range(4):
-                                acc[n][k] = mfma_f32(za[n][g][:, e], xb[k][g][:, e], acc[n][k])
-                if jb["b_off"] >= 0:
-                    if mode.bf16:
-                        for v in range(2):
-                            accb[n] = mfma_bf16(za[n][v], np.ones((64, 8)), accb[n])
-                    else:
-                        for g in range(4):
-                            for e in range(4):
-                                accb[n] = mfma_f32(za[n][g][:, e], np.ones(64), accb[n])
-        for n in range(jb["n_nt"]):
-            for k in range(jb["n_kt"]):
-                for l in range(64):
-                    c, h = l & 31, l >> 5
-                    for q in range(16):
-                        row = jb["r0"] + 32 * n + rho(q, h)
-                        col = jb["c0"] + 32 * k + c
-                        if 0 <= row < jb["r_end"] and 0 <= col < jb["c_end"] and jb["w_off"] >= 0:
-                            grads[jb["w_off"] + row * jb["ld"] + col] += acc[n][k][l, q]
-            if jb["b_off"] >= 0:
-                for l in (0, 32):
-                    for q in range(16):
-                        row = jb["r0"] + 32 * n + rho(q, l >> 5)
-                        if 0 <= row < jb["r_end"]:
-                            grads[jb["b_off"] + row] += accb[n][l, q]
+        gn, gk = int(jb["pad"]) & 255, (int(jb["pad"]) >> 8) & 255
+        assert gn * gk == 4
+        tn, tk = -(-jb["n_nt"] // gn), -(-jb["n_kt"] // gk)
+        assert tn <= 4 and tk <= 4 and jb["n_nt"] + jb["n_kt"] <= (16 if mode.bf16 else 8)
+        for wave in range(4):
+            wn, wk = wave // gk, wave % gk
+            n0, k0 = wn * tn, wk * tk
+            my_n, my_k = min(tn, jb["n_nt"] - n0), min(tk, jb["n_kt"] - k0)
+            acc = [[np.zeros((64, 16)) for _ in range(4)] for _ in range(4)]
+            accb = [np.zeros((64, 16)) for _ in range(4)]
+            do_bias = jb["b_off"] >= 0 and wk == 0
+            for b in range(jb["blk0"], jb["blk1"]):
+                za = [stash.get_tile(int(jb["z_off"]) + (b * jb["z_nt"] + jb["z_t0"] + n0 + i) * tb)
+                      for i in range(max(my_n, 0))]
+                xb = [stash.get_tile(int(jb["x_off"]) + (b * jb["x_nt"] + jb["x_t0"] + k0 + j) * tb)
+                      for j in range(max(my_k, 0))]
+                for i in range(max(my_n, 0)):
+                    for j in range(max(my_k, 0)):
+                        if mode.bf16:
+                            for v in range(2):
+                                acc[i][j] = mfma_bf16(za[i][v], xb[j][v], acc[i][j])
+                        else:
+                            for g in range(4):
+                                for e in range(4):
+                                    acc[i][j] = mfma_f32(za[i][g][:, e], xb[j][g][:, e], acc[i][j])
+                    if do_bias:
+                        if mode.bf16:
+                            for v in range(2):
+                                accb[i] = mfma_bf16(za[i][v], np.ones((64, 8)), accb[i])
+                        else:
+                            for g in range(4):
+                                for e in range(4):
+                                    accb[i] = mfma_f32(za[i][g][:, e], np.ones(64), accb[i])
+            for i in range(max(my_n, 0)):
+                for j in range(max(my_k, 0)):
+                    for l in range(64):
+                        c, h = l & 31, l >> 5
+                        for q in range(16):
+                            row = jb["r0"] + 32 * (n0 + i) + rho(q, h)
+                            col = jb["c0"] + 32 * (k0 + j) + c
+                            if 0 <= row < jb["r_end"] and 0 <= col < jb["c_end"] and jb["w_off"] >= 0:
+                                grads[jb["w_off"] + row * jb["ld"] + col] += acc[i][j][l, q]
+                if do_bias:
+                    for l in (0, 32):
+                        for q in range(16):
+                            row = jb["r0"] + 32 * (n0 + i) + rho(q, l >> 5)
+                            if 0 <= row < jb["r_end"]:
+                                grads[jb["b_off"] + row] += accb[i][l, q]
     return grads

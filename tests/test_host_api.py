@@ -1,0 +1,136 @@
+"""CPU tests of the drop-in surface: the C-ABI library loads and exports every symbol include/hn_kernels.h
+declares, struct mirrors have the C sizes, module constructors / state_dict keys / initialiser RNG order match
+the reference's golden key lists, and ops refuse CPU tensors (no CPU fallback)."""
+import ctypes
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import hypernerf_torch_amd as HN
+from hypernerf_torch_amd import _lib as L
+from hypernerf_torch_amd.hypernerf import model_utils, models, modules, warping
+from hypernerf_torch_amd.models import nerf as legacy_nerf
+from hypernerf_torch_amd.models import rendering as legacy_rendering
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMB = {"warp": list(range(100)), "camera": [0], "appearance": list(range(100)), "time": list(range(100))}
+
+
+def test_library_exports_every_declared_symbol():
+    HN.build()
+    lib = L.load()
+    header = open(os.path.join(ROOT, "include", "hn_kernels.h")).read()
+    declared = set(re.findall(r"^int (hn_\w+)\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.hn_version() == 100
+
+
+def test_abi_struct_sizes_match_c():
+    lib = L.load()
+    out = (ctypes.c_int32 * 8)()
+    assert lib.hn_abi_sizes(out, 8) == 8
+    c = list(out)
+    assert c[0] == ctypes.sizeof(L.HnMlpArgs)
+    assert c[1] == L.PACK_UNIT_DT.itemsize and c[2] == L.PACK_BIAS_DT.itemsize and c[3] == L.DWJOB_DT.itemsize
+    assert c[4] == ctypes.sizeof(L.HnCompositeArgs)
+    assert c[5] == L.FEAT_DT.itemsize and c[6] == ctypes.sizeof(L.HnSlot) and c[7] == ctypes.sizeof(L.HnSrc)
+
+
+def test_argument_errors_are_reported_not_crashes():
+    lib = L.load()
+    a = L.HnMlpArgs()
+    assert lib.hn_mlp_forward(ctypes.byref(a), None) < 0          # empty args: negative status, no launch
+    assert lib.hn_mlp_backward(None, None) < 0
+    c = L.HnCompositeArgs()
+    assert lib.hn_composite_forward(ctypes.byref(c), None) < 0
+    assert lib.hn_sample_pdf(None, 0, None, 0, None, 0, None, None, None, 0, 0, 0, None, None, None, None, None) < 0
+
+
+CASES = {
+    "bendy": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=False, use_alpha_cond=False),
+    "bendy_cond": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True),
+    "bendy_rgbcond": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True, use_rgb_cond=True),
+    "nowarp": dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=False, use_alpha_cond=False),
+    "nowarp_cond": dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=True, use_alpha_cond=True),
+    "warp_noslice": dict(use_warp=True, hyper_slice_method=None, use_nerf_embed=False, use_alpha_cond=False,
+                         hyper_slice_out_dim=0),
+    "axis": dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_nerf_embed=False,
+                 use_alpha_cond=False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_state_dict_keys_and_shapes_match_reference(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, f"g11_model_{case}_8_8.npz"))
+    m = models.NerfModel(EMB, n_samples_coarse=8, n_samples_fine=8, view_fourier_dim=6, **CASES[case])
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == g["keys"].tolist()
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == g["shapes"].tolist()
+
+
+def test_legacy_state_dict_keys(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g12_legacy_c_only.npz"))
+    sd = legacy_nerf.NeRF().state_dict()
+    assert sorted(sd.keys()) == g["keys"].tolist()
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == g["shapes"].tolist()
+    assert legacy_nerf.Embedding(3, 10).out_channels == 63 and legacy_nerf.Embedding(3, 4).out_channels == 27
+
+
+def test_reference_constructor_errors():
+    with pytest.raises(ValueError):
+        models.NerfModel(EMB, use_nerf_embed=True, use_alpha_cond=False, use_rgb_cond=False)
+    with pytest.raises(UnboundLocalError):
+        models.NerfModel(EMB, n_samples_fine=0)                 # hypernerf/models.py:292-309
+    with pytest.raises(UnboundLocalError):
+        models.NerfModel(EMB, share_GLO=False)                  # hypernerf/models.py:167-186
+    tf = warping.TranslationField(in_ch=3)
+    with pytest.raises(Exception):
+        tf(torch.zeros(2, 3), torch.zeros(2, 8), None, return_jacobian=True)
+
+
+def test_no_cpu_fallback():
+    m = models.NerfModel(EMB, n_samples_coarse=8, n_samples_fine=8, hyper_slice_method="bendy_sheet")
+    rays = {"origins": torch.zeros(4, 3), "directions": torch.ones(4, 3), "viewdirs": None,
+            "metadata": {k: torch.zeros(4, dtype=torch.long) for k in ("warp", "camera", "appearance", "time")}}
+    with pytest.raises(L.HnError):
+        m(rays, {})
+    with pytest.raises(L.HnError):
+        legacy_rendering.render_rays([legacy_nerf.NeRF()], [legacy_nerf.Embedding(3, 10), legacy_nerf.Embedding(3, 4)],
+                                     torch.zeros(4, 8))
+    with pytest.raises(L.HnError):
+        modules.MLP(8, 3, depth=2, width=32)(torch.zeros(5, 8))
+
+
+def test_ray_dict_plumbing():
+    rays = torch.arange(5 * 9, dtype=torch.float32).view(5, 9)
+    rd = model_utils.prepare_ray_dict(rays)
+    assert rd["viewdirs"] is None and torch.equal(rd["origins"], rays[:, :3]) and torch.equal(rd["directions"], rays[:, 3:6])
+    assert rd["metadata"]["time"].dtype == torch.long and torch.equal(rd["metadata"]["warp"], rays[:, 8].long())
+    part = model_utils.extract_rays_batch(rd, 1, 3)
+    assert part["origins"].shape == (2, 3) and part["metadata"]["time"].shape == (2,)
+    assert model_utils.get_posenc_ch_orig(3, 10) == 63 and model_utils.get_posenc_ch(3, 0, 8, False) == 48
+    both = model_utils.concat_ray_batch([{"a": torch.zeros(2, 3)}, {"a": torch.ones(1, 3)}])
+    assert both["a"].shape == (3, 3)
+
+
+def test_init_matches_reference_rng_order():
+    """Same torch seed -> same parameter values as a module built the reference's way (nn.Linear creation order,
+    then xavier on hidden layers, then the output initialiser): hypernerf/modules.py:99-109."""
+    torch.manual_seed(123)
+    m = modules.MLP(in_ch=7, out_ch=3, depth=3, width=16, skips=[1])
+    torch.manual_seed(123)
+    lins = [torch.nn.Linear(7, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16 + 7, 16)]
+    logit = torch.nn.Linear(16, 3)
+    for l in lins:
+        torch.nn.init.xavier_uniform_(l.weight)
+    torch.nn.init.xavier_uniform_(logit.weight)
+    for i, l in enumerate(lins):
+        assert torch.equal(m.linears[i].weight, l.weight) and torch.equal(m.linears[i].bias, l.bias)
+    assert torch.equal(m.logit_layer.weight, logit.weight)
