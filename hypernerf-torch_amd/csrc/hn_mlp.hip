@@ -552,13 +552,13 @@ HN_DEV void hn_wait_vmcnt(int n) {
   }
 }
 
-// One workgroup (4 waves, one per SIMD, 512 registers each) = one job = the whole dW tile grid
-// (<= 8x8 tiles in bf16, 4x4 in fp32) of one Linear-layer input segment over a range of point blocks.
-// Per block the dZ and X stash tiles are fetched ONCE by LDS-DMA into a 3-stage ring (2 stages in flight,
-// counted vmcnt, one barrier per block) and shared by the 4 waves, which own a gn x gk grid of
-// tn x tk tile rectangles.  HBM-bound: each stash byte is read exactly once.
+// One workgroup (8 waves, two per SIMD) = one job = the whole dW tile grid (<= 8x8 tiles in bf16, 4x4 in
+// fp32) of one Linear-layer input segment over a range of point blocks.  The dZ and X stash tiles are fetched
+// ONCE by LDS-DMA into a 3-stage ring (a stage = `bps` blocks, <= 32 KiB; 2 stages in flight; counted vmcnt;
+// one raw barrier per stage) and shared by the 8 waves, which own a gn x gk grid of tn x tk (<= 4x2) tile
+// rectangles.  HBM-bound by construction: every stash byte is read exactly once.
 template <bool BF16>
-__global__ __launch_bounds__(256, 1) void hn_wgrad_kernel(const HnDwJob* jobs, int n_jobs, const char* stash,
+__global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwJob* jobs, int n_jobs, const char* stash,
                                                           float* grads) {
   using M = ModeT<BF16>;
   constexpr int TU = M::TILE_UNITS;
@@ -570,67 +570,78 @@ __global__ __launch_bounds__(256, 1) void hn_wgrad_kernel(const HnDwJob* jobs, i
   if ((int)blockIdx.x >= n_jobs) return;
   const HnDwJob jb = jobs[blockIdx.x];
   const int c = lane & 31, h = lane >> 5;
-  const int gn = jb.pad & 255, gk = (jb.pad >> 8) & 255;
-  const int tn = (jb.n_nt + gn - 1) / gn, tk = (jb.n_kt + gk - 1) / gk;   // tiles per wave (<= 4 each)
+  const int gn = jb.pad & 255, gk = (jb.pad >> 8) & 255, bps = (jb.pad >> 16) & 255;
+  const int tn = (jb.n_nt + gn - 1) / gn, tk = (jb.n_kt + gk - 1) / gk;   // tiles per wave (<= 4, <= 2)
   const int wn = wave / gk, wk = wave % gk;
   const int n0 = wn * tn, k0 = wk * tk;
-  const int my_n = min(tn, jb.n_nt - n0), my_k = min(tk, jb.n_kt - k0);   // may be <= 0
-  const int U = TU * (jb.n_nt + jb.n_kt);        // 1-KiB units per stage
-  const size_t stage_bytes = (size_t)U * 1024;
-  int my_loads = 0;
-  for (int q = wave; q < U; q += 4) ++my_loads;
+  const int my_n = wn < gn ? min(tn, jb.n_nt - n0) : 0, my_k = min(tk, jb.n_kt - k0);   // may be <= 0
+  const int tiles_blk = jb.n_nt + jb.n_kt;
+  const int UB = TU * tiles_blk;                 // 1-KiB units per block
+  const size_t stage_bytes = (size_t)bps * UB * 1024;
+  const int nb = jb.blk1 - jb.blk0;
+  const int nstage = (nb + bps - 1) / bps;
 
-  f32x16 acc[4][4];
+  f32x16 acc[4][2];
   f32x16 accb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) accb[i][e] = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
   }
-  const bool do_bias = jb.b_off >= 0 && wk == 0;
+  const bool do_bias = jb.b_off >= 0 && wk == 0 && my_n > 0;
 
-  auto issue = [&](int b) {
-    char* dst = smem + (size_t)(b % STAGES) * stage_bytes;
-    for (int q = wave; q < U; q += 4) {
-      const int tile = q / TU, u = q % TU;
-      const char* src = tile < jb.n_nt
-                            ? stash + jb.z_off + ((size_t)b * jb.z_nt + jb.z_t0 + tile) * TB
-                            : stash + jb.x_off + ((size_t)b * jb.x_nt + jb.x_t0 + (tile - jb.n_nt)) * TB;
+  // returns the number of LDS-DMA instructions this wave issued for stage s
+  auto issue = [&](int s) -> int {
+    char* dst = smem + (size_t)(s % STAGES) * stage_bytes;
+    const int b0 = jb.blk0 + s * bps;
+    const int nblk_s = min(bps, jb.blk1 - b0);
+    int n = 0;
+    for (int q = wave; q < nblk_s * UB; q += 8) {
+      const int bi = q / UB, r = q % UB;
+      const int tile = r / TU, u = r % TU;
+      const size_t b = (size_t)(b0 + bi);
+      const char* src = tile < jb.n_nt ? stash + jb.z_off + (b * jb.z_nt + jb.z_t0 + tile) * TB
+                                       : stash + jb.x_off + (b * jb.x_nt + jb.x_t0 + (tile - jb.n_nt)) * TB;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void*)(dst + (size_t)q * 1024), 16, 0, 0);
+      ++n;
     }
+    return n;
   };
 
-  const int nb = jb.blk1 - jb.blk0;
-  if (nb > 0) issue(jb.blk0);
-  if (nb > 1) issue(jb.blk0 + 1);
-  for (int ib = 0; ib < nb; ++ib) {
-    const int b = jb.blk0 + ib;
-    hn_wait_vmcnt(ib + 1 < nb ? my_loads : 0);   // stage of block b landed (the next one may still fly)
+  int in_flight_next = 0;
+  if (nstage > 0) issue(0);
+  if (nstage > 1) in_flight_next = issue(1);
+  for (int s = 0; s < nstage; ++s) {
+    hn_wait_vmcnt(s + 1 < nstage ? in_flight_next : 0);   // stage s landed (stage s+1 may still fly)
     // raw barrier: __syncthreads() would make hipcc drain vmcnt(0) and with it the stage still in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                // ... for every wave; everyone finished block b-1
+    __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone finished stage s-1
     __builtin_amdgcn_sched_barrier(0);
-    if (ib + 2 < nb) issue(b + 2);               // refill the stage block b-1 used
-    const char* st = smem + (size_t)(b % STAGES) * stage_bytes;
-    DwFrag<BF16> za[4], xb[4];
+    if (s + 2 < nstage) in_flight_next = issue(s + 2);    // refill the buffer stage s-1 used
+    const char* st = smem + (size_t)(s % STAGES) * stage_bytes;
+    const int nblk_s = min(bps, nb - s * bps);
+    for (int bi = 0; bi < nblk_s; ++bi) {
+      const char* sb = st + (size_t)bi * UB * 1024;
+      DwFrag<BF16> za[4], xb[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < my_n) za[i].load(st + (size_t)(n0 + i) * TB, lane);
+      for (int i = 0; i < 4; ++i)
+        if (i < my_n) za[i].load(sb + (size_t)(n0 + i) * TB, lane);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < my_k) xb[j].load(st + (size_t)(jb.n_nt + k0 + j) * TB, lane);
+      for (int j = 0; j < 2; ++j)
+        if (j < my_k) xb[j].load(sb + (size_t)(jb.n_nt + k0 + j) * TB, lane);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i < my_n) {
+      for (int i = 0; i < 4; ++i) {
+        if (i < my_n) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < my_k) DwFrag<BF16>::mma(acc[i][j], za[i], xb[j]);
-        if (do_bias) DwFrag<BF16>::mma_ones(accb[i], za[i]);
+          for (int j = 0; j < 2; ++j)
+            if (j < my_k) DwFrag<BF16>::mma(acc[i][j], za[i], xb[j]);
+          if (do_bias) DwFrag<BF16>::mma_ones(accb[i], za[i]);
+        }
       }
     }
   }
@@ -641,7 +652,7 @@ __global__ __launch_bounds__(256, 1) void hn_wgrad_kernel(const HnDwJob* jobs, i
     for (int i = 0; i < 4; ++i)
       if (i < my_n)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
           if (j < my_k)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -769,10 +780,10 @@ extern "C" int hn_mlp_wgrad(int mode, const HnDwJob* jobs, int n_jobs, const voi
   // 3 stages x (<= 16 tiles) : bf16 16 x 2 KiB, fp32 8 x 4 KiB  => 96 KiB
   const size_t lds = 3 * 32 * 1024;
   if (mode == HN_MODE_BF16)
-    hipLaunchKernelGGL(hn_wgrad_kernel<true>, dim3(n_jobs), dim3(256), lds, (hipStream_t)stream, jobs, n_jobs,
+    hipLaunchKernelGGL(hn_wgrad_kernel<true>, dim3(n_jobs), dim3(512), lds, (hipStream_t)stream, jobs, n_jobs,
                        (const char*)stash, grads);
   else if (mode == HN_MODE_F32)
-    hipLaunchKernelGGL(hn_wgrad_kernel<false>, dim3(n_jobs), dim3(256), lds, (hipStream_t)stream, jobs, n_jobs,
+    hipLaunchKernelGGL(hn_wgrad_kernel<false>, dim3(n_jobs), dim3(512), lds, (hipStream_t)stream, jobs, n_jobs,
                        (const char*)stash, grads);
   else
     return -2;

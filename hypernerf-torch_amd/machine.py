@@ -426,24 +426,20 @@ class Program:
 
     @staticmethod
     def _wave_grid(n_nt: int, n_kt: int) -> Tuple[int, int]:
-        """(gn, gk), gn*gk == 4, every wave's rectangle <= 4x4 tiles, as little idle work as possible."""
-        best, cost = None, None
-        for gn, gk in ((2, 2), (1, 4), (4, 1)):
-            tn, tk = -(-n_nt // gn), -(-n_kt // gk)
-            if tn > 4 or tk > 4:
-                continue
-            c = gn * gk * tn * max(tk, 1)           # MFMA slots incl. idle waves
-            if cost is None or c < cost:
-                best, cost = (gn, gk), c
-        return best
+        """(gn, gk), gn*gk <= 8 waves, every wave's rectangle <= 4x2 tiles."""
+        if n_nt <= 4:
+            return 1, min(8, max(1, n_kt)) if n_kt <= 8 else 8
+        return 2, 4
 
-    def wgrad_jobs(self, mode: int, n_points: int, target_tile_blocks: int = 1536) -> np.ndarray:
-        """One job per (layer input segment, <=max x max tile rectangle, block chunk)."""
+    def wgrad_jobs(self, mode: int, n_points: int, target_jobs: int = 256) -> np.ndarray:
+        """One job per (layer input segment, tile rectangle, block chunk).  The chunks are sized so that the
+        launch is about `target_jobs` workgroups of equal stash bytes (one per CU, a single round)."""
         offs, _, _ = self.layout(mode, n_points)
         goffs, _ = self.grad_offsets()
         nblk = (n_points + 31) // 32
         tmax = 8 if mode == L.HN_MODE_BF16 else 4
-        jobs = []
+        stage_tiles = 16 if mode == L.HN_MODE_BF16 else 8         # 32 KiB per LDS stage
+        rects = []
         for ly in self.layers:
             segs = []
             if ly.main is not None:
@@ -452,7 +448,6 @@ class Program:
                 segs.append((offs[ly.aux.slot][0], 2 * ly.aux.groups, ly.aux_c0, ly.aux.n))
             z_off = offs[ly.dz_slot][0]
             n_tiles = (ly.n_out + 31) // 32
-            ld = ly.weight.shape[1]
             first = True
             for (x_off, x_nt, c0, ncols) in segs:
                 k_tiles = (ncols + 31) // 32
@@ -460,16 +455,21 @@ class Program:
                     n_nt = min(tmax, n_tiles - nt0)
                     for kt0 in range(0, k_tiles, tmax):
                         n_kt = min(tmax, k_tiles - kt0)
-                        gn, gk = self._wave_grid(n_nt, n_kt)
                         with_bias = first and kt0 == 0 and ly.b_id >= 0
-                        per = max(4, min(nblk, target_tile_blocks // (n_nt + n_kt)))
-                        nchunk = max(1, round(nblk / per))
-                        per = -(-nblk // nchunk)
-                        for b0 in range(0, nblk, per):
-                            jobs.append((z_off, x_off, ly.nt, x_nt, nt0, kt0, n_nt, n_kt, b0, min(nblk, b0 + per),
-                                         goffs[ly.w_id], ld, 32 * nt0, c0 + 32 * kt0, ly.n_out, c0 + ncols,
-                                         goffs[ly.b_id] if with_bias else -1, gn | gk << 8))
+                        rects.append((ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias))
                 first = False
+        total_tiles = sum(r[8] + r[9] for r in rects)
+        jobs = []
+        for (ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias) in rects:
+            gn, gk = self._wave_grid(n_nt, n_kt)
+            bps = max(1, stage_tiles // (n_nt + n_kt))
+            share = max(1, round(target_jobs * (n_nt + n_kt) / total_tiles))
+            per = max(bps, -(-nblk // share))
+            per = -(-per // bps) * bps                       # whole stages
+            for b0 in range(0, nblk, per):
+                jobs.append((z_off, x_off, ly.nt, x_nt, nt0, kt0, n_nt, n_kt, b0, min(nblk, b0 + per),
+                             goffs[ly.w_id], ly.weight.shape[1], 32 * nt0, c0 + 32 * kt0, ly.n_out, c0 + ncols,
+                             goffs[ly.b_id] if with_bias else -1, gn | gk << 8 | bps << 16))
         # heaviest jobs first: the tail of the launch is then made of short jobs
         jobs.sort(key=lambda j: -(j[6] + j[7]) * (j[9] - j[8]))
         arr = np.zeros(len(jobs), dtype=L.DWJOB_DT)

@@ -151,9 +151,10 @@ typedef struct {
   int32_t len;  /* padded length */
 } HnPackBias;
 
-/* weight-gradient job: one workgroup (4 waves) accumulates the dW tile grid n_nt x n_kt of one Linear input
- * segment over a block range; pad = gn | gk<<8 is the wave grid (gn*gk == 4), each wave owns a
- * ceil(n_nt/gn) x ceil(n_kt/gk) (<= 4x4) tile rectangle.  n_nt + n_kt <= 16 tiles (bf16) / 8 tiles (fp32). */
+/* weight-gradient job: one workgroup (8 waves) accumulates the dW tile grid n_nt x n_kt of one Linear input
+ * segment over a block range; pad = gn | gk<<8 | bps<<16: gn x gk (<= 8 waves) is the wave grid, each wave
+ * owns a ceil(n_nt/gn) x ceil(n_kt/gk) (<= 4x2) tile rectangle; bps = point blocks per LDS stage
+ * (bps * (n_nt+n_kt) tiles <= 32 KiB).  n_nt, n_kt <= 8 tiles (bf16) / 4 tiles (fp32). */
 typedef struct {
   uint64_t z_off, x_off;  /* stash byte offsets (block 0) of dZ and X slots */
   int32_t z_nt, x_nt;     /* tiles per block of the two slots */

@@ -412,17 +412,20 @@ def run_wgrad(prog, mode, jobs, stash, n_grad):
     grads = np.zeros(n_grad)
     tb = 2048 if mode.bf16 else 4096
     for jb in jobs:
-        gn, gk = int(jb["pad"]) & 255, (int(jb["pad"]) >> 8) & 255
-        assert gn * gk == 4
+        gn, gk, bps = int(jb["pad"]) & 255, (int(jb["pad"]) >> 8) & 255, (int(jb["pad"]) >> 16) & 255
+        assert gn * gk <= 8 and bps >= 1
         tn, tk = -(-jb["n_nt"] // gn), -(-jb["n_kt"] // gk)
-        assert tn <= 4 and tk <= 4 and jb["n_nt"] + jb["n_kt"] <= (16 if mode.bf16 else 8)
-        for wave in range(4):
+        assert tn <= 4 and tk <= 2
+        assert bps * (jb["n_nt"] + jb["n_kt"]) * (2 if mode.bf16 else 4) <= 32      # KiB per LDS stage
+        assert (jb["blk0"] % bps) == 0
+        for wave in range(8):
             wn, wk = wave // gk, wave % gk
             n0, k0 = wn * tn, wk * tk
-            my_n, my_k = min(tn, jb["n_nt"] - n0), min(tk, jb["n_kt"] - k0)
+            my_n = min(tn, jb["n_nt"] - n0) if wn < gn else 0
+            my_k = min(tk, jb["n_kt"] - k0)
             acc = [[np.zeros((64, 16)) for _ in range(4)] for _ in range(4)]
             accb = [np.zeros((64, 16)) for _ in range(4)]
-            do_bias = jb["b_off"] >= 0 and wk == 0
+            do_bias = jb["b_off"] >= 0 and wk == 0 and my_n > 0
             for b in range(jb["blk0"], jb["blk1"]):
                 za = [stash.get_tile(int(jb["z_off"]) + (b * jb["z_nt"] + jb["z_t0"] + n0 + i) * tb)
                       for i in range(max(my_n, 0))]
