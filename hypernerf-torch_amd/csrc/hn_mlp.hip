@@ -548,6 +548,11 @@ HN_DEV void hn_wait_vmcnt(int n) {
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -563,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwJob* jobs, i
   using M = ModeT<BF16>;
   constexpr int TU = M::TILE_UNITS;
   constexpr size_t TB = TU * 1024;
-  constexpr int STAGES = 3;
+  constexpr int STAGES = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -594,12 +599,15 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwJob* jobs, i
   }
   const bool do_bias = jb.b_off >= 0 && wk == 0 && my_n > 0;
 
-  // returns the number of LDS-DMA instructions this wave issued for stage s
-  auto issue = [&](int s) -> int {
+  auto issue_count = [&](int nblk_s) -> int {
+    int n = 0;
+    for (int q = wave; q < nblk_s * UB; q += 8) ++n;
+    return n;
+  };
+  auto issue = [&](int s) {
     char* dst = smem + (size_t)(s % STAGES) * stage_bytes;
     const int b0 = jb.blk0 + s * bps;
     const int nblk_s = min(bps, jb.blk1 - b0);
-    int n = 0;
     for (int q = wave; q < nblk_s * UB; q += 8) {
       const int bi = q / UB, r = q % UB;
       const int tile = r / TU, u = r % TU;
@@ -608,21 +616,21 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwJob* jobs, i
                                        : stash + jb.x_off + (b * jb.x_nt + jb.x_t0 + (tile - jb.n_nt)) * TB;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void*)(dst + (size_t)q * 1024), 16, 0, 0);
-      ++n;
     }
-    return n;
   };
 
-  int in_flight_next = 0;
-  if (nstage > 0) issue(0);
-  if (nstage > 1) in_flight_next = issue(1);
+  // STAGES-1 stages in flight.  Every wave issues the same number of LDS-DMA instructions for every FULL stage,
+  // so "all but the youngest k stages landed" is vmcnt(k * per_stage) (the last, partial stage only lowers it).
+  const int per_stage = issue_count(bps);
+  for (int s0 = 0; s0 < STAGES - 1 && s0 < nstage; ++s0) issue(s0);
   for (int s = 0; s < nstage; ++s) {
-    hn_wait_vmcnt(s + 1 < nstage ? in_flight_next : 0);   // stage s landed (stage s+1 may still fly)
-    // raw barrier: __syncthreads() would make hipcc drain vmcnt(0) and with it the stage still in flight
+    const int younger = min(STAGES - 2, nstage - 1 - s);     // stages issued after stage s that may stay in flight
+    hn_wait_vmcnt(younger * per_stage);
+    // raw barrier: __syncthreads() would make hipcc drain vmcnt(0) and with it the stages still in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone finished stage s-1
     __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < nstage) in_flight_next = issue(s + 2);    // refill the buffer stage s-1 used
+    if (s + STAGES - 1 < nstage) issue(s + STAGES - 1);   // refill the buffer stage s-1 used
     const char* st = smem + (size_t)(s % STAGES) * stage_bytes;
     const int nblk_s = min(bps, nb - s * bps);
     for (int bi = 0; bi < nblk_s; ++bi) {
@@ -778,7 +786,7 @@ extern "C" int hn_mlp_wgrad(int mode, const HnDwJob* jobs, int n_jobs, const voi
   if (jobs == nullptr || stash == nullptr || grads == nullptr) return -3;
   hn_allow_big_lds();
   // 3 stages x (<= 16 tiles) : bf16 16 x 2 KiB, fp32 8 x 4 KiB  => 96 KiB
-  const size_t lds = 3 * 32 * 1024;
+  const size_t lds = 4 * 32 * 1024;
   if (mode == HN_MODE_BF16)
     hipLaunchKernelGGL(hn_wgrad_kernel<true>, dim3(n_jobs), dim3(512), lds, (hipStream_t)stream, jobs, n_jobs,
                        (const char*)stash, grads);
