@@ -51,6 +51,7 @@ class HnMlpArgs(C.Structure):
         ("ops", C.c_void_p), ("wstream", C.c_void_p), ("bias", C.c_void_p), ("feat", C.c_void_p),
         ("stash", C.c_void_p), ("masks", C.c_void_p), ("dsrc", C.c_void_p),
         ("src", HnSrc * HN_MAX_SRC), ("dst", HnDst * HN_MAX_DST), ("slots", HnSlot * HN_MAX_SLOTS),
+        ("prof", C.c_void_p),
     ]
 
 
@@ -109,6 +110,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
            "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    for macro in ("HN_BF16_WAVES", "HN_PROF"):          # build-time tuning knobs (A/B experiments)
+        if os.environ.get(macro):
+            cmd.insert(1, f"-D{macro}={os.environ[macro]}")
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise HnError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
@@ -139,6 +143,7 @@ def load():
 # through `launch()` is bracketed by HIP events on the launch stream; `collect_kernel_times()` resolves them.
 KERNEL_TIMES = None
 _PENDING = []
+PROF_BUFFER = None   # diagnostic: uint64[8] device tensor receiving in-kernel cycle sums of the MLP machine
 
 
 def launch(name: str, *args, tag: str = ""):

@@ -35,12 +35,16 @@ HN_DEV f32x16 hn_mfma_f32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+#ifndef HN_BF16_WAVES
+#define HN_BF16_WAVES 8
+#endif
+
 template <bool BF16>
 struct ModeT;
 
 template <>
 struct ModeT<true> {
-  static constexpr int WAVES = 8;      // 512 threads, 2 waves per SIMD (<= 256 registers)
+  static constexpr int WAVES = HN_BF16_WAVES;   // 8: 512 threads, 2 waves/SIMD (256 regs) ; 4: 1 wave/SIMD (512 regs)
   static constexpr int STEPS32 = 2;    // operand fragments per 32 features
   static constexpr int UNITS32 = 2;    // 1-KiB weight units per (32 out x 32 in) block
   static constexpr int TILE_UNITS = 2; // 1-KiB units per stashed 32x32 tile

@@ -45,50 +45,18 @@ struct WStream {
 };
 
 // ------------------------------------------------------------------------------------------------
-// per-launch descriptors, copied once into LDS: the by-value kernel argument is only ever indexed with
-// compile-time constants (a dynamically indexed kernarg struct gets spilled to scratch memory by hipcc)
-// ------------------------------------------------------------------------------------------------
-struct HnShared {
-  HnSlot slots[HN_MAX_SLOTS];
-  HnSrc src[HN_MAX_SRC];
-  HnDst dst[HN_MAX_DST];
-  char* stash;
-  uint32_t* masks;
-  int training, pad;
-};
-constexpr int HN_SHARED_BYTES = (sizeof(HnShared) + 255) & ~255;
-
-HN_DEV void hn_fill_shared(HnShared* sh, const HnMlpArgs& a) {
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < HN_MAX_SLOTS; ++i) {
-      sh->slots[i].off = a.slots[i].off;
-      sh->slots[i].nt = a.slots[i].nt;
-    }
-#pragma unroll
-    for (int i = 0; i < HN_MAX_SRC; ++i) {
-      sh->src[i].ptr = a.src[i].ptr;
-      sh->src[i].ld = a.src[i].ld;
-      sh->src[i].per_ray = a.src[i].per_ray;
-    }
-#pragma unroll
-    for (int i = 0; i < HN_MAX_DST; ++i) {
-      sh->dst[i].ptr = a.dst[i].ptr;
-      sh->dst[i].ld = a.dst[i].ld;
-    }
-    sh->stash = reinterpret_cast<char*>(a.stash);
-    sh->masks = a.masks;
-    sh->training = a.training;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // generated input features
 // ------------------------------------------------------------------------------------------------
-HN_DEV HnSrc hn_src_select(const HnShared* a, int sid) { return a->src[sid]; }
+HN_DEV HnSrc hn_src_select(const HnMlpArgs& a, int sid) {
+  HnSrc s = a.src[0];
+  if (sid == 1) s = a.src[1];
+  if (sid == 2) s = a.src[2];
+  if (sid == 3) s = a.src[3];
+  return s;
+}
 
 template <bool BF16>
-HN_DEV float hn_feature(const HnFeat e, const HnShared* a, int p, int ray) {
+HN_DEV float hn_feature(const HnFeat e, const HnMlpArgs& a, int p, int ray) {
   const int kind = (e.packed >> 12) & 15;
   if (kind == HN_FEAT_ZERO) return 0.0f;
   const HnSrc s = hn_src_select(a, (e.packed >> 8) & 15);
@@ -102,7 +70,7 @@ HN_DEV float hn_feature(const HnFeat e, const HnShared* a, int p, int ray) {
 
 // d value / d x  of a generated feature
 template <bool BF16>
-HN_DEV float hn_feature_grad(const HnFeat e, const HnShared* a, int p, int ray) {
+HN_DEV float hn_feature_grad(const HnFeat e, const HnMlpArgs& a, int p, int ray) {
   const int kind = (e.packed >> 12) & 15;
   if (kind == HN_FEAT_ID) return 1.0f;
   const HnSrc s = hn_src_select(a, (e.packed >> 8) & 15);
@@ -114,7 +82,7 @@ HN_DEV float hn_feature_grad(const HnFeat e, const HnShared* a, int p, int ray) 
 }
 
 // fragments of one group of 64 generated features (invalid points -> zeros)
-HN_DEV void hn_make_group(bf16x8* out, const HnFeat* ft, const HnShared* a, int p, int ray, bool valid, int lane) {
+HN_DEV void hn_make_group(bf16x8* out, const HnFeat* ft, const HnMlpArgs& a, int p, int ray, bool valid, int lane) {
   const int h = lane >> 5;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -126,7 +94,7 @@ HN_DEV void hn_make_group(bf16x8* out, const HnFeat* ft, const HnShared* a, int 
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-HN_DEV void hn_make_group(float* out, const HnFeat* ft, const HnShared* a, int p, int ray, bool valid, int lane) {
+HN_DEV void hn_make_group(float* out, const HnFeat* ft, const HnMlpArgs& a, int p, int ray, bool valid, int lane) {
   const int h = lane >> 5;
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
@@ -165,127 +133,20 @@ HN_DEV void hn_gemm_k(f32x16& acc, const typename ModeT<BF16>::Frag* in, int K32
   else if (K32 == 1) hn_gemm_blocks<BF16, 1>(acc, in, ws);
 }
 
-// transposed stash of one 32-feature tile; the bf16 permuted-identity operand comes from LDS (ident)
 template <bool BF16>
-HN_DEV void hn_stash(const typename ModeT<BF16>::Frag* fr, const HnShared* a, int slot, int blk, int t, int lane,
-                     const char* ident) {
+HN_DEV void hn_stash(const typename ModeT<BF16>::Frag* fr, const HnMlpArgs& a, int slot, int blk, int t, int lane) {
   using M = ModeT<BF16>;
-  const HnSlot sl = a->slots[slot];
-  char* base = a->stash + sl.off + ((size_t)blk * sl.nt + t) * (M::TILE_UNITS * 1024);
-  f32x16 z;
-  if constexpr (BF16) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      z = hn_mfma_bf16(fr[u], *reinterpret_cast<const bf16x8*>(ident + u * 1024 + lane * 16), z);
-  } else {
-    z = hn_transpose_tile(fr, lane);
-  }
+  const HnSlot sl = a.slots[slot];
+  char* base = reinterpret_cast<char*>(a.stash) + sl.off + ((size_t)blk * sl.nt + t) * (M::TILE_UNITS * 1024);
+  const f32x16 z = hn_transpose_tile(fr, lane);
   hn_store_tile(z, base, lane, (typename M::Frag*)nullptr);
-}
-
-HN_DEV void hn_make_ident(char* ident, int tid) {
-  if (tid < 128) {   // [u][lane][8 bf16]
-    const int u = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
-    bf16x8 id;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) id[j] = (c == 16 * u + hn_pi16(h, j)) ? (__bf16)1.0f : (__bf16)0.0f;
-    *reinterpret_cast<bf16x8*>(ident + u * 1024 + lane * 16) = id;
-  }
 }
 
 constexpr int HN_AUXG_MAX = 3;  // generated-feature groups per layer (192 features)
 
-// out[t] = fragments of one tile; t is a run-time tile index, the register arrays need static indices
-template <int STEPS32, typename Frag>
-HN_DEV void hn_put_tile(Frag* out, int t, const Frag* src) {
-  switch (t) {
-#define HN_PUT(T)                                                              \
-  case T:                                                                      \
-    _Pragma("unroll") for (int s = 0; s < STEPS32; ++s) out[T * STEPS32 + s] = src[s]; \
-    break;
-    HN_PUT(0) HN_PUT(1) HN_PUT(2) HN_PUT(3) HN_PUT(4) HN_PUT(5) HN_PUT(6) HN_PUT(7)
-#undef HN_PUT
-    default: break;
-  }
-}
-
-struct HnLaneCtx {
-  int lane, h, r, p, ray, blk;
-  bool valid, all_valid, wave_valid;
-};
-
-// relu bit masks: element e = 16*(t&1) + i of a tile pair lives at bit 31-e; bit = 1 <=> pre-activation has sign 0
-HN_DEV unsigned hn_sign_push(unsigned sb, float v) { return __builtin_amdgcn_alignbit(sb, __float_as_uint(v), 31); }
-HN_DEV float hn_mask_apply(float v, unsigned bits, int e) {
-  const int m = ((int)(bits << e)) >> 31;
-  return __uint_as_float(__float_as_uint(v) & (unsigned)m);
-}
-
 // ------------------------------------------------------------------------------------------------
 // forward machine
 // ------------------------------------------------------------------------------------------------
-template <bool BF16>
-HN_DEV void hn_fwd_layer(const int* w, const HnShared* a, const typename ModeT<BF16>::Frag* in,
-                         typename ModeT<BF16>::Frag* out, f32x16& accL, WStream<ModeT<BF16>::WAVES>& ws,
-                         const float* bias_lds, const HnFeat* feat_lds, const char* ident, const HnLaneCtx& c) {
-  using M = ModeT<BF16>;
-  using Frag = typename M::Frag;
-  const int K32 = w[1] & 255, nG = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
-  const int act = (w[1] >> 24) & 15, flags = (w[1] >> 28) & 15;
-  const float* bias = bias_lds + w[2];
-  const bool do_mask = a->training && w[4] >= 0 && c.wave_valid;
-  const bool do_stash = a->training && w[5] >= 0 && c.wave_valid;
-  Frag aux[HN_AUXG_MAX * 2 * M::STEPS32];
-#pragma unroll
-  for (int g = 0; g < HN_AUXG_MAX; ++g) {
-    if (g < nG) {
-      hn_make_group(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, a, c.p, c.ray, c.valid, c.lane);
-      if (a->training && w[6] >= 0 && c.wave_valid) {
-        hn_stash<BF16>(aux + g * 2 * M::STEPS32, a, w[6], c.blk, 2 * g, c.lane, ident);
-        hn_stash<BF16>(aux + (g * 2 + 1) * M::STEPS32, a, w[6], c.blk, 2 * g + 1, c.lane, ident);
-      }
-    }
-  }
-  unsigned sb = 0;
-  // static tile loop: a run-time tile index would force the fragment arrays into scratch memory
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    if (t >= NT) break;
-    f32x16 acc;
-    hn_init_acc(acc, bias, t, c.h);
-    hn_gemm_k<BF16>(acc, in, K32, ws);
-#pragma unroll
-    for (int g = 0; g < HN_AUXG_MAX; ++g)
-      if (g < nG) hn_gemm_blocks<BF16, 2>(acc, aux + g * 2 * M::STEPS32, ws);
-    if (flags & HN_LAYER_NO_COMMIT) accL = acc;
-    if (do_mask) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sb = hn_sign_push(sb, acc[i]);
-      if ((t & 1) || t == NT - 1) {
-        if (!(t & 1)) sb <<= 16;
-        const HnSlot sl = a->slots[w[4]];
-        __builtin_nontemporal_store(~sb, a->masks + sl.off / 4 + ((size_t)c.blk * sl.nt + (t >> 1)) * 64 + c.lane);
-        sb = 0;
-      }
-    }
-    if (act == HN_ACT_RELU) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], 0.0f);
-    }
-    if (!c.all_valid) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = c.valid ? acc[i] : 0.0f;
-    }
-    Frag fr[M::STEPS32];
-    hn_acc_to_frags(acc, fr);
-    if (do_stash) hn_stash<BF16>(fr, a, w[5], c.blk, t, c.lane, ident);
-#pragma unroll
-    for (int s = 0; s < M::STEPS32; ++s) out[t * M::STEPS32 + s] = fr[s];
-  }
-}
-
 template <bool BF16>
 __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_fwd_kernel(const HnMlpArgs a) {
   using M = ModeT<BF16>;
@@ -293,6 +154,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
   constexpr int PTS = M::WAVES * 32;
   const int ntiles = (a.n_points + PTS - 1) / PTS;
 
@@ -303,68 +165,105 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   ws.wave = wave;
   ws.lane = lane;
 
-  Frag bufA[8 * M::STEPS32];
-  Frag bufB[8 * M::STEPS32];
+  Frag cur[8 * M::STEPS32];
+  Frag nxt[8 * M::STEPS32];
   f32x16 accL;
 
-  // identity operand, biases and the feature table live in LDS for the whole kernel:
-  // no global loads inside the MFMA loops
-  char* ident = smem + 2 * HN_CHUNK_UNITS * 1024;
-  HnShared* sh = reinterpret_cast<HnShared*>(ident + 2048);
-  float* bias_lds = reinterpret_cast<float*>(ident + 2048 + HN_SHARED_BYTES);
+  // biases and the feature table live in LDS for the whole kernel: no global loads inside the MFMA loops
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * HN_CHUNK_UNITS * 1024);
   HnFeat* feat_lds = reinterpret_cast<HnFeat*>(bias_lds + ((a.n_bias + 3) & ~3));
-  hn_make_ident(ident, threadIdx.x);
-  hn_fill_shared(sh, a);
   for (int i = threadIdx.x; i < a.n_bias; i += blockDim.x) bias_lds[i] = a.bias[i];
   for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
   __syncthreads();
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    HnLaneCtx c;
-    c.lane = lane; c.h = lane >> 5; c.r = lane & 31;
-    c.blk = tile * M::WAVES + wave;  // 32-point block of this wave
-    const int p0 = c.blk * 32 + c.r;
-    c.valid = p0 < a.n_points;
-    c.p = c.valid ? p0 : a.n_points - 1;
-    c.ray = c.p / a.samples_per_ray;
-    c.wave_valid = c.blk * 32 < a.n_points;        // wave-uniform: the block holds at least one point
-    c.all_valid = c.blk * 32 + 32 <= a.n_points;   // wave-uniform: no lane needs masking
+    const int blk = tile * M::WAVES + wave;  // 32-point block of this wave
+    const int p0 = blk * 32 + r;
+    const bool valid = p0 < a.n_points;
+    const int p = valid ? p0 : a.n_points - 1;
+    const int ray = p / a.samples_per_ray;
+    const bool wave_valid = blk * 32 < a.n_points;  // wave-uniform: the block holds at least one point
     ws.start();
 
     for (int op = 0; op < a.n_ops; ++op) {
       const int* w = a.ops + op * HN_OP_WORDS;
       const int code = w[0];
       if (code == HN_OP_LAYER) {
-        hn_fwd_layer<BF16>(w, sh, bufA, bufB, accL, ws, bias_lds, feat_lds, ident, c);
-        if (!(((w[1] >> 28) & 15) & HN_LAYER_NO_COMMIT)) {
-          const int NT = (w[1] >> 16) & 255;
+        const int K32 = w[1] & 255, nG = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
+        const int act = (w[1] >> 24) & 15, flags = (w[1] >> 28) & 15;
+        const float* bias = bias_lds + w[2];
+        const bool do_mask = a.training && w[4] >= 0 && wave_valid;
+        const bool do_stash = a.training && w[5] >= 0 && wave_valid;
+        Frag aux[HN_AUXG_MAX * 2 * M::STEPS32];
+#pragma unroll
+        for (int g = 0; g < HN_AUXG_MAX; ++g) {
+          if (g < nG) {
+            hn_make_group(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, a, p, ray, valid, lane);
+            if (a.training && w[6] >= 0 && wave_valid) {
+              hn_stash<BF16>(aux + g * 2 * M::STEPS32, a, w[6], blk, 2 * g, lane);
+              hn_stash<BF16>(aux + (g * 2 + 1) * M::STEPS32, a, w[6], blk, 2 * g + 1, lane);
+            }
+          }
+        }
+        unsigned bits = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (t < NT) {
+            f32x16 acc;
+            hn_init_acc(acc, bias, t, h);
+            hn_gemm_k<BF16>(acc, cur, K32, ws);
+#pragma unroll
+            for (int g = 0; g < HN_AUXG_MAX; ++g)
+              if (g < nG) hn_gemm_blocks<BF16, 2>(acc, aux + g * 2 * M::STEPS32, ws);
+            accL = acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const bool pos = acc[i] > 0.0f;
+              bits |= (pos ? 1u : 0u) << (16 * (t & 1) + i);
+              float x = acc[i];
+              if (act == HN_ACT_RELU) x = pos ? x : 0.0f;
+              acc[i] = valid ? x : 0.0f;
+            }
+            hn_acc_to_frags(acc, nxt + t * M::STEPS32);
+            if ((t & 1) || t == NT - 1) {
+              if (do_mask) {
+                const HnSlot sl = a.slots[w[4]];
+                uint32_t* mp = a.masks + sl.off / 4 + ((size_t)blk * sl.nt + (t >> 1)) * 64 + lane;
+                __builtin_nontemporal_store(bits, mp);
+              }
+              bits = 0;
+            }
+            if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, a, w[5], blk, t, lane);
+          }
+        }
+        if (!(flags & HN_LAYER_NO_COMMIT)) {
 #pragma unroll
           for (int t = 0; t < 8; ++t)
             if (t < NT)
 #pragma unroll
-              for (int s2 = 0; s2 < M::STEPS32; ++s2) bufA[t * M::STEPS32 + s2] = bufB[t * M::STEPS32 + s2];
+              for (int s = 0; s < M::STEPS32; ++s) cur[t * M::STEPS32 + s] = nxt[t * M::STEPS32 + s];
         }
       } else if (code == HN_OP_OUT) {
         const int n = w[3];
-        if (c.h == 0 && c.valid) {
-          const HnDst d = sh->dst[w[1]];
+        if (h == 0 && valid) {
+          const HnDst d = a.dst[w[1]];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             if (i < n) {
               float y = accL[i];
               if (w[4] == 1) y = 1.0f / (1.0f + expf(-y));
               if (w[5] >= 0) {
-                const HnSrc s = sh->src[w[5]];
-                y = __fadd_rn(s.ptr[(size_t)(s.per_ray ? c.ray : c.p) * s.ld + w[6] + i], y);
+                const HnSrc s = a.src[w[5]];
+                y = __fadd_rn(s.ptr[(size_t)(s.per_ray ? ray : p) * s.ld + w[6] + i], y);
               }
-              d.ptr[(size_t)c.p * d.ld + w[2] + i] = y;
+              d.ptr[(size_t)p * d.ld + w[2] + i] = y;
             }
           }
         }
       } else if (code == HN_OP_OUT_WIDE) {
         const int n = w[3], NT = w[4];
-        if (c.valid) {
-          const HnDst d = sh->dst[w[1]];
+        if (valid) {
+          const HnDst d = a.dst[w[1]];
 #pragma unroll
           for (int t = 0; t < 8; ++t)
             if (t < NT) {
@@ -373,15 +272,14 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                   for (int j = 0; j < 8; ++j) {
-                    const int row = 32 * t + 16 * s + hn_pi16(c.h, j);
-                    if (row < n)
-                      d.ptr[(size_t)c.p * d.ld + w[2] + row] = (float)bufA[2 * t + s][j];
+                    const int row = 32 * t + 16 * s + hn_pi16(h, j);
+                    if (row < n) d.ptr[(size_t)p * d.ld + w[2] + row] = (float)cur[2 * t + s][j];
                   }
               } else {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                  const int row = 32 * t + hn_rho(q, c.h);
-                  if (row < n) d.ptr[(size_t)c.p * d.ld + w[2] + row] = bufA[16 * t + q];
+                  const int row = 32 * t + hn_rho(q, h);
+                  if (row < n) d.ptr[(size_t)p * d.ld + w[2] + row] = cur[16 * t + q];
                 }
               }
             }
@@ -395,83 +293,17 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 // backward-data machine
 // ------------------------------------------------------------------------------------------------
 template <bool BF16>
-HN_DEV void hn_bwd_layer(const int* w, const HnShared* a, const typename ModeT<BF16>::Frag* in,
-                         const typename ModeT<BF16>::Frag* in2, typename ModeT<BF16>::Frag* out,
-                         WStream<ModeT<BF16>::WAVES>& ws, const char* ident, const HnLaneCtx& c) {
-  using M = ModeT<BF16>;
-  using Frag = typename M::Frag;
-  const int K32 = w[1] & 255, K32b = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
-  const bool has_mask = w[4] >= 0;
-  const bool do_stash = a->training && w[5] >= 0 && c.wave_valid;
-  unsigned mbits[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-  if (has_mask) {   // all relu masks of the layer up front: one VMEM wait per layer, none per tile
-    const HnSlot sl = a->slots[w[4]];
-#pragma unroll
-    for (int dd = 0; dd < 4; ++dd)
-      if (2 * dd < NT)
-        mbits[dd] = c.wave_valid ? a->masks[sl.off / 4 + ((size_t)c.blk * sl.nt + dd) * 64 + c.lane] : 0u;
-  }
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    if (t >= NT) break;
-    f32x16 acc;
-    hn_init_acc(acc, nullptr, t, c.h);
-    hn_gemm_k<BF16>(acc, in, K32, ws);
-    if (K32b) hn_gemm_blocks<BF16, 1>(acc, in2, ws);
-    if (has_mask) {
-      const unsigned bits = mbits[t >> 1];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = hn_mask_apply(acc[i], bits, 16 * (t & 1) + i);
-    }
-    if (!c.all_valid) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = c.valid ? acc[i] : 0.0f;
-    }
-    Frag fr[M::STEPS32];
-    hn_acc_to_frags(acc, fr);
-    if (do_stash) hn_stash<BF16>(fr, a, w[5], c.blk, t, c.lane, ident);
-#pragma unroll
-    for (int s = 0; s < M::STEPS32; ++s) out[t * M::STEPS32 + s] = fr[s];
-  }
-}
-
-template <bool BF16>
-HN_DEV void hn_bwd_aux(const int* w, const HnShared* a, const typename ModeT<BF16>::Frag* in,
-                       const typename ModeT<BF16>::Frag* in2, WStream<ModeT<BF16>::WAVES>& ws,
-                       const HnFeat* feat_lds, float* dsrc_lds, const HnLaneCtx& c) {
-  // gradient of generated features: per 32-feature tile tmp = W_aux^T . dZ, then the chain rule
-  const int K32 = w[1] & 255, K32b = (w[1] >> 8) & 255, nG = (w[1] >> 16) & 255;
-  for (int tt = 0; tt < 2 * nG; ++tt) {
-    f32x16 acc;
-    hn_init_acc(acc, nullptr, 0, c.h);
-    hn_gemm_k<BF16>(acc, in, K32, ws);
-    if (K32b) hn_gemm_blocks<BF16, 1>(acc, in2, ws);
-    const HnFeat* ft = feat_lds + w[3] + 32 * tt;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const HnFeat e = ft[hn_rho(i, c.h)];
-      const int slot = ((e.packed >> 16) & 255) - 1;
-      if (slot >= 0 && c.valid)
-        atomicAdd(dsrc_lds + c.r * HN_DSRC_COMPS + slot, acc[i] * hn_feature_grad<BF16>(e, a, c.p, c.ray));
-    }
-  }
-}
-
-template <bool BF16>
 __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_bwd_kernel(const HnMlpArgs a) {
   using M = ModeT<BF16>;
   using Frag = typename M::Frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
   constexpr int PTS = M::WAVES * 32;
   const int ntiles = (a.n_points + PTS - 1) / PTS;
-  char* ident = smem + 2 * HN_CHUNK_UNITS * 1024;
-  HnShared* sh = reinterpret_cast<HnShared*>(ident + 2048);
-  HnFeat* feat_lds = reinterpret_cast<HnFeat*>(ident + 2048 + HN_SHARED_BYTES);
+  HnFeat* feat_lds = reinterpret_cast<HnFeat*>(smem + 2 * HN_CHUNK_UNITS * 1024);
   float* dsrc_lds = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (32 * HN_DSRC_COMPS);
-  hn_make_ident(ident, threadIdx.x);
-  hn_fill_shared(sh, a);
   for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
   __syncthreads();
 
@@ -482,20 +314,17 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   ws.wave = wave;
   ws.lane = lane;
 
-  Frag bufA[8 * M::STEPS32];
-  Frag bufB[8 * M::STEPS32];
+  Frag cur[8 * M::STEPS32];
+  Frag nxt[8 * M::STEPS32];
   Frag cur2[M::STEPS32];
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    HnLaneCtx c;
-    c.lane = lane; c.h = lane >> 5; c.r = lane & 31;
-    c.blk = tile * M::WAVES + wave;
-    const int p0 = c.blk * 32 + c.r;
-    c.valid = p0 < a.n_points;
-    c.p = c.valid ? p0 : a.n_points - 1;
-    c.ray = c.p / a.samples_per_ray;
-    c.wave_valid = c.blk * 32 < a.n_points;
-    c.all_valid = c.blk * 32 + 32 <= a.n_points;
+    const int blk = tile * M::WAVES + wave;
+    const int p0 = blk * 32 + r;
+    const bool valid = p0 < a.n_points;
+    const int p = valid ? p0 : a.n_points - 1;
+    const int ray = p / a.samples_per_ray;
+    const bool wave_valid = blk * 32 < a.n_points;
     for (int i = lane; i < 32 * HN_DSRC_COMPS; i += 64) dsrc_lds[i] = 0.0f;
     ws.start();
 
@@ -507,15 +336,15 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const int n = w[3] & 255;
         const bool to2 = (w[3] >> 8) & 1;
         float d[4] = {0.f, 0.f, 0.f, 0.f};
-        if (c.h == 0 && c.valid) {
-          const HnSrc s = sh->src[w[1]];
+        if (h == 0 && valid) {
+          const HnSrc s = a.src[w[1]];
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (i < n) {
-              float g = s.ptr[(size_t)c.p * s.ld + w[2] + i];
+              float g = s.ptr[(size_t)p * s.ld + w[2] + i];
               if (w[4] == 1) {
-                const HnSrc ys = sh->src[w[5]];
-                const float y = ys.ptr[(size_t)c.p * ys.ld + w[6] + i];
+                const HnSrc ys = a.src[w[5]];
+                const float y = ys.ptr[(size_t)p * ys.ld + w[6] + i];
                 g = g * y * (1.0f - y);
               }
               d[i] = g;
@@ -530,57 +359,95 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
           for (int i = 0; i < 4; ++i) tmp[i] = d[i];             // step q, h==0 <-> feature q
         }
-        if (a.training && w[7] >= 0 && c.wave_valid) hn_stash<BF16>(tmp, sh, w[7], c.blk, 0, lane, ident);
+        if (a.training && w[7] >= 0 && wave_valid) hn_stash<BF16>(tmp, a, w[7], blk, 0, lane);
 #pragma unroll
         for (int s = 0; s < M::STEPS32; ++s) {
           if (to2) cur2[s] = tmp[s];
-          else bufA[s] = tmp[s];
+          else cur[s] = tmp[s];
         }
       } else if (code == HN_BOP_LOAD_WIDE) {
         const int n = w[3], NT = w[4];
-        const HnSrc s = sh->src[w[1]];
+        const HnSrc s = a.src[w[1]];
         unsigned bits = 0xffffffffu;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          if (t >= NT) break;
-          if (w[5] >= 0 && !(t & 1)) {  // output activation was relu: dZ = dY * relu'
-            const HnSlot sl = sh->slots[w[5]];
-            bits = c.wave_valid ? a.masks[sl.off / 4 + ((size_t)c.blk * sl.nt + (t >> 1)) * 64 + lane] : 0u;
-          }
-          f32x16 v;
+          if (t < NT) {
+            if (w[5] >= 0 && !(t & 1)) {  // output activation was relu: dZ = dY * relu'
+              const HnSlot sl = a.slots[w[5]];
+              bits = wave_valid ? a.masks[sl.off / 4 + ((size_t)blk * sl.nt + (t >> 1)) * 64 + lane] : 0u;
+            }
+            f32x16 v;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int row = 32 * t + hn_rho(i, c.h);
-            const float g = (c.valid && row < n) ? s.ptr[(size_t)c.p * s.ld + w[2] + row] : 0.0f;
-            v[i] = hn_mask_apply(g, bits, 16 * (t & 1) + i);
+            for (int i = 0; i < 16; ++i) {
+              const int row = 32 * t + hn_rho(i, h);
+              const bool keep = ((bits >> (16 * (t & 1) + i)) & 1u) != 0u;
+              v[i] = (valid && keep && row < n) ? s.ptr[(size_t)p * s.ld + w[2] + row] : 0.0f;
+            }
+            hn_acc_to_frags(v, cur + t * M::STEPS32);
+            if (a.training && w[7] >= 0 && wave_valid) hn_stash<BF16>(cur + t * M::STEPS32, a, w[7], blk, t, lane);
           }
-          Frag fr[M::STEPS32];
-          hn_acc_to_frags(v, fr);
-          if (a.training && w[7] >= 0 && c.wave_valid) hn_stash<BF16>(fr, sh, w[7], c.blk, t, lane, ident);
-#pragma unroll
-          for (int s2 = 0; s2 < M::STEPS32; ++s2) bufA[t * M::STEPS32 + s2] = fr[s2];
         }
       } else if (code == HN_BOP_LAYER) {
-        hn_bwd_layer<BF16>(w, sh, bufA, cur2, bufB, ws, ident, c);
-        {
-          const int NT = (w[1] >> 16) & 255;
+        const int K32 = w[1] & 255, K32b = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
+        const bool has_mask = w[4] >= 0;
+        const bool do_stash = a.training && w[5] >= 0 && wave_valid;
+        unsigned bits = 0xffffffffu;
+        unsigned mbits[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        if (has_mask) {   // all relu masks of the layer up front: one VMEM wait per layer, none per tile
+          const HnSlot sl = a.slots[w[4]];
 #pragma unroll
-          for (int t = 0; t < 8; ++t)
-            if (t < NT)
-#pragma unroll
-              for (int s2 = 0; s2 < M::STEPS32; ++s2) bufA[t * M::STEPS32 + s2] = bufB[t * M::STEPS32 + s2];
+          for (int dd = 0; dd < 4; ++dd)
+            if (2 * dd < NT)
+              mbits[dd] = wave_valid ? a.masks[sl.off / 4 + ((size_t)blk * sl.nt + dd) * 64 + lane] : 0u;
         }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (t < NT) {
+            f32x16 acc;
+            hn_init_acc(acc, nullptr, t, h);
+            hn_gemm_k<BF16>(acc, cur, K32, ws);
+            if (K32b) hn_gemm_blocks<BF16, 1>(acc, cur2, ws);
+            if (!(t & 1)) bits = mbits[t >> 1];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const bool keep = ((bits >> (16 * (t & 1) + i)) & 1u) != 0u;
+              acc[i] = (keep && valid) ? acc[i] : 0.0f;
+            }
+            hn_acc_to_frags(acc, nxt + t * M::STEPS32);
+            if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, a, w[5], blk, t, lane);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (t < NT)
+#pragma unroll
+            for (int s = 0; s < M::STEPS32; ++s) cur[t * M::STEPS32 + s] = nxt[t * M::STEPS32 + s];
       } else if (code == HN_BOP_AUX) {
-        hn_bwd_aux<BF16>(w, sh, bufA, cur2, ws, feat_lds, dsrc_lds, c);
+        // gradient of generated features: per 32-feature tile tmp = W_aux^T . dZ, then the chain rule
+        const int K32 = w[1] & 255, K32b = (w[1] >> 8) & 255, nG = (w[1] >> 16) & 255;
+        for (int tt = 0; tt < 2 * nG; ++tt) {
+          f32x16 acc;
+          hn_init_acc(acc, nullptr, 0, h);
+          hn_gemm_k<BF16>(acc, cur, K32, ws);
+          if (K32b) hn_gemm_blocks<BF16, 1>(acc, cur2, ws);
+          const HnFeat* ft = feat_lds + w[3] + 32 * tt;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const HnFeat e = ft[hn_rho(i, h)];
+            const int slot = ((e.packed >> 16) & 255) - 1;
+            if (slot >= 0 && valid)
+              atomicAdd(dsrc_lds + r * HN_DSRC_COMPS + slot, acc[i] * hn_feature_grad<BF16>(e, a, p, ray));
+          }
+        }
       }
     }
     // source gradients of this block -> global
     if (a.n_dsrc > 0) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       for (int i = lane; i < 32 * HN_DSRC_COMPS; i += 64) {
-        const int rr = i / HN_DSRC_COMPS, cc = i % HN_DSRC_COMPS;
-        const int pp = c.blk * 32 + rr;
-        if (cc < a.n_dsrc && pp < a.n_points) a.dsrc[(size_t)pp * a.n_dsrc + cc] = dsrc_lds[i];
+        const int rr = i / HN_DSRC_COMPS, c = i % HN_DSRC_COMPS;
+        const int pp = blk * 32 + rr;
+        if (c < a.n_dsrc && pp < a.n_points) a.dsrc[(size_t)pp * a.n_dsrc + c] = dsrc_lds[i];
       }
     }
   }
@@ -880,7 +747,7 @@ extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
   int rc = hn_check_args(a);
   if (rc) return rc;
   hn_allow_big_lds();
-  const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + 2048 + HN_SHARED_BYTES + (size_t)((a->n_bias + 3) & ~3) * 4 + (size_t)a->n_feat * 8;
+  const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + (size_t)((a->n_bias + 3) & ~3) * 4 + (size_t)a->n_feat * 8;
   if (lds > 150 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
     hipLaunchKernelGGL(hn_mlp_fwd_kernel<true>, dim3(hn_grid_for(a->n_points, 256)), dim3(512), lds,
@@ -900,11 +767,11 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
   const size_t flds = (size_t)((a->n_feat + 1) & ~1) * 8;
   if (flds > 64 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
-    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + 2048 + HN_SHARED_BYTES + flds + 8 * 32 * HN_DSRC_COMPS * 4;
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 8 * 32 * HN_DSRC_COMPS * 4;
     hipLaunchKernelGGL(hn_mlp_bwd_kernel<true>, dim3(hn_grid_for(a->n_points, 256)), dim3(512), lds,
                        (hipStream_t)stream, *a);
   } else {
-    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + 2048 + HN_SHARED_BYTES + flds + 4 * 32 * HN_DSRC_COMPS * 4;
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 4 * 32 * HN_DSRC_COMPS * 4;
     hipLaunchKernelGGL(hn_mlp_bwd_kernel<false>, dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
                        (hipStream_t)stream, *a);
   }

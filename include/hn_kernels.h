@@ -131,6 +131,7 @@ typedef struct {
   HnSrc src[HN_MAX_SRC]; /* forward: feature sources ; backward: same + gradient inputs */
   HnDst dst[HN_MAX_DST];
   HnSlot slots[HN_MAX_SLOTS];
+  uint64_t* prof;        /* diagnostic only (NULL in production): 8 shader-clock sums, see tools/ */
 } HnMlpArgs;
 
 /* weight packing: one descriptor per 1-KiB unit of a stream */

@@ -269,11 +269,11 @@ def run_forward(prog, mode, tables, params, srcs, n_points, spr, dst_widths, tra
                     for g in range(ng):
                         acc = gemm_blocks(mode, acc, ws, aux[g], 2)
                     accL = acc.copy()
-                    pos = ~np.signbit(acc)          # sign bit 0 (relu'(+0) = 1: only structural zeros hit it)
+                    pos = acc > 0
                     for i in range(16):
-                        bits |= (pos[:, i].astype(np.uint64) << np.uint64(31 - (16 * (t & 1) + i)))
+                        bits |= (pos[:, i].astype(np.uint64) << np.uint64(16 * (t & 1) + i))
                     if act == 1:
-                        acc = np.maximum(acc, 0.0)
+                        acc = np.where(pos, acc, 0.0)
                     acc = np.where(valid[:, None], acc, 0.0)
                     nxt[t * mode.steps32:(t + 1) * mode.steps32] = acc_to_frags(mode, acc)
                     if (t & 1) or t == nt - 1:
@@ -363,7 +363,7 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
                     for l in range(64):
                         for i in range(16):
                             row = 32 * t + rho(i, l >> 5)
-                            keep = True if bits is None else bool((int(bits[l]) >> (31 - (16 * (t & 1) + i))) & 1)
+                            keep = True if bits is None else bool((int(bits[l]) >> (16 * (t & 1) + i)) & 1)
                             if valid[l] and keep and row < n:
                                 v[l, i] = arr[p[l], w[2] + row]
                     cur[t * mode.steps32:(t + 1) * mode.steps32] = acc_to_frags(mode, v)
@@ -381,7 +381,7 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
                         bits = stash.get_mask(w[4], blk, t >> 1)
                         for l in range(64):
                             for i in range(16):
-                                if not ((int(bits[l]) >> (31 - (16 * (t & 1) + i))) & 1):
+                                if not ((int(bits[l]) >> (16 * (t & 1) + i)) & 1):
                                     acc[l, i] = 0.0
                     acc = np.where(valid[:, None], acc, 0.0)
                     nxt[t * mode.steps32:(t + 1) * mode.steps32] = acc_to_frags(mode, acc)
