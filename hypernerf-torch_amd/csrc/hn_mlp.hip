@@ -599,29 +599,46 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwJob* jobs, i
   }
   const bool do_bias = jb.b_off >= 0 && wk == 0 && my_n > 0;
 
-  auto issue_count = [&](int nblk_s) -> int {
-    int n = 0;
-    for (int q = wave; q < nblk_s * UB; q += 8) ++n;
-    return n;
-  };
+  // Per-wave LDS-DMA slots of one stage, decoded ONCE (the integer divisions by run-time tile counts would
+  // otherwise cost ~600 scalar instructions per stage): slot i moves 1 KiB from
+  // sbase[i] + (first block of the stage) * sstride[i]  to  stage buffer + sdst[i], if sblk[i] < blocks in stage.
+  constexpr int MAXSLOT = 8;                     // <= 32 units per stage / 8 waves... (fp32 tiles: 4 units each)
+  unsigned long long sbase[MAXSLOT];
+  int sinfo[MAXSLOT];          // block index inside the stage << 1 | (dZ tile ? 1 : 0) ; huge = unused slot
+  const unsigned zstride = (unsigned)(jb.z_nt * TB), xstride = (unsigned)(jb.x_nt * TB);
+  int per_stage = 0;
+#pragma unroll
+  for (int i = 0; i < MAXSLOT; ++i) {
+    const int q = wave + 8 * i;
+    sinfo[i] = 1 << 30;
+    sbase[i] = 0;
+    if (q < bps * UB) {
+      const int bi = q / UB, r = q % UB;
+      const int tile = r / TU, u = r % TU;
+      const bool isz = tile < jb.n_nt;
+      const unsigned long long rel = isz ? ((unsigned long long)bi * jb.z_nt + jb.z_t0 + tile) * TB
+                                         : ((unsigned long long)bi * jb.x_nt + jb.x_t0 + (tile - jb.n_nt)) * TB;
+      sbase[i] = (isz ? jb.z_off : jb.x_off) + rel + (unsigned long long)u * 1024;
+      sinfo[i] = bi << 1 | (isz ? 1 : 0);
+      ++per_stage;
+    }
+  }
   auto issue = [&](int s) {
     char* dst = smem + (size_t)(s % STAGES) * stage_bytes;
     const int b0 = jb.blk0 + s * bps;
     const int nblk_s = min(bps, jb.blk1 - b0);
-    for (int q = wave; q < nblk_s * UB; q += 8) {
-      const int bi = q / UB, r = q % UB;
-      const int tile = r / TU, u = r % TU;
-      const size_t b = (size_t)(b0 + bi);
-      const char* src = tile < jb.n_nt ? stash + jb.z_off + (b * jb.z_nt + jb.z_t0 + tile) * TB
-                                       : stash + jb.x_off + (b * jb.x_nt + jb.x_t0 + (tile - jb.n_nt)) * TB;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * 1024 + lane * 16),
-                                       (__attribute__((address_space(3))) void*)(dst + (size_t)q * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MAXSLOT; ++i) {
+      if ((sinfo[i] >> 1) < nblk_s) {
+        const char* src = stash + sbase[i] + (unsigned long long)b0 * ((sinfo[i] & 1) ? zstride : xstride);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0, 0);
+      }
     }
   };
 
   // STAGES-1 stages in flight.  Every wave issues the same number of LDS-DMA instructions for every FULL stage,
   // so "all but the youngest k stages landed" is vmcnt(k * per_stage) (the last, partial stage only lowers it).
-  const int per_stage = issue_count(bps);
   for (int s0 = 0; s0 < STAGES - 1 && s0 < nstage; ++s0) issue(s0);
   for (int s = 0; s < nstage; ++s) {
     const int younger = min(STAGES - 2, nstage - 1 - s);     // stages issued after stage s that may stay in flight
@@ -635,20 +652,19 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwJob* jobs, i
     const int nblk_s = min(bps, nb - s * bps);
     for (int bi = 0; bi < nblk_s; ++bi) {
       const char* sb = st + (size_t)bi * UB * 1024;
-      DwFrag<BF16> za[4], xb[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (i < my_n) za[i].load(sb + (size_t)(n0 + i) * TB, lane);
+      DwFrag<BF16> xb[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         if (j < my_k) xb[j].load(sb + (size_t)(jb.n_nt + k0 + j) * TB, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (i < my_n) {
+          DwFrag<BF16> za;
+          za.load(sb + (size_t)(n0 + i) * TB, lane);
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            if (j < my_k) DwFrag<BF16>::mma(acc[i][j], za[i], xb[j]);
-          if (do_bias) DwFrag<BF16>::mma_ones(accb[i], za[i]);
+            if (j < my_k) DwFrag<BF16>::mma(acc[i][j], za, xb[j]);
+          if (do_bias) DwFrag<BF16>::mma_ones(accb[i], za);
         }
       }
     }
