@@ -161,29 +161,38 @@ def main():
         times = L.collect_kernel_times()
         L.KERNEL_TIMES = None
         tot = {k: sum(v) for k, v in times.items()}
-        dom = max(tot, key=tot.get)
-        avg_ms = tot[dom] / len(times[dom])
-        lvl = "fine" if "fine" in dom else "coarse"
-        call = [c for k, c in model._template_calls.items() if k[0] == lvl]
-        pts = b * (a.nc + a.nf if lvl == "fine" else a.nc)
-        flops = 0.0
-        if "template" in dom and call:
-            flops = 2.0 * macs_per_point(call[0].program) * pts
-        elif "TranslationField" in dom:
-            flops = 2.0 * macs_per_point(model.warp_field._calls[next(iter(model.warp_field._calls))].program) * pts
-        ach = flops / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
-        step_ms = sum(tot.values()) / a.steps
-        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": PEAK[a.precision] / 1e12,
-                           "unit": "TFLOP/s", "frac": ach / PEAK[a.precision], "traffic": None,
-                           "avg_launch_ms": avg_ms, "algorithmic_flops_per_launch": flops,
+        # group launches by KERNEL (= rocprofv3's per-symbol rows): forward / backward-data / weight-gradient machine
+        progs = {}
+        for lvl, pts in (("coarse", b * a.nc), ("fine", b * (a.nc + a.nf))):
+            call = [c for k, c in model._template_calls.items() if k[0] == lvl][0]
+            progs[f"template_{lvl}"] = (macs_per_point(call.program), pts)
+        warp_prog = model.warp_field._calls[next(iter(model.warp_field._calls))].program
+        sheet_prog = model.hyper_sheet_mlp._calls[next(iter(model.hyper_sheet_mlp._calls))].program
+        all_pts = b * (2 * a.nc + a.nf)
+        progs["TranslationField"] = (macs_per_point(warp_prog), all_pts)
+        progs["HyperSheetMLP"] = (macs_per_point(sheet_prog), all_pts)
+        flops_per_step = sum(2.0 * m * p for m, p in progs.values())        # per machine kernel and step
+        kern = {}
+        for sym in ("hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad"):
+            ks = [k for k in tot if k.startswith(sym + "[")]
+            kern[sym] = (sum(tot[k] for k in ks) / a.steps, sum(len(times[k]) for k in ks) / a.steps)
+        dom = max(kern, key=lambda k: kern[k][0])
+        ms_step, launches = kern[dom]
+        avg_ms = ms_step / launches
+        ach = flops_per_step / (ms_step * 1e-3)
+        res["roofline"] = {"bound": "mfma", "kernel": {"hn_mlp_forward": "hn_mlp_fwd_kernel<true>",
+                                                       "hn_mlp_backward": "hn_mlp_bwd_kernel<true>",
+                                                       "hn_mlp_wgrad": "hn_wgrad_kernel<true>"}[dom]
+                           if a.precision == "bf16" else dom,
+                           "achieved": ach / 1e12, "peak": PEAK[a.precision] / 1e12, "unit": "TFLOP/s",
+                           "frac": ach / PEAK[a.precision], "traffic": None,
+                           "avg_launch_ms": avg_ms, "launches_per_step": launches,
+                           "algorithmic_flops_per_launch": flops_per_step / launches,
+                           "note": "achieved = algorithmic GEMM FLOPs of all launches of this kernel in a step / their "
+                                   "summed HIP-event duration; HBM traffic per launch: profiles/r01_pmc_per_kernel.csv",
                            "kernel_ms_per_step": {k: tot[k] / a.steps for k in sorted(tot, key=tot.get, reverse=True)},
-                           "sum_kernel_ms_per_step": step_ms}
-        # whole-step algorithmic rate (3x forward MACs over all three MLPs and both levels)
-        mac_pt = macs_per_point(call[0].program) if call else 0
-        for m in (model.warp_field, model.hyper_sheet_mlp):
-            mac_pt += macs_per_point(m._calls[next(iter(m._calls))].program)
-        step_flops = 6.0 * mac_pt * b * (2 * a.nc + a.nf)
-        res["step_tflops"] = step_flops / (dt / a.steps) / 1e12
+                           "sum_kernel_ms_per_step": sum(tot.values()) / a.steps}
+        res["step_tflops"] = 3.0 * flops_per_step / (dt / a.steps) / 1e12
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a)
