@@ -23,12 +23,13 @@ HN_MODE_F32, HN_MODE_BF16 = 0, 1
 HN_MAX_SRC, HN_MAX_DST, HN_MAX_SLOTS = 8, 4, 64
 HN_OP_WORDS, HN_CHUNK_UNITS, HN_DSRC_COMPS = 8, 32, 16
 HN_AUXG_MAX = 3
+HN_MAX_COMPS = 32
 
 HN_OP_LAYER, HN_OP_OUT, HN_OP_OUT_WIDE = 1, 4, 5
 HN_ACT_NONE, HN_ACT_RELU = 0, 1
 HN_LAYER_NO_COMMIT = 1
 HN_BOP_LOAD, HN_BOP_LOAD_WIDE, HN_BOP_LAYER, HN_BOP_AUX = 1, 2, 3, 4
-HN_FEAT_ZERO, HN_FEAT_ID, HN_FEAT_SIN, HN_FEAT_COS, HN_FEAT_SINP = 0, 1, 2, 3, 4
+HN_FEAT_ZERO, HN_FEAT_ID, HN_FEAT_SIN, HN_FEAT_COS, HN_FEAT_SINP, HN_FEAT_ID_DIRECT = 0, 1, 2, 3, 4, 5
 
 
 class HnSrc(C.Structure):
@@ -51,7 +52,7 @@ class HnMlpArgs(C.Structure):
         ("ops", C.c_void_p), ("wstream", C.c_void_p), ("bias", C.c_void_p), ("feat", C.c_void_p),
         ("stash", C.c_void_p), ("masks", C.c_void_p), ("dsrc", C.c_void_p),
         ("src", HnSrc * HN_MAX_SRC), ("dst", HnDst * HN_MAX_DST), ("slots", HnSlot * HN_MAX_SLOTS),
-        ("prof", C.c_void_p),
+        ("prof", C.c_void_p), ("comps", C.c_void_p), ("n_comps", C.c_int32), ("pad1", C.c_int32),
     ]
 
 

@@ -47,20 +47,38 @@ struct WStream {
 // ------------------------------------------------------------------------------------------------
 // generated input features
 // ------------------------------------------------------------------------------------------------
-HN_DEV HnSrc hn_src_select(const HnMlpArgs& a, int sid) {
-  HnSrc s = a.src[0];
-  if (sid == 1) s = a.src[1];
-  if (sid == 2) s = a.src[2];
-  if (sid == 3) s = a.src[3];
-  return s;
+// Per 32-point block the source components a program reads (HnMlpArgs.comps) are staged once into LDS
+// (srcv[ci][point]); a feature then costs two LDS reads (table entry, value) instead of a chain of global loads.
+HN_DEV void hn_stage_sources(float* srcv, const HnMlpArgs& a, int p, int ray, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  for (int ci = h; ci < a.n_comps; ci += 2) {
+    const int c = a.comps[ci];
+    const int sid = c >> 16, col = c & 0xffff;
+    const float* base = a.src[0].ptr;
+    int ld = a.src[0].ld, pr = a.src[0].per_ray;
+    if (sid == 1) { base = a.src[1].ptr; ld = a.src[1].ld; pr = a.src[1].per_ray; }
+    if (sid == 2) { base = a.src[2].ptr; ld = a.src[2].ld; pr = a.src[2].per_ray; }
+    if (sid == 3) { base = a.src[3].ptr; ld = a.src[3].ld; pr = a.src[3].per_ray; }
+    srcv[ci * 32 + r] = base[(size_t)(pr ? ray : p) * ld + col];
+  }
+}
+
+HN_DEV float hn_direct_source(const HnFeat e, const HnMlpArgs& a, int p, int ray) {
+  const int sid = (e.packed >> 8) & 15, col = (e.packed >> 24) & 255;
+  const float* base = a.src[0].ptr;
+  int ld = a.src[0].ld, pr = a.src[0].per_ray;
+  if (sid == 1) { base = a.src[1].ptr; ld = a.src[1].ld; pr = a.src[1].per_ray; }
+  if (sid == 2) { base = a.src[2].ptr; ld = a.src[2].ld; pr = a.src[2].per_ray; }
+  if (sid == 3) { base = a.src[3].ptr; ld = a.src[3].ld; pr = a.src[3].per_ray; }
+  return base[(size_t)(pr ? ray : p) * ld + col];
 }
 
 template <bool BF16>
-HN_DEV float hn_feature(const HnFeat e, const HnMlpArgs& a, int p, int ray) {
+HN_DEV float hn_feature(const HnFeat e, const float* srcv, int r, const HnMlpArgs& a, int p, int ray) {
   const int kind = (e.packed >> 12) & 15;
   if (kind == HN_FEAT_ZERO) return 0.0f;
-  const HnSrc s = hn_src_select(a, (e.packed >> 8) & 15);
-  const float x = s.ptr[(size_t)(s.per_ray ? ray : p) * s.ld + (e.packed & 255)];
+  if (kind == HN_FEAT_ID_DIRECT) return hn_direct_source(e, a, p, ray);
+  const float x = srcv[(e.packed & 255) * 32 + r];
   if (kind == HN_FEAT_ID) return x;
   float arg = __fmul_rn(e.freq, x);
   if (kind == HN_FEAT_SINP) arg = __fadd_rn(arg, 0.5f * 3.1415926f);
@@ -70,11 +88,10 @@ HN_DEV float hn_feature(const HnFeat e, const HnMlpArgs& a, int p, int ray) {
 
 // d value / d x  of a generated feature
 template <bool BF16>
-HN_DEV float hn_feature_grad(const HnFeat e, const HnMlpArgs& a, int p, int ray) {
+HN_DEV float hn_feature_grad(const HnFeat e, const float* srcv, int r) {
   const int kind = (e.packed >> 12) & 15;
-  if (kind == HN_FEAT_ID) return 1.0f;
-  const HnSrc s = hn_src_select(a, (e.packed >> 8) & 15);
-  const float x = s.ptr[(size_t)(s.per_ray ? ray : p) * s.ld + (e.packed & 255)];
+  if (kind == HN_FEAT_ID || kind == HN_FEAT_ID_DIRECT) return 1.0f;
+  const float x = srcv[(e.packed & 255) * 32 + r];
   float arg = __fmul_rn(e.freq, x);
   if (kind == HN_FEAT_SINP) arg = __fadd_rn(arg, 0.5f * 3.1415926f);
   if (kind == HN_FEAT_COS) return -e.freq * (BF16 ? __sinf(arg) : sinf(arg));
@@ -82,23 +99,24 @@ HN_DEV float hn_feature_grad(const HnFeat e, const HnMlpArgs& a, int p, int ray)
 }
 
 // fragments of one group of 64 generated features (invalid points -> zeros)
-HN_DEV void hn_make_group(bf16x8* out, const HnFeat* ft, const HnMlpArgs& a, int p, int ray, bool valid, int lane) {
-  const int h = lane >> 5;
+HN_DEV void hn_make_group(bf16x8* out, const HnFeat* ft, const float* srcv, bool valid, int lane,
+                          const HnMlpArgs& a, int p, int ray) {
+  const int h = lane >> 5, r = lane & 31;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float v = hn_feature<true>(ft[16 * s + hn_pi16(h, j)], a, p, ray);
+      const float v = hn_feature<true>(ft[16 * s + hn_pi16(h, j)], srcv, r, a, p, ray);
       out[s][j] = (__bf16)(valid ? v : 0.0f);
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
-HN_DEV void hn_make_group(float* out, const HnFeat* ft, const HnMlpArgs& a, int p, int ray, bool valid, int lane) {
-  const int h = lane >> 5;
+HN_DEV void hn_make_group(float* out, const HnFeat* ft, const float* srcv, bool valid, int lane,
+                          const HnMlpArgs& a, int p, int ray) {
+  const int h = lane >> 5, r = lane & 31;
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
-    const float v = hn_feature<false>(ft[32 * (s >> 4) + hn_rho(s & 15, h)], a, p, ray);
+    const float v = hn_feature<false>(ft[32 * (s >> 4) + hn_rho(s & 15, h)], srcv, r, a, p, ray);
     out[s] = valid ? v : 0.0f;
     if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
@@ -172,6 +190,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   // biases and the feature table live in LDS for the whole kernel: no global loads inside the MFMA loops
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * HN_CHUNK_UNITS * 1024);
   HnFeat* feat_lds = reinterpret_cast<HnFeat*>(bias_lds + ((a.n_bias + 3) & ~3));
+  float* srcv = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (HN_MAX_COMPS * 32);
   for (int i = threadIdx.x; i < a.n_bias; i += blockDim.x) bias_lds[i] = a.bias[i];
   for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
   __syncthreads();
@@ -183,6 +202,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
     const int p = valid ? p0 : a.n_points - 1;
     const int ray = p / a.samples_per_ray;
     const bool wave_valid = blk * 32 < a.n_points;  // wave-uniform: the block holds at least one point
+    hn_stage_sources(srcv, a, p, ray, lane);
     ws.start();
 
     for (int op = 0; op < a.n_ops; ++op) {
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
         for (int g = 0; g < HN_AUXG_MAX; ++g) {
           if (g < nG) {
-            hn_make_group(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, a, p, ray, valid, lane);
+            hn_make_group(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, srcv, valid, lane, a, p, ray);
             if (a.training && w[6] >= 0 && wave_valid) {
               hn_stash<BF16>(aux + g * 2 * M::STEPS32, a, w[6], blk, 2 * g, lane);
               hn_stash<BF16>(aux + (g * 2 + 1) * M::STEPS32, a, w[6], blk, 2 * g + 1, lane);
@@ -304,6 +324,8 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   const int ntiles = (a.n_points + PTS - 1) / PTS;
   HnFeat* feat_lds = reinterpret_cast<HnFeat*>(smem + 2 * HN_CHUNK_UNITS * 1024);
   float* dsrc_lds = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (32 * HN_DSRC_COMPS);
+  float* srcv = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + M::WAVES * (32 * HN_DSRC_COMPS) +
+                wave * (HN_MAX_COMPS * 32);
   for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
   __syncthreads();
 
@@ -326,6 +348,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
     const int ray = p / a.samples_per_ray;
     const bool wave_valid = blk * 32 < a.n_points;
     for (int i = lane; i < 32 * HN_DSRC_COMPS; i += 64) dsrc_lds[i] = 0.0f;
+    hn_stage_sources(srcv, a, p, ray, lane);
     ws.start();
 
     for (int op = 0; op < a.n_ops; ++op) {
@@ -436,7 +459,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             const HnFeat e = ft[hn_rho(i, h)];
             const int slot = ((e.packed >> 16) & 255) - 1;
             if (slot >= 0 && valid)
-              atomicAdd(dsrc_lds + r * HN_DSRC_COMPS + slot, acc[i] * hn_feature_grad<BF16>(e, a, p, ray));
+              atomicAdd(dsrc_lds + r * HN_DSRC_COMPS + slot, acc[i] * hn_feature_grad<BF16>(e, srcv, r));
           }
         }
       }
@@ -755,7 +778,8 @@ static int hn_check_args(const HnMlpArgs* a) {
   if (a->ops == nullptr || a->wstream == nullptr) return -3;
   if (a->mode != HN_MODE_BF16 && a->mode != HN_MODE_F32) return -4;
   if (a->n_dsrc < 0 || a->n_dsrc > HN_DSRC_COMPS) return -5;
-  if (a->n_bias < 0 || a->n_feat < 0) return -5;
+  if (a->n_bias < 0 || a->n_feat < 0 || a->n_comps < 0 || a->n_comps > HN_MAX_COMPS) return -5;
+  if (a->n_comps > 0 && a->comps == nullptr) return -3;
   return 0;
 }
 
@@ -763,7 +787,8 @@ extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
   int rc = hn_check_args(a);
   if (rc) return rc;
   hn_allow_big_lds();
-  const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + (size_t)((a->n_bias + 3) & ~3) * 4 + (size_t)a->n_feat * 8;
+  const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + (size_t)((a->n_bias + 3) & ~3) * 4 +
+                     (size_t)((a->n_feat + 1) & ~1) * 8 + 8 * HN_MAX_COMPS * 32 * 4;
   if (lds > 150 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
     hipLaunchKernelGGL(hn_mlp_fwd_kernel<true>, dim3(hn_grid_for(a->n_points, 256)), dim3(512), lds,
@@ -783,11 +808,11 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
   const size_t flds = (size_t)((a->n_feat + 1) & ~1) * 8;
   if (flds > 64 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
-    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 8 * 32 * HN_DSRC_COMPS * 4;
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 8 * 32 * HN_DSRC_COMPS * 4 + 8 * HN_MAX_COMPS * 32 * 4;
     hipLaunchKernelGGL(hn_mlp_bwd_kernel<true>, dim3(hn_grid_for(a->n_points, 256)), dim3(512), lds,
                        (hipStream_t)stream, *a);
   } else {
-    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 4 * 32 * HN_DSRC_COMPS * 4;
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 4 * 32 * HN_DSRC_COMPS * 4 + 4 * HN_MAX_COMPS * 32 * 4;
     hipLaunchKernelGGL(hn_mlp_bwd_kernel<false>, dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
                        (hipStream_t)stream, *a);
   }

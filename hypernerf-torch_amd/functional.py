@@ -47,6 +47,7 @@ class ProgramCall:
         self.src_per_ray = list(src_per_ray)
         self.dst_widths = list(dst_widths)
         self.grad_srcs = list(grad_srcs)
+        self.cache = {}
 
 
 class _ProgramFn(torch.autograd.Function):
@@ -108,12 +109,18 @@ class _ProgramFn(torch.autograd.Function):
             width = shp[-1]
             if call.src_per_ray[i]:
                 n_rays = ctx.n_points // ctx.spr
-                g = torch.zeros(n_rays, width, dtype=torch.float32, device=dsrc.device)
-                sum_samples_into(dsrc, cols, n_rays, ctx.spr, g)
+                g = sum_samples(dsrc, cols, n_rays, ctx.spr, width)
             else:
-                g = torch.zeros(ctx.n_points, width, dtype=torch.float32, device=dsrc.device)
-                for c, s in cols.items():
-                    g[:, c] = dsrc[:, s]
+                key = ("colidx", i)
+                idx = call.cache.get(key)
+                if idx is None:
+                    idx = torch.tensor([cols.get(c, 0) for c in range(width)], dtype=torch.int64, device=dsrc.device)
+                    mask = torch.tensor([1.0 if c in cols else 0.0 for c in range(width)], device=dsrc.device)
+                    idx = (idx, None if all(c in cols for c in range(width)) else mask)
+                    call.cache[key] = idx
+                g = dsrc.index_select(1, idx[0])          # one gather instead of a copy kernel per column
+                if idx[1] is not None:
+                    g = g * idx[1]
             src_grads.append(g.view(shp))
         pgrads = call.runner.split_grads(flat)
         n_par = len(prog.params)
@@ -132,24 +139,29 @@ def run_program(call: ProgramCall, srcs: Sequence[Optional[torch.Tensor]], sampl
     return _ProgramFn.apply(call, mode_of(precision), int(samples_per_ray), len(srcs), training, *srcs, *params)
 
 
-def sum_samples_into(d_points: torch.Tensor, cols: Dict[int, int], n_rays: int, n_samples: int, out: torch.Tensor):
-    """out[b, c] += sum_s d_points[b*S + s, slot]  for every (c -> slot) — HIP reduction kernel.
-    Consecutive (c, slot) pairs are reduced by one launch."""
+def sum_samples(d_points: torch.Tensor, cols: Dict[int, int], n_rays: int, n_samples: int, width: int):
+    """(n_rays, width) with out[b, c] = sum_s d_points[b*S + s, slot(c)] — HIP reduction kernel, one launch per
+    run of consecutive (column, slot) pairs (the 8 GLO components are one run)."""
     L.load()
-    idx = torch.arange(n_rays, dtype=torch.int64, device=out.device)
+    idx = torch.arange(n_rays, dtype=torch.int64, device=d_points.device)
     items = sorted(cols.items())
+    out = None
     i = 0
     while i < len(items):
         j = i
         while j + 1 < len(items) and items[j + 1][0] == items[j][0] + 1 and items[j + 1][1] == items[j][1] + 1:
             j += 1
         c0, s0, run = items[i][0], items[i][1], j - i + 1
-        tmp = torch.zeros(n_rays, run, dtype=torch.float32, device=out.device)
+        tmp = torch.zeros(n_rays, run, dtype=torch.float32, device=d_points.device)
         L.launch("hn_embed_backward", L.ptr(d_points), C.c_int(d_points.shape[1]), C.c_int(s0), L.ptr(idx),
-                                      C.c_int(n_rays), C.c_int(n_samples), C.c_int(run), C.c_int(n_rays), L.ptr(tmp),
-                                      L.stream_handle())
-        out[:, c0:c0 + run] += tmp
+                 C.c_int(n_rays), C.c_int(n_samples), C.c_int(run), C.c_int(n_rays), L.ptr(tmp), L.stream_handle())
+        if run == width:
+            return tmp
+        if out is None:
+            out = torch.zeros(n_rays, width, dtype=torch.float32, device=d_points.device)
+        out[:, c0:c0 + run] = tmp
         i = j + 1
+    return out if out is not None else torch.zeros(n_rays, width, dtype=torch.float32, device=d_points.device)
 
 
 # --------------------------------------------------------------------------------------------

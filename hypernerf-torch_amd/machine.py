@@ -150,6 +150,7 @@ class Program:
         self.slots: List[SlotInfo] = []
         self.feat_table: List[Feature] = []
         self.dsrc_map: Dict[Tuple[int, int], int] = {}
+        self.comp_map: Dict[Tuple[int, int], int] = {}     # (src, column) -> staged component index
         self.bias_len = 0
         self._link()
         self.fwd_ops = self._build_fwd_ops()
@@ -197,6 +198,14 @@ class Program:
                     self.feat_table += list(ly.aux.feats) + [Feature(0, 0, L.HN_FEAT_ZERO)] * pad
                     ly.aux.slot = self._new_slot("stash", 2 * ly.aux.groups)
                     for ft in ly.aux.feats:
+                        if ft.kind != L.HN_FEAT_ZERO and (ft.src, ft.comp) not in self.comp_map:
+                            # staged in LDS while there is room; trigonometric features always are; surplus
+                            # identity features (wide raw inputs of stand-alone modules) are read directly
+                            if len(self.comp_map) < L.HN_MAX_COMPS:
+                                self.comp_map[(ft.src, ft.comp)] = len(self.comp_map)
+                            elif ft.kind != L.HN_FEAT_ID or ft.comp > 255:
+                                raise NotImplementedError(
+                                    f"{ly.name}: more than {L.HN_MAX_COMPS} distinct encoded source components")
                         if ft.need_grad and (ft.src, ft.comp) not in self.dsrc_map:
                             self.dsrc_map[(ft.src, ft.comp)] = len(self.dsrc_map)
             if ly.main is None and ly.aux is None:
@@ -208,6 +217,7 @@ class Program:
                 cur = ly
         if len(self.dsrc_map) > L.HN_DSRC_COMPS:
             raise NotImplementedError(f"{self.name}: more than {L.HN_DSRC_COMPS} source-gradient components")
+
         consumers = {id(l.prev) for l in self.layers if l.prev is not None}
         for ly in self.layers:
             ly.dz_slot = self._new_slot("stash", ly.nt)
@@ -396,9 +406,16 @@ class Program:
         feat = np.zeros(max(1, len(self.feat_table)), dtype=L.FEAT_DT)
         for i, f in enumerate(self.feat_table):
             slot = self.dsrc_map.get((f.src, f.comp), -1) + 1 if f.need_grad else 0
-            feat[i] = (f.comp | f.src << 8 | f.kind << 12 | slot << 16, np.float32(f.freq))
+            if f.kind != L.HN_FEAT_ZERO and (f.src, f.comp) not in self.comp_map:
+                feat[i] = (f.src << 8 | L.HN_FEAT_ID_DIRECT << 12 | slot << 16 | f.comp << 24, np.float32(f.freq))
+                continue
+            ci = self.comp_map.get((f.src, f.comp), 0)
+            feat[i] = (ci | f.kind << 12 | slot << 16, np.float32(f.freq))
+        comps = np.zeros(max(1, len(self.comp_map)), dtype=np.int32)
+        for (src, col), ci in self.comp_map.items():
+            comps[ci] = src << 16 | col
         t = dict(fwd_units=fwd_units, fwd_chunks=fwd_chunks, bwd_units=bwd_units, bwd_chunks=bwd_chunks,
-                 bias=bias, feat=feat)
+                 bias=bias, feat=feat, comps=comps)
         self.tables[mode] = t
         return t
 
@@ -431,7 +448,7 @@ class Program:
             return 1, min(8, max(1, n_kt)) if n_kt <= 8 else 8
         return 2, 4
 
-    def wgrad_jobs(self, mode: int, n_points: int, target_jobs: int = 256) -> np.ndarray:
+    def wgrad_jobs(self, mode: int, n_points: int, target_jobs: int = 512) -> np.ndarray:
         """One job per (layer input segment, tile rectangle, block chunk).  The chunks are sized so that the
         launch is about `target_jobs` workgroups of equal stash bytes (one per CU, a single round)."""
         offs, _, _ = self.layout(mode, n_points)
@@ -463,13 +480,16 @@ class Program:
         for (ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias) in rects:
             gn, gk = self._wave_grid(n_nt, n_kt)
             bps = max(1, stage_tiles // (n_nt + n_kt))
-            share = max(1, round(target_jobs * (n_nt + n_kt) / total_tiles))
-            per = max(bps, -(-nblk // share))
-            per = -(-per // bps) * bps                       # whole stages
-            for b0 in range(0, nblk, per):
-                jobs.append((z_off, x_off, ly.nt, x_nt, nt0, kt0, n_nt, n_kt, b0, min(nblk, b0 + per),
-                             goffs[ly.w_id], ly.weight.shape[1], 32 * nt0, c0 + 32 * kt0, ly.n_out, c0 + ncols,
-                             goffs[ly.b_id] if with_bias else -1, gn | gk << 8 | bps << 16))
+            nstage = -(-nblk // bps)
+            share = max(1, min(nstage, round(target_jobs * (n_nt + n_kt) / total_tiles)))
+            # split the stages as evenly as possible over `share` jobs
+            bounds = [min(nblk, (i * nstage // share) * bps) for i in range(share + 1)]
+            bounds[-1] = nblk
+            for b0, b1 in zip(bounds[:-1], bounds[1:]):
+                if b1 > b0:
+                    jobs.append((z_off, x_off, ly.nt, x_nt, nt0, kt0, n_nt, n_kt, b0, b1,
+                                 goffs[ly.w_id], ly.weight.shape[1], 32 * nt0, c0 + 32 * kt0, ly.n_out, c0 + ncols,
+                                 goffs[ly.b_id] if with_bias else -1, gn | gk << 8 | bps << 16))
         # heaviest jobs first: the tail of the launch is then made of short jobs
         jobs.sort(key=lambda j: -(j[6] + j[7]) * (j[9] - j[8]))
         arr = np.zeros(len(jobs), dtype=L.DWJOB_DT)
@@ -506,6 +526,7 @@ class MlpRunner:
             d.bias_desc = L.to_device_bytes(ht["bias"], device)
             d.n_bias = len(ht["bias"])
             d.feat = L.to_device_bytes(ht["feat"], device)
+            d.comps = L.to_device_bytes(ht["comps"], device)
             d.fwd_ops = L.to_device_bytes(self.prog.fwd_ops, device)
             d.bwd_ops = L.to_device_bytes(self.prog.bwd_ops, device)
             d.wstream = torch.empty(d.n_units * 1024, dtype=torch.uint8, device=device)
@@ -544,6 +565,7 @@ class MlpRunner:
         a.ops, a.wstream, a.bias, a.feat = ops.data_ptr(), wstream_ptr, d.bias.data_ptr(), d.feat.data_ptr()
         a.n_bias, a.n_feat = max(32, self.prog.bias_len), max(1, len(self.prog.feat_table))
         a.prof = L.PROF_BUFFER.data_ptr() if L.PROF_BUFFER is not None else 0
+        a.comps, a.n_comps = d.comps.data_ptr(), len(self.prog.comp_map)
         a.stash = stash.data_ptr() if stash is not None else 0
         a.masks = masks.data_ptr() if masks is not None else 0
         a.dsrc = dsrc.data_ptr() if dsrc is not None else 0

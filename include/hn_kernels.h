@@ -75,11 +75,16 @@ typedef void* hnStream_t; /* hipStream_t */
  * source-gradient accumulators (LDS), written to `dsrc` at the end of the program.               */
 #define HN_BOP_AUX 4       /* w1 = K32 | K32b<<8 | nG<<16 ; w3=feat_off                            */
 
-/* feature table entry (8 bytes).  value(p) = kind(freq * x[src][p or ray(p)][comp]) */
+/* feature table entry (8 bytes).  value(p) = kind(freq * x), x = staged source component `ci` of point p.
+ * The distinct (source, column) pairs a program reads are listed once in HnMlpArgs.comps; every workgroup
+ * stages them per 32-point block into LDS, so evaluating a feature costs two LDS reads and no global load. */
 typedef struct {
-  int32_t packed; /* bits 0-7 comp | 8-11 src | 12-15 kind | 16-23 grad slot + 1 (0 = no gradient) */
+  int32_t packed; /* bits 0-7 ci (index into comps) | 12-15 kind | 16-23 grad slot + 1 (0 = no gradient) */
   float freq;
 } HnFeat;
+#define HN_MAX_COMPS 32 /* staged source components per program */
+#define HN_FEAT_ID_DIRECT 5 /* identity feature read straight from global memory: src in bits 8-11, column in
+                               bits 24-31 (stand-alone modules with > HN_MAX_COMPS raw input channels) */
 #define HN_FEAT_ZERO 0
 #define HN_FEAT_ID 1
 #define HN_FEAT_SIN 2  /* sin(freq*x)                                                        */
@@ -132,6 +137,9 @@ typedef struct {
   HnDst dst[HN_MAX_DST];
   HnSlot slots[HN_MAX_SLOTS];
   uint64_t* prof;        /* diagnostic only (NULL in production): 8 shader-clock sums, see tools/ */
+  const int32_t* comps;  /* device, n_comps entries: src << 16 | column */
+  int32_t n_comps;
+  int32_t pad1;
 } HnMlpArgs;
 
 /* weight packing: one descriptor per 1-KiB unit of a stream */

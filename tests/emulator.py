@@ -158,14 +158,24 @@ def store_tile(mode, z):
 
 
 # ---- features ---------------------------------------------------------------------------------------
+COMPS = None     # staged component table of the program under emulation (src << 16 | column)
+
+
+def _source_value(e, srcs, p, ray):
+    if ((e["packed"] >> 12) & 15) == 5:      # HN_FEAT_ID_DIRECT
+        arr, per_ray = srcs[(e["packed"] >> 8) & 15]
+        return arr[ray if per_ray else p, (int(e["packed"]) >> 24) & 255]
+    c = int(COMPS[e["packed"] & 255])
+    arr, per_ray = srcs[c >> 16]
+    return arr[ray if per_ray else p, c & 0xffff]
+
+
 def feature_value(e, srcs, p, ray):
     kind = (e["packed"] >> 12) & 15
     if kind == 0:
         return 0.0
-    sid, comp = (e["packed"] >> 8) & 15, e["packed"] & 255
-    arr, per_ray = srcs[sid]
-    x = arr[ray if per_ray else p, comp]
-    if kind == 1:
+    x = _source_value(e, srcs, p, ray)
+    if kind in (1, 5):
         return x
     arg = e["freq"] * x
     if kind == 4:
@@ -175,11 +185,9 @@ def feature_value(e, srcs, p, ray):
 
 def feature_grad(e, srcs, p, ray):
     kind = (e["packed"] >> 12) & 15
-    if kind == 1:
+    if kind in (1, 5):
         return 1.0
-    sid, comp = (e["packed"] >> 8) & 15, e["packed"] & 255
-    arr, per_ray = srcs[sid]
-    x = arr[ray if per_ray else p, comp]
+    x = _source_value(e, srcs, p, ray)
     arg = e["freq"] * x
     if kind == 4:
         arg = arg + 0.5 * 3.1415926
@@ -235,6 +243,8 @@ def bias_acc(bias, off, t):
 
 
 def run_forward(prog, mode, tables, params, srcs, n_points, spr, dst_widths, training=True):
+    global COMPS
+    COMPS = tables["comps"]
     units = pack_units(mode, tables["fwd_units"], params)
     bias = pack_bias(tables["bias"], params, prog.bias_len)
     feat = tables["feat"]
@@ -318,6 +328,8 @@ def run_forward(prog, mode, tables, params, srcs, n_points, spr, dst_widths, tra
 
 
 def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
+    global COMPS
+    COMPS = tables["comps"]
     units = pack_units(mode, tables["bwd_units"], params)
     feat = tables["feat"]
     dsrc = np.zeros((n_points, max(1, prog.n_dsrc)))

@@ -139,3 +139,29 @@ def test_wide_output_mlp_emulated(bf16):
     jobs = prog.wgrad_jobs(1 if bf16 else 0, n)
     _, gtot = prog.grad_offsets()
     check_grads(prog, E.run_wgrad(prog, mode, jobs, stash, gtot), tp, dict(m.named_parameters()))
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+def test_wide_raw_input_direct_features_emulated(bf16):
+    """> HN_MAX_COMPS raw input channels: the surplus identity features are read directly (HN_FEAT_ID_DIRECT)."""
+    m = modules.MLP(in_ch=45, out_ch=3, depth=2, width=32, skips=[7])
+    sd = load_hash(m, 13)
+    n = 40
+    x = H.uniform(7, "x", (n, 45), -1, 1).double()
+    call = m._call(False)
+    prog = call.program
+    assert len(prog.comp_map) == 32
+    mode = E.Mode(bf16)
+    tables = prog.host_tables(1 if bf16 else 0)
+    params = np_params(prog)
+    srcs = [(x.numpy(), False), None, None, None]
+    outs, stash = E.run_forward(prog, mode, tables, params, srcs, n, 1, [3])
+    tp = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y = O.mlp({"m." + k: v for k, v in tp.items()}, "m", x, depth=2, skips=(7,))
+    np.testing.assert_allclose(outs[0], y.detach().numpy(), rtol=1e-9, atol=1e-11)
+    g = H.uniform(8, "g", (n, 3), -1, 1).double()
+    (y * g).sum().backward()
+    E.run_backward(prog, mode, tables, params, srcs + [(g.numpy(), False), (outs[0], False)], n, 1, stash)
+    jobs = prog.wgrad_jobs(1 if bf16 else 0, n)
+    _, gtot = prog.grad_offsets()
+    check_grads(prog, E.run_wgrad(prog, mode, jobs, stash, gtot), tp, dict(m.named_parameters()))
