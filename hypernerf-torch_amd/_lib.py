@@ -21,13 +21,13 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "hn_kernels.h")
 
 HN_MODE_F32, HN_MODE_BF16 = 0, 1
 HN_MAX_SRC, HN_MAX_DST, HN_MAX_SLOTS = 8, 4, 64
-HN_OP_WORDS, HN_CHUNK_UNITS, HN_DSRC_COMPS = 8, 32, 16
+HN_OP_WORDS, HN_CHUNK_UNITS, HN_DSRC_COMPS = 8, int(os.environ.get("HN_CHUNK_UNITS", 32)), 16
 HN_AUXG_MAX = 3
 HN_MAX_COMPS = 32
 
 HN_OP_LAYER, HN_OP_OUT, HN_OP_OUT_WIDE = 1, 4, 5
 HN_ACT_NONE, HN_ACT_RELU = 0, 1
-HN_LAYER_NO_COMMIT = 1
+HN_LAYER_NO_COMMIT, HN_LAYER_DIRECT = 1, 2
 HN_BOP_LOAD, HN_BOP_LOAD_WIDE, HN_BOP_LAYER, HN_BOP_AUX = 1, 2, 3, 4
 HN_FEAT_ZERO, HN_FEAT_ID, HN_FEAT_SIN, HN_FEAT_COS, HN_FEAT_SINP, HN_FEAT_ID_DIRECT = 0, 1, 2, 3, 4, 5
 
@@ -111,7 +111,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
            "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    for macro in ("HN_BF16_WAVES", "HN_PROF"):          # build-time tuning knobs (A/B experiments)
+    for macro in ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS"):          # build-time tuning knobs (A/B experiments)
         if os.environ.get(macro):
             cmd.insert(1, f"-D{macro}={os.environ[macro]}")
     res = subprocess.run(cmd, capture_output=True, text=True)

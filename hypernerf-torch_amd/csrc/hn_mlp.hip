@@ -73,51 +73,72 @@ HN_DEV float hn_direct_source(const HnFeat e, const HnMlpArgs& a, int p, int ray
   return base[(size_t)(pr ? ray : p) * ld + col];
 }
 
-template <bool BF16>
+// sin(2*pi*t): one v_fract + one v_sin, any magnitude of t
+HN_DEV float hn_sin_rev(float t) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t)); }
+#define HN_INV_2PI 0.15915494309189535f
+
+// bf16 mode evaluates every trigonometric kind with ONE transcendental and no branch:
+//   sin(f x) = sin_rev(f x / 2pi), cos(f x) = sin(f x + pi/2) = sin_rev(f x / 2pi + 1/4)
+// fp32 (parity) mode calls the precise sinf/cosf the reference's CPU path uses.
+// DIRECT: the program holds identity features read straight from global memory (HN_LAYER_DIRECT).
+template <bool BF16, bool DIRECT>
 HN_DEV float hn_feature(const HnFeat e, const float* srcv, int r, const HnMlpArgs& a, int p, int ray) {
   const int kind = (e.packed >> 12) & 15;
-  if (kind == HN_FEAT_ZERO) return 0.0f;
-  if (kind == HN_FEAT_ID_DIRECT) return hn_direct_source(e, a, p, ray);
+  if constexpr (DIRECT) {
+    if (kind == HN_FEAT_ID_DIRECT) return hn_direct_source(e, a, p, ray);
+  }
   const float x = srcv[(e.packed & 255) * 32 + r];
-  if (kind == HN_FEAT_ID) return x;
-  float arg = __fmul_rn(e.freq, x);
-  if (kind == HN_FEAT_SINP) arg = __fadd_rn(arg, 0.5f * 3.1415926f);
-  if (BF16) return kind == HN_FEAT_COS ? __cosf(arg) : __sinf(arg);
-  return kind == HN_FEAT_COS ? cosf(arg) : sinf(arg);
+  if constexpr (BF16) {
+    const float ph = (kind == HN_FEAT_COS || kind == HN_FEAT_SINP) ? 0.25f : 0.0f;
+    const float s = hn_sin_rev(__builtin_fmaf(e.freq * HN_INV_2PI, x, ph));
+    return kind == HN_FEAT_ID ? x : (kind == HN_FEAT_ZERO ? 0.0f : s);
+  } else {
+    if (kind == HN_FEAT_ZERO) return 0.0f;
+    if (kind == HN_FEAT_ID) return x;
+    float arg = __fmul_rn(e.freq, x);
+    if (kind == HN_FEAT_SINP) arg = __fadd_rn(arg, 0.5f * 3.1415926f);
+    return kind == HN_FEAT_COS ? cosf(arg) : sinf(arg);
+  }
 }
 
 // d value / d x  of a generated feature
 template <bool BF16>
 HN_DEV float hn_feature_grad(const HnFeat e, const float* srcv, int r) {
   const int kind = (e.packed >> 12) & 15;
-  if (kind == HN_FEAT_ID || kind == HN_FEAT_ID_DIRECT) return 1.0f;
   const float x = srcv[(e.packed & 255) * 32 + r];
-  float arg = __fmul_rn(e.freq, x);
-  if (kind == HN_FEAT_SINP) arg = __fadd_rn(arg, 0.5f * 3.1415926f);
-  if (kind == HN_FEAT_COS) return -e.freq * (BF16 ? __sinf(arg) : sinf(arg));
-  return e.freq * (BF16 ? __cosf(arg) : cosf(arg));
+  if constexpr (BF16) {
+    // d sin(f x) = f sin_rev(t + 1/4) ; d cos(f x) = d sin(f x + pi/2) = f sin_rev(t + 1/2)
+    const float ph = (kind == HN_FEAT_COS || kind == HN_FEAT_SINP) ? 0.5f : 0.25f;
+    const float g = e.freq * hn_sin_rev(__builtin_fmaf(e.freq * HN_INV_2PI, x, ph));
+    return (kind == HN_FEAT_ID || kind == HN_FEAT_ID_DIRECT) ? 1.0f : g;
+  } else {
+    if (kind == HN_FEAT_ID || kind == HN_FEAT_ID_DIRECT) return 1.0f;
+    float arg = __fmul_rn(e.freq, x);
+    if (kind == HN_FEAT_SINP) arg = __fadd_rn(arg, 0.5f * 3.1415926f);
+    if (kind == HN_FEAT_COS) return -e.freq * sinf(arg);
+    return e.freq * cosf(arg);
+  }
 }
 
-// fragments of one group of 64 generated features (invalid points -> zeros)
-HN_DEV void hn_make_group(bf16x8* out, const HnFeat* ft, const float* srcv, bool valid, int lane,
-                          const HnMlpArgs& a, int p, int ray) {
+// fragments of one group of 64 generated features
+template <bool DIRECT>
+HN_DEV void hn_make_group(bf16x8* out, const HnFeat* ft, const float* srcv, int lane, const HnMlpArgs& a, int p,
+                          int ray) {
   const int h = lane >> 5, r = lane & 31;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = hn_feature<true>(ft[16 * s + hn_pi16(h, j)], srcv, r, a, p, ray);
-      out[s][j] = (__bf16)(valid ? v : 0.0f);
-    }
+    for (int j = 0; j < 8; ++j)
+      out[s][j] = (__bf16)hn_feature<true, DIRECT>(ft[16 * s + hn_pi16(h, j)], srcv, r, a, p, ray);
   }
 }
-HN_DEV void hn_make_group(float* out, const HnFeat* ft, const float* srcv, bool valid, int lane,
-                          const HnMlpArgs& a, int p, int ray) {
+template <bool DIRECT>
+HN_DEV void hn_make_group(float* out, const HnFeat* ft, const float* srcv, int lane, const HnMlpArgs& a, int p,
+                          int ray) {
   const int h = lane >> 5, r = lane & 31;
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
-    const float v = hn_feature<false>(ft[32 * (s >> 4) + hn_rho(s & 15, h)], srcv, r, a, p, ray);
-    out[s] = valid ? v : 0.0f;
+    out[s] = hn_feature<false, DIRECT>(ft[32 * (s >> 4) + hn_rho(s & 15, h)], srcv, r, a, p, ray);
     if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -160,6 +181,17 @@ HN_DEV void hn_stash(const typename ModeT<BF16>::Frag* fr, const HnMlpArgs& a, i
   hn_store_tile(z, base, lane, (typename M::Frag*)nullptr);
 }
 
+// ReLU masks: one 32-bit word per lane and PAIR of tiles; element i of tile (2d + q) is bit 31 - (16 q + i), and a
+// set bit means "gradient dropped".  bf16 mode shifts in the sign bit of the pre-activation (one v_alignbit), fp32
+// (parity) mode the exact reference predicate !(x > 0).
+template <bool BF16>
+HN_DEV unsigned hn_push_mask(unsigned bits, float x) {
+  if constexpr (BF16) return __builtin_amdgcn_alignbit(bits, __float_as_uint(x), 31);
+  return (bits << 1) | (x > 0.0f ? 0u : 1u);
+}
+// all-ones where element (q, i) of the mask word is kept, zero where it is dropped
+HN_DEV int hn_keep_mask(unsigned nbits, int q, int i) { return (int)(nbits << (16 * q + i)) >> 31; }
+
 constexpr int HN_AUXG_MAX = 3;  // generated-feature groups per layer (192 features)
 
 // ------------------------------------------------------------------------------------------------
@@ -190,7 +222,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   // biases and the feature table live in LDS for the whole kernel: no global loads inside the MFMA loops
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * HN_CHUNK_UNITS * 1024);
   HnFeat* feat_lds = reinterpret_cast<HnFeat*>(bias_lds + ((a.n_bias + 3) & ~3));
-  float* srcv = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (HN_MAX_COMPS * 32);
+  float* srcv = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (a.n_comps * 32);
   for (int i = threadIdx.x; i < a.n_bias; i += blockDim.x) bias_lds[i] = a.bias[i];
   for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
   __syncthreads();
@@ -218,7 +250,10 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
         for (int g = 0; g < HN_AUXG_MAX; ++g) {
           if (g < nG) {
-            hn_make_group(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, srcv, valid, lane, a, p, ray);
+            if (flags & HN_LAYER_DIRECT)
+              hn_make_group<true>(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, srcv, lane, a, p, ray);
+            else
+              hn_make_group<false>(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, srcv, lane, a, p, ray);
             if (a.training && w[6] >= 0 && wave_valid) {
               hn_stash<BF16>(aux + g * 2 * M::STEPS32, a, w[6], blk, 2 * g, lane);
               hn_stash<BF16>(aux + (g * 2 + 1) * M::STEPS32, a, w[6], blk, 2 * g + 1, lane);
@@ -236,20 +271,19 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             for (int g = 0; g < HN_AUXG_MAX; ++g)
               if (g < nG) hn_gemm_blocks<BF16, 2>(acc, aux + g * 2 * M::STEPS32, ws);
             accL = acc;
+            if (act == HN_ACT_RELU) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const bool pos = acc[i] > 0.0f;
-              bits |= (pos ? 1u : 0u) << (16 * (t & 1) + i);
-              float x = acc[i];
-              if (act == HN_ACT_RELU) x = pos ? x : 0.0f;
-              acc[i] = valid ? x : 0.0f;
+              for (int i = 0; i < 16; ++i) {
+                bits = hn_push_mask<BF16>(bits, acc[i]);
+                acc[i] = __int_as_float(max(__float_as_int(acc[i]), 0));  // relu on the bit pattern: one v_max_i32
+              }
             }
             hn_acc_to_frags(acc, nxt + t * M::STEPS32);
             if ((t & 1) || t == NT - 1) {
               if (do_mask) {
                 const HnSlot sl = a.slots[w[4]];
                 uint32_t* mp = a.masks + sl.off / 4 + ((size_t)blk * sl.nt + (t >> 1)) * 64 + lane;
-                __builtin_nontemporal_store(bits, mp);
+                __builtin_nontemporal_store((t & 1) ? bits : bits << 16, mp);
               }
               bits = 0;
             }
@@ -325,7 +359,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   HnFeat* feat_lds = reinterpret_cast<HnFeat*>(smem + 2 * HN_CHUNK_UNITS * 1024);
   float* dsrc_lds = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (32 * HN_DSRC_COMPS);
   float* srcv = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + M::WAVES * (32 * HN_DSRC_COMPS) +
-                wave * (HN_MAX_COMPS * 32);
+                wave * (a.n_comps * 32);
   for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
   __syncthreads();
 
@@ -391,19 +425,19 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
       } else if (code == HN_BOP_LOAD_WIDE) {
         const int n = w[3], NT = w[4];
         const HnSrc s = a.src[w[1]];
-        unsigned bits = 0xffffffffu;
+        unsigned nbits = 0xffffffffu;  // complement of the mask word: set = keep
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           if (t < NT) {
             if (w[5] >= 0 && !(t & 1)) {  // output activation was relu: dZ = dY * relu'
               const HnSlot sl = a.slots[w[5]];
-              bits = wave_valid ? a.masks[sl.off / 4 + ((size_t)blk * sl.nt + (t >> 1)) * 64 + lane] : 0u;
+              nbits = wave_valid ? ~a.masks[sl.off / 4 + ((size_t)blk * sl.nt + (t >> 1)) * 64 + lane] : 0u;
             }
             f32x16 v;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               const int row = 32 * t + hn_rho(i, h);
-              const bool keep = ((bits >> (16 * (t & 1) + i)) & 1u) != 0u;
+              const bool keep = hn_keep_mask(nbits, t & 1, i) != 0;
               v[i] = (valid && keep && row < n) ? s.ptr[(size_t)p * s.ld + w[2] + row] : 0.0f;
             }
             hn_acc_to_frags(v, cur + t * M::STEPS32);
@@ -414,14 +448,14 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const int K32 = w[1] & 255, K32b = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
         const bool has_mask = w[4] >= 0;
         const bool do_stash = a.training && w[5] >= 0 && wave_valid;
-        unsigned bits = 0xffffffffu;
-        unsigned mbits[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        unsigned nbits = 0xffffffffu;
+        unsigned mbits[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // complemented words: set = keep
         if (has_mask) {   // all relu masks of the layer up front: one VMEM wait per layer, none per tile
           const HnSlot sl = a.slots[w[4]];
 #pragma unroll
           for (int dd = 0; dd < 4; ++dd)
             if (2 * dd < NT)
-              mbits[dd] = wave_valid ? a.masks[sl.off / 4 + ((size_t)blk * sl.nt + dd) * 64 + lane] : 0u;
+              mbits[dd] = wave_valid ? ~a.masks[sl.off / 4 + ((size_t)blk * sl.nt + dd) * 64 + lane] : 0u;
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -430,12 +464,11 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             hn_init_acc(acc, nullptr, t, h);
             hn_gemm_k<BF16>(acc, cur, K32, ws);
             if (K32b) hn_gemm_blocks<BF16, 1>(acc, cur2, ws);
-            if (!(t & 1)) bits = mbits[t >> 1];
+            if (!(t & 1)) nbits = mbits[t >> 1];
+            // dZ of padded points is zero from the LOAD ops on and stays zero: no `valid` select here
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const bool keep = ((bits >> (16 * (t & 1) + i)) & 1u) != 0u;
-              acc[i] = (keep && valid) ? acc[i] : 0.0f;
-            }
+            for (int i = 0; i < 16; ++i)
+              acc[i] = __int_as_float(__float_as_int(acc[i]) & hn_keep_mask(nbits, t & 1, i));
             hn_acc_to_frags(acc, nxt + t * M::STEPS32);
             if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, a, w[5], blk, t, lane);
           }
@@ -787,11 +820,12 @@ extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
   int rc = hn_check_args(a);
   if (rc) return rc;
   hn_allow_big_lds();
+  constexpr int WB = ModeT<true>::WAVES;
   const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + (size_t)((a->n_bias + 3) & ~3) * 4 +
-                     (size_t)((a->n_feat + 1) & ~1) * 8 + 8 * HN_MAX_COMPS * 32 * 4;
+                     (size_t)((a->n_feat + 1) & ~1) * 8 + (size_t)8 * a->n_comps * 32 * 4;
   if (lds > 150 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
-    hipLaunchKernelGGL(hn_mlp_fwd_kernel<true>, dim3(hn_grid_for(a->n_points, 256)), dim3(512), lds,
+    hipLaunchKernelGGL(hn_mlp_fwd_kernel<true>, dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
                        (hipStream_t)stream, *a);
   } else {
     hipLaunchKernelGGL(hn_mlp_fwd_kernel<false>, dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
@@ -808,11 +842,12 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
   const size_t flds = (size_t)((a->n_feat + 1) & ~1) * 8;
   if (flds > 64 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
-    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 8 * 32 * HN_DSRC_COMPS * 4 + 8 * HN_MAX_COMPS * 32 * 4;
-    hipLaunchKernelGGL(hn_mlp_bwd_kernel<true>, dim3(hn_grid_for(a->n_points, 256)), dim3(512), lds,
+    constexpr int WB = ModeT<true>::WAVES;
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + WB * 32 * HN_DSRC_COMPS * 4 + (size_t)WB * a->n_comps * 32 * 4;
+    hipLaunchKernelGGL(hn_mlp_bwd_kernel<true>, dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
                        (hipStream_t)stream, *a);
   } else {
-    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 4 * 32 * HN_DSRC_COMPS * 4 + 4 * HN_MAX_COMPS * 32 * 4;
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 4 * 32 * HN_DSRC_COMPS * 4 + (size_t)4 * a->n_comps * 32 * 4;
     hipLaunchKernelGGL(hn_mlp_bwd_kernel<false>, dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
                        (hipStream_t)stream, *a);
   }

@@ -242,6 +242,9 @@ class Program:
             ng = ly.aux.groups if ly.aux is not None else 0
             act = L.HN_ACT_RELU if ly.act == "relu" else L.HN_ACT_NONE
             flags = 0 if ly.commit else L.HN_LAYER_NO_COMMIT
+            if ly.aux is not None and any(f.kind != L.HN_FEAT_ZERO and (f.src, f.comp) not in self.comp_map
+                                          for f in ly.aux.feats):
+                flags |= L.HN_LAYER_DIRECT
             aux_slot = -1
             if ly.aux is not None and id(ly.aux) not in stashed_aux:
                 aux_slot = ly.aux.slot

@@ -39,7 +39,9 @@ typedef void* hnStream_t; /* hipStream_t */
 #define HN_MAX_DST 4
 #define HN_MAX_SLOTS 64
 #define HN_OP_WORDS 8
+#ifndef HN_CHUNK_UNITS
 #define HN_CHUNK_UNITS 32 /* weight stream is consumed in chunks of 32 units of 1 KiB */
+#endif
 #define HN_DSRC_COMPS 16  /* per-point source-gradient accumulators in the backward machine */
 
 /* ---- forward ops: word0 = opcode ---------------------------------------------------------
@@ -57,6 +59,7 @@ typedef void* hnStream_t; /* hipStream_t */
 #define HN_ACT_NONE 0
 #define HN_ACT_RELU 1
 #define HN_LAYER_NO_COMMIT 1 /* flags bit0: leave cur untouched (head layers read by an OUT op)      */
+#define HN_LAYER_DIRECT 2    /* flags bit1: the layer's feature groups hold HN_FEAT_ID_DIRECT entries       */
 /* dst[w1][p*ld + w2 + i] = act(accL row i) (+ residual src[w5][.. + w6 + i]), i < w3 <= 4           */
 #define HN_OP_OUT 4      /* w1=dst  w2=col  w3=n  w4=act(0 none,1 sigmoid)  w5=res_src|-1  w6=res_col */
 #define HN_OP_OUT_WIDE 5 /* w1=dst  w2=col  w3=n (<= 32*NT)  w4=NT   (cur features -> dst)            */

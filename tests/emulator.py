@@ -202,11 +202,11 @@ def make_group(mode, ft, srcs, p_of_lane, ray_of_lane, valid):
             for s in range(4):
                 for j in range(8):
                     v = feature_value(ft[16 * s + pi16(h, j)], srcs, p_of_lane[l], ray_of_lane[l])
-                    fr[s, l, j] = v if valid[l] else 0.0
+                    fr[s, l, j] = v     # padded lanes replicate the last point, like the device
         else:
             for s in range(32):
                 v = feature_value(ft[32 * (s >> 4) + rho(s & 15, h)], srcs, p_of_lane[l], ray_of_lane[l])
-                fr[s, l] = v if valid[l] else 0.0
+                fr[s, l] = v
     return fr
 
 
@@ -280,11 +280,12 @@ def run_forward(prog, mode, tables, params, srcs, n_points, spr, dst_widths, tra
                         acc = gemm_blocks(mode, acc, ws, aux[g], 2)
                     accL = acc.copy()
                     pos = acc > 0
-                    for i in range(16):
-                        bits |= (pos[:, i].astype(np.uint64) << np.uint64(16 * (t & 1) + i))
                     if act == 1:
+                        # device mask word: element i of tile (2d+q) is bit 31-(16q+i); set = gradient dropped.
+                        # Padded points keep their (finite) activations: their dZ is zero throughout the backward.
+                        for i in range(16):
+                            bits |= ((~pos[:, i]).astype(np.uint64) << np.uint64(31 - (16 * (t & 1) + i)))
                         acc = np.where(pos, acc, 0.0)
-                    acc = np.where(valid[:, None], acc, 0.0)
                     nxt[t * mode.steps32:(t + 1) * mode.steps32] = acc_to_frags(mode, acc)
                     if (t & 1) or t == nt - 1:
                         if training and w[4] >= 0:
@@ -375,7 +376,7 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
                     for l in range(64):
                         for i in range(16):
                             row = 32 * t + rho(i, l >> 5)
-                            keep = True if bits is None else bool((int(bits[l]) >> (16 * (t & 1) + i)) & 1)
+                            keep = True if bits is None else not ((int(bits[l]) >> (31 - (16 * (t & 1) + i))) & 1)
                             if valid[l] and keep and row < n:
                                 v[l, i] = arr[p[l], w[2] + row]
                     cur[t * mode.steps32:(t + 1) * mode.steps32] = acc_to_frags(mode, v)
@@ -393,9 +394,8 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
                         bits = stash.get_mask(w[4], blk, t >> 1)
                         for l in range(64):
                             for i in range(16):
-                                if not ((int(bits[l]) >> (16 * (t & 1) + i)) & 1):
+                                if (int(bits[l]) >> (31 - (16 * (t & 1) + i))) & 1:
                                     acc[l, i] = 0.0
-                    acc = np.where(valid[:, None], acc, 0.0)
                     nxt[t * mode.steps32:(t + 1) * mode.steps32] = acc_to_frags(mode, acc)
                     if w[5] >= 0:
                         stash.put_tile(w[5], blk, t, transpose_tile(mode, nxt[t * mode.steps32:(t + 1) * mode.steps32]))
