@@ -192,6 +192,14 @@ HN_DEV unsigned hn_push_mask(unsigned bits, float x) {
 // all-ones where element (q, i) of the mask word is kept, zero where it is dropped
 HN_DEV int hn_keep_mask(unsigned nbits, int q, int i) { return (int)(nbits << (16 * q + i)) >> 31; }
 
+// Op words are read through the constant address space: scalar loads (s_load_dwordx8 through the scalar cache), and
+// the compiler knows no store of the kernel can change them (a plain pointer made it re-load a word with a vector
+// load + vmcnt(0) after every stash store).
+typedef const __attribute__((address_space(4))) int* HnOpPtr;
+HN_DEV HnOpPtr hn_op_words(const int* ops, int op) {
+  return (HnOpPtr)(uintptr_t)(ops + (size_t)op * HN_OP_WORDS);
+}
+
 constexpr int HN_AUXG_MAX = 3;  // generated-feature groups per layer (192 features)
 
 // ------------------------------------------------------------------------------------------------
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
     ws.start();
 
     for (int op = 0; op < a.n_ops; ++op) {
-      const int* w = a.ops + op * HN_OP_WORDS;
+      const HnOpPtr w = hn_op_words(a.ops, op);
       const int code = w[0];
       if (code == HN_OP_LAYER) {
         const int K32 = w[1] & 255, nG = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
@@ -357,9 +365,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   constexpr int PTS = M::WAVES * 32;
   const int ntiles = (a.n_points + PTS - 1) / PTS;
   HnFeat* feat_lds = reinterpret_cast<HnFeat*>(smem + 2 * HN_CHUNK_UNITS * 1024);
-  float* dsrc_lds = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (32 * HN_DSRC_COMPS);
-  float* srcv = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + M::WAVES * (32 * HN_DSRC_COMPS) +
-                wave * (a.n_comps * 32);
+  float* srcv = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (a.n_comps * 32);
   for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
   __syncthreads();
 
@@ -381,12 +387,13 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
     const int p = valid ? p0 : a.n_points - 1;
     const int ray = p / a.samples_per_ray;
     const bool wave_valid = blk * 32 < a.n_points;
-    for (int i = lane; i < 32 * HN_DSRC_COMPS; i += 64) dsrc_lds[i] = 0.0f;
+    f32x16 dacc;  // source gradients of the block: row rho(i,h) = dsrc column, col r = point
+    hn_init_acc(dacc, nullptr, 0, h);
     hn_stage_sources(srcv, a, p, ray, lane);
     ws.start();
 
     for (int op = 0; op < a.n_ops; ++op) {
-      const int* w = a.ops + op * HN_OP_WORDS;
+      const HnOpPtr w = hn_op_words(a.ops, op);
       const int code = w[0];
       if (code == HN_BOP_LOAD) {
         // dZ (<= 4 columns) of an output layer -> one 32-feature tile
@@ -486,24 +493,25 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
           hn_init_acc(acc, nullptr, 0, h);
           hn_gemm_k<BF16>(acc, cur, K32, ws);
           if (K32b) hn_gemm_blocks<BF16, 1>(acc, cur2, ws);
+          // chain rule per feature, then the reduction over the features of each source component as one more
+          // matrix product: dacc[slot][point] += S[slot][feature] . G[feature][point]  (S: 0/1 selection block that
+          // the host put in the weight stream right behind this tile's weights).  No LDS accumulators: an LDS
+          // atomic after an LDS-DMA makes the compiler drain vmcnt, i.e. the weight prefetch.
           const HnFeat* ft = feat_lds + w[3] + 32 * tt;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const HnFeat e = ft[hn_rho(i, h)];
-            const int slot = ((e.packed >> 16) & 255) - 1;
-            if (slot >= 0 && valid)
-              atomicAdd(dsrc_lds + r * HN_DSRC_COMPS + slot, acc[i] * hn_feature_grad<BF16>(e, srcv, r));
-          }
+          for (int i = 0; i < 16; ++i) acc[i] *= hn_feature_grad<BF16>(ft[hn_rho(i, h)], srcv, r);
+          Frag gfr[M::STEPS32];
+          hn_acc_to_frags(acc, gfr);
+          hn_gemm_blocks<BF16, 1>(dacc, gfr, ws);
         }
       }
     }
     // source gradients of this block -> global
-    if (a.n_dsrc > 0) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      for (int i = lane; i < 32 * HN_DSRC_COMPS; i += 64) {
-        const int rr = i / HN_DSRC_COMPS, c = i % HN_DSRC_COMPS;
-        const int pp = blk * 32 + rr;
-        if (c < a.n_dsrc && pp < a.n_points) a.dsrc[(size_t)pp * a.n_dsrc + c] = dsrc_lds[i];
+    if (a.n_dsrc > 0 && p0 < a.n_points) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int slot = hn_rho(i, h);
+        if (slot < a.n_dsrc) a.dsrc[(size_t)p0 * a.n_dsrc + slot] = dacc[i];
       }
     }
   }
@@ -843,11 +851,11 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
   if (flds > 64 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
     constexpr int WB = ModeT<true>::WAVES;
-    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + WB * 32 * HN_DSRC_COMPS * 4 + (size_t)WB * a->n_comps * 32 * 4;
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + (size_t)WB * a->n_comps * 32 * 4;
     hipLaunchKernelGGL(hn_mlp_bwd_kernel<true>, dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
                        (hipStream_t)stream, *a);
   } else {
-    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + 4 * 32 * HN_DSRC_COMPS * 4 + (size_t)4 * a->n_comps * 32 * 4;
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + (size_t)4 * a->n_comps * 32 * 4;
     hipLaunchKernelGGL(hn_mlp_bwd_kernel<false>, dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
                        (hipStream_t)stream, *a);
   }

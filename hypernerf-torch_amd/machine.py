@@ -385,7 +385,28 @@ class Program:
                     else:
                         pos, ctr = self._take(ctr, u32)
                         put(pos, ly, 0, c0, ly.aux_c0 + ly.aux.n)
+                    # the 0/1 selection block that sums this tile's feature gradients into their source components
+                    pos, ctr = self._take(ctr, u32)
+                    f0 = ly.aux.feat_off + 64 * g + 32 * tt
+                    for u in range(u32):
+                        k0 = 16 * u if mode == L.HN_MODE_BF16 else 4 * u
+                        units[pos + u] = (self.sel_w_id, len(self.feat_table), 0, f0, self.n_dsrc,
+                                          len(self.feat_table), k0, 0)
         return units, ctr
+
+    @property
+    def sel_w_id(self) -> int:
+        """Pseudo weight id of the selection matrix (one past the parameters) in the packer's pointer list."""
+        return len(self.params)
+
+    def selection_matrix(self) -> np.ndarray:
+        """S[d, f] = 1 where generated feature f differentiates into source-gradient column d.  The backward machine
+        reduces (W_aux^T dZ * dfeature/dx) over features with one more matrix product against S."""
+        S = np.zeros((max(1, self.n_dsrc), max(1, len(self.feat_table))), dtype=np.float32)
+        for i, f in enumerate(self.feat_table):
+            if f.need_grad and (f.src, f.comp) in self.dsrc_map:
+                S[self.dsrc_map[(f.src, f.comp)], i] = 1.0
+        return S
 
     def _units_array(self, units: Dict[int, tuple], ctr: int) -> Tuple[np.ndarray, int]:
         n_chunks = max(1, (ctr + CHUNK - 1) // CHUNK)
@@ -534,6 +555,7 @@ class MlpRunner:
             d.bwd_ops = L.to_device_bytes(self.prog.bwd_ops, device)
             d.wstream = torch.empty(d.n_units * 1024, dtype=torch.uint8, device=device)
             d.bias = torch.zeros(max(32, self.prog.bias_len), dtype=torch.float32, device=device)
+            d.sel = torch.from_numpy(self.prog.selection_matrix()).to(device)
             d.ptr_key, d.ptrs, d.pack_key = None, None, None
             self._dev[key] = d
         return d
@@ -551,7 +573,7 @@ class MlpRunner:
             L.require_gpu(p)
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise L.HnError("parameters must be contiguous fp32 tensors")
-        pk = tuple(p.data_ptr() for p in self.prog.params)
+        pk = tuple(p.data_ptr() for p in self.prog.params) + (d.sel.data_ptr(),)
         if d.ptr_key != pk:
             d.ptrs = torch.tensor(list(pk), dtype=torch.int64).to(device)
             d.ptr_key = pk

@@ -331,7 +331,7 @@ def run_forward(prog, mode, tables, params, srcs, n_points, spr, dst_widths, tra
 def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
     global COMPS
     COMPS = tables["comps"]
-    units = pack_units(mode, tables["bwd_units"], params)
+    units = pack_units(mode, tables["bwd_units"], list(params) + [prog.selection_matrix().astype(np.float64)])
     feat = tables["feat"]
     dsrc = np.zeros((n_points, max(1, prog.n_dsrc)))
     nblk = (n_points + 31) // 32
@@ -343,6 +343,7 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
         ws = WStream(units)
         cur = mode.zero_frags(8 * mode.steps32)
         cur2 = mode.zero_frags(mode.steps32)
+        dacc = np.zeros((64, 16))      # source gradients of the block: row = dsrc column, col = point
         for w in prog.bwd_ops:
             code = w[0]
             if code == 1:
@@ -408,14 +409,20 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
                     if k32b:
                         acc = gemm_blocks(mode, acc, ws, cur2, 1)
                     ft = feat[w[3] + 32 * tt: w[3] + 32 * tt + 32]
+                    G = np.zeros((64, 16))
                     for l in range(64):
-                        if not valid[l]:
-                            continue
                         for i in range(16):
                             e = ft[rho(i, l >> 5)]
-                            slot = ((e["packed"] >> 16) & 255) - 1
-                            if slot >= 0:
-                                dsrc[p[l], slot] += acc[l, i] * feature_grad(e, srcs, p[l], ray[l])
+                            G[l, i] = acc[l, i] * feature_grad(e, srcs, p[l], ray[l])
+                    # dacc[slot][point] += S[slot][feature] . G[feature][point]  (selection units of the stream)
+                    sel = ws.take(mode.units32)
+                    dacc = mma_block32(mode, dacc, sel, acc_to_frags(mode, G))
+        for l in range(64):
+            if valid[l]:
+                for i in range(16):
+                    slot = rho(i, l >> 5)
+                    if slot < prog.n_dsrc:
+                        dsrc[p[l], slot] = dacc[l, i]
     return dsrc
 
 
