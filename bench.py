@@ -68,12 +68,15 @@ def main():
     model = NerfModel(EMB, near=0.0, far=1.0, n_samples_coarse=a.nc, n_samples_fine=a.nf, noise_std=1.0,
                       hyper_slice_method="bendy_sheet", use_warp=True, use_nerf_embed=True, use_alpha_cond=True,
                       view_fourier_dim=6).to(dev)
-    params = [p for p in model.parameters()]
     use_graph = not a.no_graph
-    # the optimizer step is part of the captured graph on one GPU; with N>1 the gradient all-reduce sits between
+    # parameters and gradients live in one flat arena each: the kernels accumulate dW straight into it, Adam
+    # steps one tensor, and data parallelism all-reduces the gradient buffer in place.
+    # The optimizer step is part of the captured graph on one GPU; with N>1 the gradient all-reduce sits between
     # the captured forward+backward and an eager fused Adam
-    opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8, fused=True, capturable=(use_graph and world == 1))
-    bucket = GradBucket(params)
+    arena = HN.ParamArena(model.parameters())
+    opt = torch.optim.Adam([arena.flat_param], lr=5e-4, eps=1e-8, fused=True,
+                           capturable=(use_graph and world == 1))
+    bucket = arena
     loss_fn = MSELoss()
 
     # synthetic rays (B,9): origins U(-1,1)^3, unit-ish directions, near/far 0/1, image id; rgb targets
@@ -90,7 +93,7 @@ def main():
         rd = model_utils.prepare_ray_dict(rays)
         out = model(rd, extra)
         loss = loss_fn(out, target)
-        opt.zero_grad(set_to_none=True)
+        arena.zero_grad()
         loss.backward()
         return out, loss
 

@@ -12,6 +12,7 @@ All device arithmetic runs in hand-written HIP kernels behind the C ABI in inclu
 (csrc/libhn_hip.so).  There is no CPU execution path: ops raise on CPU tensors or a missing library.
 """
 from . import _lib
+from .arena import ParamArena
 from .functional import get_precision, set_precision
 
 __version__ = "0.1.0"

@@ -48,6 +48,11 @@ class GradBucket:
         """Average gradients across ranks with a single all-reduce; missing grads count as zero."""
         if not self.params:
             return
+        from .arena import ParamArena
+        arena = ParamArena.lookup(self.params)
+        if arena is not None and arena[0].params == self.params:
+            arena[0].all_reduce_mean(group)      # the gradients already are one flat buffer: reduce it in place
+            return
         self._ensure(self.params[0].device)
         self.flat.zero_()
         for p, o in zip(self.params, self.offsets):

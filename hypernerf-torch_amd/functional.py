@@ -12,6 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
+from .arena import ParamArena
 from .machine import MlpRunner, Program
 
 _PRECISION = os.environ.get("HN_PRECISION", "bf16")
@@ -94,10 +95,14 @@ class _ProgramFn(torch.autograd.Function):
                 bsrcs.append((g.contiguous(), False))
             else:
                 bsrcs.append((ctx.outs[k], False))
-        dsrc, flat = call.runner.backward(ctx.mode, ctx.n_points, ctx.spr, bsrcs, ctx.stash, ctx.masks)
+        # parameters attached to a ParamArena: accumulate into its gradient buffer, return nothing through autograd
+        prog = call.program
+        wants = [ctx.needs_input_grad[5 + ctx.n_src + j] for j in range(len(prog.params))]
+        target = ParamArena.lookup(prog.params) if all(wants) else None
+        dsrc, flat = call.runner.backward(ctx.mode, ctx.n_points, ctx.spr, bsrcs, ctx.stash, ctx.masks,
+                                          grad_target=(target[0].grad, target[1]) if target else None)
         ctx.stash = ctx.masks = None
         src_grads: List[Optional[torch.Tensor]] = []
-        prog = call.program
         for i, shp in enumerate(ctx.src_shapes):
             if shp is None or not ctx.needs_input_grad[5 + i]:
                 src_grads.append(None)
@@ -122,11 +127,10 @@ class _ProgramFn(torch.autograd.Function):
                 if idx[1] is not None:
                     g = g * idx[1]
             src_grads.append(g.view(shp))
+        if flat is None:
+            return (None, None, None, None, None, *src_grads, *([None] * len(prog.params)))
         pgrads = call.runner.split_grads(flat)
-        n_par = len(prog.params)
-        out_p = []
-        for j in range(n_par):
-            out_p.append(pgrads[j] if ctx.needs_input_grad[5 + ctx.n_src + j] else None)
+        out_p = [pgrads[j] if wants[j] else None for j in range(len(prog.params))]
         return (None, None, None, None, None, *src_grads, *out_p)
 
 
@@ -139,11 +143,16 @@ def run_program(call: ProgramCall, srcs: Sequence[Optional[torch.Tensor]], sampl
     return _ProgramFn.apply(call, mode_of(precision), int(samples_per_ray), len(srcs), training, *srcs, *params)
 
 
+_ARANGE: Dict[tuple, torch.Tensor] = {}
+
+
 def sum_samples(d_points: torch.Tensor, cols: Dict[int, int], n_rays: int, n_samples: int, width: int):
     """(n_rays, width) with out[b, c] = sum_s d_points[b*S + s, slot(c)] — HIP reduction kernel, one launch per
     run of consecutive (column, slot) pairs (the 8 GLO components are one run)."""
     L.load()
-    idx = torch.arange(n_rays, dtype=torch.int64, device=d_points.device)
+    idx = _ARANGE.get((n_rays, d_points.device))
+    if idx is None:
+        idx = _ARANGE[(n_rays, d_points.device)] = torch.arange(n_rays, dtype=torch.int64, device=d_points.device)
     items = sorted(cols.items())
     out = None
     i = 0
@@ -177,18 +186,22 @@ class _EmbedFn(torch.autograd.Function):
         out = torch.empty(n, dim, dtype=torch.float32, device=table.device)
         L.launch("hn_embed_gather", L.ptr(table.detach().contiguous()), L.ptr(idx), C.c_int(n), C.c_int(dim),
                                     C.c_int(table.shape[0]), L.ptr(out), L.stream_handle())
-        ctx.idx, ctx.shape = idx, table.shape
+        ctx.idx, ctx.shape, ctx.table = idx, table.shape, table
         return out
 
     @staticmethod
     def backward(ctx, g):
         L.load()
         g = g.contiguous()
-        d_table = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        target = ParamArena.lookup([ctx.table]) if isinstance(ctx.table, torch.nn.Parameter) else None
+        if target is not None:      # scatter-add straight into the arena's view of table.grad
+            d_table, ret = ctx.table.grad, None
+        else:
+            d_table = ret = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
         n, dim = g.shape
         L.launch("hn_embed_backward", L.ptr(g), C.c_int(dim), C.c_int(0), L.ptr(ctx.idx), C.c_int(n), C.c_int(1),
                                       C.c_int(dim), C.c_int(ctx.shape[0]), L.ptr(d_table), L.stream_handle())
-        return d_table, None
+        return ret, None
 
 
 def embed_lookup(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
@@ -299,6 +312,7 @@ class _CompositeFn(torch.autograd.Function):
         if o_mp is not None:
             outs.append(o_mp); nd.append(o_mp)
         ctx.mark_non_differentiable(*nd)
+        ctx.set_materialize_grads(False)      # unused outputs (depth, acc, weights) arrive as None, not as zero fills
         return tuple(outs)
 
     @staticmethod

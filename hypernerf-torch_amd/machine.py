@@ -472,11 +472,12 @@ class Program:
             return 1, min(8, max(1, n_kt)) if n_kt <= 8 else 8
         return 2, 4
 
-    def wgrad_jobs(self, mode: int, n_points: int, target_jobs: int = 512) -> np.ndarray:
+    def wgrad_jobs(self, mode: int, n_points: int, target_jobs: int = 512,
+                   grad_offsets: Optional[Sequence[int]] = None) -> np.ndarray:
         """One job per (layer input segment, tile rectangle, block chunk).  The chunks are sized so that the
         launch is about `target_jobs` workgroups of equal stash bytes (one per CU, a single round)."""
         offs, _, _ = self.layout(mode, n_points)
-        goffs, _ = self.grad_offsets()
+        goffs = list(grad_offsets) if grad_offsets is not None else self.grad_offsets()[0]
         nblk = (n_points + 31) // 32
         tmax = 8 if mode == L.HN_MODE_BF16 else 4
         stage_tiles = 16 if mode == L.HN_MODE_BF16 else 8         # 32 KiB per LDS stage
@@ -561,7 +562,12 @@ class MlpRunner:
         return d
 
     def _param_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.prog.params)
+        # parameters that live in a ParamArena are updated through the arena's flat tensor: its version counts
+        key = []
+        for p in self.prog.params:
+            tag = getattr(p, "_hn_arena", None)
+            key.append((p.data_ptr(), p._version, tag[0].version() if tag is not None else 0))
+        return tuple(key)
 
     def pack(self, device, mode):
         """(Re)pack both weight streams if any parameter changed since the last pack."""
@@ -626,9 +632,11 @@ class MlpRunner:
         L.launch("hn_mlp_forward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         return stash, masks
 
-    def backward(self, mode, n_points, samples_per_ray, srcs, stash, masks):
+    def backward(self, mode, n_points, samples_per_ray, srcs, stash, masks, grad_target=None):
         """Launch backward-data then the weight-gradient kernel.
-        Returns (dsrc [P, n_dsrc] or None, flat fp32 gradient buffer)."""
+        grad_target = (flat fp32 buffer, per-parameter offsets): accumulate the weight gradients there (a
+        ParamArena's gradient buffer) instead of into a fresh zero-filled buffer.
+        Returns (dsrc [P, n_dsrc] or None, flat fp32 gradient buffer or None when grad_target was given)."""
         device = stash.device
         d = self.pack(device, mode)
         dsrc = None
@@ -637,16 +645,20 @@ class MlpRunner:
         a = self._args(d, mode, n_points, samples_per_ray, True, d.bwd_ops, len(self.prog.bwd_ops),
                        d.wstream.data_ptr() + d.n_fwd_units * 1024, d.bwd_chunks, srcs, [], stash, masks, dsrc)
         L.launch("hn_mlp_backward", C.byref(a), L.stream_handle(), tag=self.prog.name)
-        jkey = (str(device), mode, n_points)
+        goffs = tuple(grad_target[1]) if grad_target is not None else None
+        jkey = (str(device), mode, n_points, goffs)
         if jkey not in self._jobs:
-            jobs = self.prog.wgrad_jobs(mode, n_points)
+            jobs = self.prog.wgrad_jobs(mode, n_points, grad_offsets=goffs)
             self._jobs[jkey] = (L.to_device_bytes(jobs, device), len(jobs))
         jobs_dev, n_jobs = self._jobs[jkey]
-        _, gtot = self.prog.grad_offsets()
-        grads = torch.zeros(gtot, dtype=torch.float32, device=device)
+        if grad_target is not None:
+            grads, ret = grad_target[0], None
+        else:
+            _, gtot = self.prog.grad_offsets()
+            grads = ret = torch.zeros(gtot, dtype=torch.float32, device=device)
         L.launch("hn_mlp_wgrad", C.c_int(mode), L.ptr(jobs_dev), C.c_int(n_jobs), L.ptr(stash), L.ptr(grads),
                  L.stream_handle(), tag=self.prog.name)
-        return dsrc, grads
+        return dsrc, ret
 
     def split_grads(self, flat: torch.Tensor) -> List[torch.Tensor]:
         offs, _ = self.prog.grad_offsets()

@@ -44,6 +44,18 @@ def _worker(rank, world, port, q):
         ok = (torch.allclose(a.grad, torch.full((5, 3), 1.5)) and
               torch.allclose(b.grad, torch.arange(7, dtype=torch.float32) / 2) and
               torch.allclose(c.grad, torch.full((2, 2), 15.0)))
+        # the same through a ParamArena: gradients already are one buffer, reduced in place (GradBucket fast path)
+        from hypernerf_torch_amd import ParamArena
+        d = torch.nn.Parameter(torch.ones(3, 3))
+        e = torch.nn.Parameter(torch.ones(5))
+        arena = ParamArena([d, e])
+        d.grad.fill_(float(rank + 1))
+        e.grad.copy_(torch.arange(5, dtype=torch.float32) * (rank + 1))
+        GradBucket([d, e]).all_reduce_mean()
+        ok = ok and torch.allclose(d.grad, torch.full((3, 3), 1.5)) and \
+            torch.allclose(e.grad, torch.arange(5, dtype=torch.float32) * 1.5) and \
+            arena.attached(d) == 0 and arena.attached(e) == 12 and \
+            torch.allclose(arena.grad[:9], torch.full((9,), 1.5))
         px = torch.full((4, 3), float(rank))
         allpx = all_gather_pixels(px)
         ok = ok and allpx.shape == (8, 3) and torch.equal(allpx[:4], torch.zeros(4, 3)) and \

@@ -317,3 +317,51 @@ def test_config2_full_size_properties():
         if k.startswith("nerf_embed"):
             continue    # unused when GLO tables are shared
         assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
+
+
+@pytest.mark.gpu
+def test_param_arena_gradients_match_autograd_path():
+    """The same step with parameters attached to a ParamArena (dW accumulated straight into the flat gradient
+    buffer, embedding scatter-add into its view) must give the gradients the autograd-returned path gives, and
+    a second backward must ACCUMULATE like torch does.  fp32 mode; the only difference allowed is the order of
+    the fp32 atomic adds."""
+    import hypernerf_torch_amd as HN
+    HN.set_precision("fp32")
+    try:
+        kw = dict(n_samples_coarse=16, n_samples_fine=16, noise_std=1.0, hyper_slice_method="bendy_sheet",
+                  use_nerf_embed=True, use_alpha_cond=True, view_fourier_dim=6)
+        m1 = models.NerfModel(EMB, **kw).to(DEV)
+        load_hash(m1, 5)
+        m2 = models.NerfModel(EMB, **kw).to(DEV)
+        m2.load_state_dict(m1.state_dict())
+        arena = HN.ParamArena(m2.parameters())
+        o, d, idx = rays_for(3, 48)
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        b = 48
+        rng = {"t_rand": torch.rand(b, 16, device=DEV), "noise_coarse": torch.randn(b, 16, 1, device=DEV),
+               "u": torch.rand(b, 16, device=DEV), "noise_fine": torch.randn(b, 32, 1, device=DEV)}
+
+        def loss_of(m):
+            out = m(rays, {}, rng=rng)
+            return (out["coarse"]["rgb"] ** 2).mean() + (out["fine"]["rgb"] ** 2).mean() + out["fine"]["depth"].mean()
+
+        l1 = loss_of(m1)
+        l1.backward()
+        arena.zero_grad()
+        l2 = loss_of(m2)
+        l2.backward()
+        assert float((l1 - l2).detach().abs()) <= 1e-6 * max(1.0, float(l1.detach().abs()))
+        n1 = dict(m1.named_parameters())
+        for name, p in m2.named_parameters():
+            assert arena.attached(p) is not None, name
+            g1 = n1[name].grad
+            if g1 is None:
+                assert float(p.grad.abs().max()) == 0.0, name
+                continue
+            assert_grad_close(p.grad, g1, 1e-5, name)
+        first = arena.grad.clone()
+        loss_of(m2).backward()              # accumulates
+        assert_close(arena.grad, 2 * first, 1e-5, "accumulated gradients")
+    finally:
+        HN.set_precision("bf16")

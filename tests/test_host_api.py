@@ -134,3 +134,31 @@ def test_init_matches_reference_rng_order():
     for i, l in enumerate(lins):
         assert torch.equal(m.linears[i].weight, l.weight) and torch.equal(m.linears[i].bias, l.bias)
     assert torch.equal(m.logit_layer.weight, logit.weight)
+
+
+def test_param_arena_views_and_detach():
+    """ParamArena: p.data / p.grad become views of two flat buffers; values survive; one tensor to optimise;
+    zero_grad(set_to_none=True) on a parameter detaches it (kernels then fall back to autograd gradients)."""
+    lin = torch.nn.Linear(5, 3)
+    emb = torch.nn.Embedding(7, 2)
+    w0, b0, e0 = lin.weight.detach().clone(), lin.bias.detach().clone(), emb.weight.detach().clone()
+    params = list(lin.parameters()) + list(emb.parameters())
+    arena = HN.ParamArena(params + [lin.weight])        # duplicates are ignored
+    assert arena.numel == 16 + 4 + 16 and arena.offsets == [0, 16, 20]
+    assert torch.equal(lin.weight, w0) and torch.equal(lin.bias, b0) and torch.equal(emb.weight, e0)
+    assert lin.weight.data_ptr() == arena.data.data_ptr() and lin.bias.data_ptr() == arena.data.data_ptr() + 64
+    assert HN.ParamArena.lookup(params)[1] == [0, 16, 20]
+    # ordinary autograd still accumulates into the views
+    y = lin(torch.ones(2, 5)).sum() + emb(torch.tensor([1, 1, 3])).sum()
+    y.backward()
+    assert torch.allclose(arena.grad[:15], torch.full((15,), 2.0)) and float(arena.grad[15]) == 0.0   # padding
+    assert torch.allclose(emb.weight.grad[1], torch.full((2,), 2.0))
+    # one optimiser tensor; stepping it changes the module's weights and the arena version
+    v = arena.version()
+    torch.optim.SGD([arena.flat_param], lr=0.5).step()
+    assert arena.version() != v
+    assert torch.allclose(lin.weight, w0 - 1.0) and torch.allclose(emb.weight[3], e0[3] - 0.5)
+    arena.zero_grad()
+    assert float(lin.weight.grad.abs().sum()) == 0.0 and arena.attached(lin.weight) == 0
+    lin.weight.grad = None
+    assert arena.attached(lin.weight) is None and HN.ParamArena.lookup(params) is None
