@@ -530,6 +530,20 @@ class _DevTables:
     pass
 
 
+_OPT_STEPS = [0]
+
+
+def _count_optimizer_steps(optimizer, args, kwargs):
+    _OPT_STEPS[0] += 1
+
+
+try:    # any torch optimizer step invalidates packed weights (inference after training; training repacks anyway)
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+    register_optimizer_step_post_hook(_count_optimizer_steps)
+except ImportError:     # pragma: no cover
+    pass
+
+
 class MlpRunner:
     """Owns the device copies of a Program's tables and launches the three kernels."""
 
@@ -562,18 +576,21 @@ class MlpRunner:
         return d
 
     def _param_key(self):
-        # parameters that live in a ParamArena are updated through the arena's flat tensor: its version counts
-        key = []
+        # Tensor._version does not see every update (fused optimizers write parameters without bumping it), so the
+        # key also carries the arena version and a global count of optimizer steps (see _count_optimizer_steps);
+        # training forwards repack unconditionally.
+        key = [_OPT_STEPS[0]]
         for p in self.prog.params:
             tag = getattr(p, "_hn_arena", None)
             key.append((p.data_ptr(), p._version, tag[0].version() if tag is not None else 0))
         return tuple(key)
 
-    def pack(self, device, mode):
-        """(Re)pack both weight streams if any parameter changed since the last pack."""
+    def pack(self, device, mode, force: bool = False):
+        """(Re)pack both weight streams: always when `force` (every training forward — a fused optimizer step
+        leaves no trace on the tensors), otherwise only if a parameter is known to have changed."""
         d = self._tables(device, mode)
         key = self._param_key()
-        if d.pack_key == key:
+        if d.pack_key == key and not force:
             return d
         for p in self.prog.params:
             L.require_gpu(p)
@@ -621,7 +638,7 @@ class MlpRunner:
     def forward(self, mode, n_points, samples_per_ray, srcs, dsts, training: bool):
         """Launch the forward machine.  Returns (stash, masks) (None, None when not training)."""
         device = dsts[0].device if dsts and dsts[0] is not None else srcs[0][0].device
-        d = self.pack(device, mode)
+        d = self.pack(device, mode, force=training)
         stash = masks = None
         if training:
             _, sb, mb = self.prog.layout(mode, n_points)
@@ -638,7 +655,7 @@ class MlpRunner:
         ParamArena's gradient buffer) instead of into a fresh zero-filled buffer.
         Returns (dsrc [P, n_dsrc] or None, flat fp32 gradient buffer or None when grad_target was given)."""
         device = stash.device
-        d = self.pack(device, mode)
+        d = self._tables(device, mode)       # the streams its forward packed
         dsrc = None
         if self.prog.n_dsrc > 0:
             dsrc = torch.empty(n_points, self.prog.n_dsrc, dtype=torch.float32, device=device)

@@ -365,3 +365,43 @@ def test_param_arena_gradients_match_autograd_path():
         assert_close(arena.grad, 2 * first, 1e-5, "accumulated gradients")
     finally:
         HN.set_precision("bf16")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_arena", [False, True])
+def test_weights_are_repacked_after_fused_optimizer_step(use_arena):
+    """A fused optimizer updates parameters without bumping Tensor._version; the packed weight streams must still
+    follow.  After one Adam step the model has to render what a freshly built model with the updated state dict
+    renders (inference mode, i.e. the change-detection path, and training mode)."""
+    import hypernerf_torch_amd as HN
+    HN.set_precision("fp32")
+    try:
+        kw = dict(n_samples_coarse=8, n_samples_fine=8, noise_std=0.0, hyper_slice_method="bendy_sheet",
+                  use_nerf_embed=True, use_alpha_cond=True, view_fourier_dim=6)
+        m = models.NerfModel(EMB, **kw).to(DEV)
+        load_hash(m, 9)
+        o, d, idx = rays_for(4, 32)
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        rng = {"t_rand": torch.rand(32, 8, device=DEV), "u": torch.rand(32, 8, device=DEV)}
+        if use_arena:
+            arena = HN.ParamArena(m.parameters())
+            opt = torch.optim.Adam([arena.flat_param], lr=1e-2, fused=True)
+        else:
+            opt = torch.optim.Adam(m.parameters(), lr=1e-2, fused=True)
+        out0 = m(rays, {}, rng=rng)
+        loss = (out0["fine"]["rgb"] ** 2).mean() + (out0["coarse"]["rgb"] ** 2).mean()
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            out1 = m(rays, {}, rng=rng)["fine"]["rgb"]
+        out1_train = m(rays, {}, rng=rng)["fine"]["rgb"]
+        fresh = models.NerfModel(EMB, **kw).to(DEV)
+        fresh.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+        with torch.no_grad():
+            ref = fresh(rays, {}, rng=rng)["fine"]["rgb"]
+        assert float((ref - out0["fine"]["rgb"].detach()).abs().max()) > 1e-4      # the step did move the output
+        assert_close(out1, ref, 1e-6, "inference after optimizer step")
+        assert_close(out1_train, ref, 1e-6, "training forward after optimizer step")
+    finally:
+        HN.set_precision("bf16")
