@@ -48,7 +48,7 @@ class HnMlpArgs(C.Structure):
     _fields_ = [
         ("mode", C.c_int32), ("n_points", C.c_int32), ("samples_per_ray", C.c_int32), ("training", C.c_int32),
         ("n_ops", C.c_int32), ("n_chunks", C.c_int32), ("n_dsrc", C.c_int32), ("n_bias", C.c_int32),
-        ("n_feat", C.c_int32), ("pad0", C.c_int32),
+        ("n_feat", C.c_int32), ("max_groups", C.c_int32),
         ("ops", C.c_void_p), ("wstream", C.c_void_p), ("bias", C.c_void_p), ("feat", C.c_void_p),
         ("stash", C.c_void_p), ("masks", C.c_void_p), ("dsrc", C.c_void_p),
         ("src", HnSrc * HN_MAX_SRC), ("dst", HnDst * HN_MAX_DST), ("slots", HnSlot * HN_MAX_SLOTS),

@@ -157,12 +157,36 @@ HN_DEV void hn_init_acc(f32x16& acc, const float* bias, int t, int h) {
 }
 
 // acc += W[tile][32*K32 features] . in   (K32 consecutive blocks of the stream)
+// bf16: the A fragments (one ds_read_b128 per MFMA) are read HN_PF units ahead of the MFMA that consumes them, so
+// the LDS latency hides behind the two or three MFMAs in between instead of being paid before every pair.
+constexpr int HN_PF = 4;
 template <bool BF16, int K32>
 HN_DEV void hn_gemm_blocks(f32x16& acc, const typename ModeT<BF16>::Frag* in, WStream<ModeT<BF16>::WAVES>& ws) {
   using M = ModeT<BF16>;
   const char* w = ws.take(K32 * M::UNITS32);
+  if constexpr (BF16) {
+    constexpr int N = 2 * K32;
+    constexpr int D = N < HN_PF ? N : HN_PF;
+    const char* wl = w + ws.lane * 16;
+    bf16x8 q[D];
 #pragma unroll
-  for (int k = 0; k < K32; ++k) hn_mma_block32(acc, w + k * M::UNITS32 * 1024, in + k * M::STEPS32, ws.lane);
+    for (int u = 0; u < D; ++u) q[u] = *reinterpret_cast<const bf16x8*>(wl + u * 1024);
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      acc = hn_mfma_bf16(q[u % D], in[u], acc);
+      if (u + D < N) q[u % D] = *reinterpret_cast<const bf16x8*>(wl + (u + D) * 1024);
+    }
+    // pin that order (left alone, the scheduler pulls every read back next to its MFMA to save registers)
+    __builtin_amdgcn_sched_group_barrier(0x100, D, 0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (u + D < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K32; ++k) hn_mma_block32(acc, w + k * M::UNITS32 * 1024, in + k * M::STEPS32, ws.lane);
+  }
 }
 template <bool BF16>
 HN_DEV void hn_gemm_k(f32x16& acc, const typename ModeT<BF16>::Frag* in, int K32, WStream<ModeT<BF16>::WAVES>& ws) {
@@ -172,13 +196,20 @@ HN_DEV void hn_gemm_k(f32x16& acc, const typename ModeT<BF16>::Frag* in, int K32
   else if (K32 == 1) hn_gemm_blocks<BF16, 1>(acc, in, ws);
 }
 
+// address of tile 0 of a stash slot for one 32-point block (looked up once per op, outside the tile loops: the slot
+// table sits in the kernel arguments and a lookup is two dependent scalar loads)
 template <bool BF16>
-HN_DEV void hn_stash(const typename ModeT<BF16>::Frag* fr, const HnMlpArgs& a, int slot, int blk, int t, int lane) {
-  using M = ModeT<BF16>;
+HN_DEV char* hn_slot_base(const HnMlpArgs& a, int slot, int blk) {
+  if (slot < 0) return nullptr;
   const HnSlot sl = a.slots[slot];
-  char* base = reinterpret_cast<char*>(a.stash) + sl.off + ((size_t)blk * sl.nt + t) * (M::TILE_UNITS * 1024);
+  return reinterpret_cast<char*>(a.stash) + sl.off + (size_t)blk * sl.nt * (ModeT<BF16>::TILE_UNITS * 1024);
+}
+// transpose one tile through the matrix core and store it as tile t of the slot
+template <bool BF16>
+HN_DEV void hn_stash(const typename ModeT<BF16>::Frag* fr, char* slot_base, int t, int lane) {
+  using M = ModeT<BF16>;
   const f32x16 z = hn_transpose_tile(fr, lane);
-  hn_store_tile(z, base, lane, (typename M::Frag*)nullptr);
+  hn_store_tile(z, slot_base + (size_t)t * (M::TILE_UNITS * 1024), lane, (typename M::Frag*)nullptr);
 }
 
 // ReLU masks: one 32-bit word per lane and PAIR of tiles; element i of tile (2d + q) is bit 31 - (16 q + i), and a
@@ -200,12 +231,13 @@ HN_DEV HnOpPtr hn_op_words(const int* ops, int op) {
   return (HnOpPtr)(uintptr_t)(ops + (size_t)op * HN_OP_WORDS);
 }
 
-constexpr int HN_AUXG_MAX = 3;  // generated-feature groups per layer (192 features)
 
 // ------------------------------------------------------------------------------------------------
 // forward machine
 // ------------------------------------------------------------------------------------------------
-template <bool BF16>
+// AUXG: generated-feature groups (64 features each) a layer may have.  Their fragments stay in registers across the
+// layer's tile loop, so the common programs (<= 2 groups) get a build that does not pay for the third.
+template <bool BF16, int AUXG>
 __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_fwd_kernel(const HnMlpArgs a) {
   using M = ModeT<BF16>;
   using Frag = typename M::Frag;
@@ -225,7 +257,6 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 
   Frag cur[8 * M::STEPS32];
   Frag nxt[8 * M::STEPS32];
-  f32x16 accL;
 
   // biases and the feature table live in LDS for the whole kernel: no global loads inside the MFMA loops
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * HN_CHUNK_UNITS * 1024);
@@ -254,17 +285,29 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const float* bias = bias_lds + w[2];
         const bool do_mask = a.training && w[4] >= 0 && wave_valid;
         const bool do_stash = a.training && w[5] >= 0 && wave_valid;
-        Frag aux[HN_AUXG_MAX * 2 * M::STEPS32];
+        char* out_base = do_stash ? hn_slot_base<BF16>(a, w[5], blk) : nullptr;
+        char* aux_base = (a.training && wave_valid) ? hn_slot_base<BF16>(a, w[6], blk) : nullptr;
+        uint32_t* mask_base = nullptr;
+        if (do_mask) {
+          const HnSlot sl = a.slots[w[4]];
+          mask_base = a.masks + sl.off / 4 + (size_t)blk * sl.nt * 64 + lane;
+        }
+        HnOpPtr out_w = nullptr;
+        if (op + 1 < a.n_ops) {
+          const HnOpPtr nw = hn_op_words(a.ops, op + 1);
+          if (nw[0] == HN_OP_OUT) out_w = nw;
+        }
+        Frag aux[AUXG * 2 * M::STEPS32];
 #pragma unroll
-        for (int g = 0; g < HN_AUXG_MAX; ++g) {
+        for (int g = 0; g < AUXG; ++g) {
           if (g < nG) {
             if (flags & HN_LAYER_DIRECT)
               hn_make_group<true>(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, srcv, lane, a, p, ray);
             else
               hn_make_group<false>(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, srcv, lane, a, p, ray);
-            if (a.training && w[6] >= 0 && wave_valid) {
-              hn_stash<BF16>(aux + g * 2 * M::STEPS32, a, w[6], blk, 2 * g, lane);
-              hn_stash<BF16>(aux + (g * 2 + 1) * M::STEPS32, a, w[6], blk, 2 * g + 1, lane);
+            if (aux_base != nullptr) {
+              hn_stash<BF16>(aux + g * 2 * M::STEPS32, aux_base, 2 * g, lane);
+              hn_stash<BF16>(aux + (g * 2 + 1) * M::STEPS32, aux_base, 2 * g + 1, lane);
             }
           }
         }
@@ -276,9 +319,8 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             hn_init_acc(acc, bias, t, h);
             hn_gemm_k<BF16>(acc, cur, K32, ws);
 #pragma unroll
-            for (int g = 0; g < HN_AUXG_MAX; ++g)
+            for (int g = 0; g < AUXG; ++g)
               if (g < nG) hn_gemm_blocks<BF16, 2>(acc, aux + g * 2 * M::STEPS32, ws);
-            accL = acc;
             if (act == HN_ACT_RELU) {
 #pragma unroll
               for (int i = 0; i < 16; ++i) {
@@ -286,16 +328,29 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
                 acc[i] = __int_as_float(max(__float_as_int(acc[i]), 0));  // relu on the bit pattern: one v_max_i32
               }
             }
+            if (out_w != nullptr && t == 0 && h == 0 && valid) {
+              // the OUT op that follows a head layer: <= 4 fp32 columns straight from the accumulator
+              const HnDst d = a.dst[out_w[1]];
+              const int n = out_w[3];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (i < n) {
+                  float y = acc[i];
+                  if (out_w[4] == 1) y = 1.0f / (1.0f + expf(-y));
+                  if (out_w[5] >= 0) {
+                    const HnSrc sr = a.src[out_w[5]];
+                    y = __fadd_rn(sr.ptr[(size_t)(sr.per_ray ? ray : p) * sr.ld + out_w[6] + i], y);
+                  }
+                  d.ptr[(size_t)p * d.ld + out_w[2] + i] = y;
+                }
+              }
+            }
             hn_acc_to_frags(acc, nxt + t * M::STEPS32);
             if ((t & 1) || t == NT - 1) {
-              if (do_mask) {
-                const HnSlot sl = a.slots[w[4]];
-                uint32_t* mp = a.masks + sl.off / 4 + ((size_t)blk * sl.nt + (t >> 1)) * 64 + lane;
-                __builtin_nontemporal_store((t & 1) ? bits : bits << 16, mp);
-              }
+              if (do_mask) __builtin_nontemporal_store((t & 1) ? bits : bits << 16, mask_base + (t >> 1) * 64);
               bits = 0;
             }
-            if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, a, w[5], blk, t, lane);
+            if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, out_base, t, lane);
           }
         }
         if (!(flags & HN_LAYER_NO_COMMIT)) {
@@ -306,22 +361,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
               for (int s = 0; s < M::STEPS32; ++s) cur[t * M::STEPS32 + s] = nxt[t * M::STEPS32 + s];
         }
       } else if (code == HN_OP_OUT) {
-        const int n = w[3];
-        if (h == 0 && valid) {
-          const HnDst d = a.dst[w[1]];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (i < n) {
-              float y = accL[i];
-              if (w[4] == 1) y = 1.0f / (1.0f + expf(-y));
-              if (w[5] >= 0) {
-                const HnSrc s = a.src[w[5]];
-                y = __fadd_rn(s.ptr[(size_t)(s.per_ray ? ray : p) * s.ld + w[6] + i], y);
-              }
-              d.ptr[(size_t)p * d.ld + w[2] + i] = y;
-            }
-          }
-        }
+        // handled inside the LAYER op it follows (the raw accumulator is only alive there)
       } else if (code == HN_OP_OUT_WIDE) {
         const int n = w[3], NT = w[4];
         if (valid) {
@@ -423,7 +463,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
           for (int i = 0; i < 4; ++i) tmp[i] = d[i];             // step q, h==0 <-> feature q
         }
-        if (a.training && w[7] >= 0 && wave_valid) hn_stash<BF16>(tmp, a, w[7], blk, 0, lane);
+        if (a.training && w[7] >= 0 && wave_valid) hn_stash<BF16>(tmp, hn_slot_base<BF16>(a, w[7], blk), 0, lane);
 #pragma unroll
         for (int s = 0; s < M::STEPS32; ++s) {
           if (to2) cur2[s] = tmp[s];
@@ -433,6 +473,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const int n = w[3], NT = w[4];
         const HnSrc s = a.src[w[1]];
         unsigned nbits = 0xffffffffu;  // complement of the mask word: set = keep
+        char* dz_base = (a.training && wave_valid) ? hn_slot_base<BF16>(a, w[7], blk) : nullptr;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           if (t < NT) {
@@ -448,13 +489,14 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
               v[i] = (valid && keep && row < n) ? s.ptr[(size_t)p * s.ld + w[2] + row] : 0.0f;
             }
             hn_acc_to_frags(v, cur + t * M::STEPS32);
-            if (a.training && w[7] >= 0 && wave_valid) hn_stash<BF16>(cur + t * M::STEPS32, a, w[7], blk, t, lane);
+            if (dz_base != nullptr) hn_stash<BF16>(cur + t * M::STEPS32, dz_base, t, lane);
           }
         }
       } else if (code == HN_BOP_LAYER) {
         const int K32 = w[1] & 255, K32b = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
         const bool has_mask = w[4] >= 0;
         const bool do_stash = a.training && w[5] >= 0 && wave_valid;
+        char* dz_base = do_stash ? hn_slot_base<BF16>(a, w[5], blk) : nullptr;
         unsigned nbits = 0xffffffffu;
         unsigned mbits[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // complemented words: set = keep
         if (has_mask) {   // all relu masks of the layer up front: one VMEM wait per layer, none per tile
@@ -477,7 +519,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             for (int i = 0; i < 16; ++i)
               acc[i] = __int_as_float(__float_as_int(acc[i]) & hn_keep_mask(nbits, t & 1, i));
             hn_acc_to_frags(acc, nxt + t * M::STEPS32);
-            if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, a, w[5], blk, t, lane);
+            if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, dz_base, t, lane);
           }
         }
 #pragma unroll
@@ -787,8 +829,9 @@ static void hn_allow_big_lds() {
   if (done) return;
   done = true;
   const int big = 160 * 1024;
-  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -820,6 +863,7 @@ static int hn_check_args(const HnMlpArgs* a) {
   if (a->mode != HN_MODE_BF16 && a->mode != HN_MODE_F32) return -4;
   if (a->n_dsrc < 0 || a->n_dsrc > HN_DSRC_COMPS) return -5;
   if (a->n_bias < 0 || a->n_feat < 0 || a->n_comps < 0 || a->n_comps > HN_MAX_COMPS) return -5;
+  if (a->max_groups < 0 || a->max_groups > 3) return -5;
   if (a->n_comps > 0 && a->comps == nullptr) return -3;
   return 0;
 }
@@ -833,10 +877,14 @@ extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
                      (size_t)((a->n_feat + 1) & ~1) * 8 + (size_t)8 * a->n_comps * 32 * 4;
   if (lds > 150 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
-    hipLaunchKernelGGL(hn_mlp_fwd_kernel<true>, dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
-                       (hipStream_t)stream, *a);
+    if (a->max_groups <= 2)
+      hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 2>), dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
+                         (hipStream_t)stream, *a);
+    else
+      hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 3>), dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
+                         (hipStream_t)stream, *a);
   } else {
-    hipLaunchKernelGGL(hn_mlp_fwd_kernel<false>, dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
+    hipLaunchKernelGGL((hn_mlp_fwd_kernel<false, 3>), dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
                        (hipStream_t)stream, *a);
   }
   HN_CHECK_LAUNCH();

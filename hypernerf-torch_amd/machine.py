@@ -612,6 +612,7 @@ class MlpRunner:
         a.n_ops, a.n_chunks, a.n_dsrc = n_ops, n_chunks, self.prog.n_dsrc if dsrc is not None else 0
         a.ops, a.wstream, a.bias, a.feat = ops.data_ptr(), wstream_ptr, d.bias.data_ptr(), d.feat.data_ptr()
         a.n_bias, a.n_feat = max(32, self.prog.bias_len), max(1, len(self.prog.feat_table))
+        a.max_groups = max([ly.aux.groups for ly in self.prog.layers if ly.aux is not None], default=0)
         a.prof = L.PROF_BUFFER.data_ptr() if L.PROF_BUFFER is not None else 0
         a.comps, a.n_comps = d.comps.data_ptr(), len(self.prog.comp_map)
         a.stash = stash.data_ptr() if stash is not None else 0

@@ -128,7 +128,7 @@ typedef struct {
   int32_t n_dsrc;   /* backward: number of source-gradient components written per point (<=16) */
   int32_t n_bias;   /* floats in `bias` (staged into LDS once per workgroup) */
   int32_t n_feat;   /* entries in `feat` (staged into LDS once per workgroup) */
-  int32_t pad0;
+  int32_t max_groups; /* most feature groups any one layer has (the forward machine is built for <=2 and for 3) */
   const int32_t* ops;    /* device, n_ops * HN_OP_WORDS */
   const void* wstream;   /* device, packed weight units (hn_pack_units) */
   const float* bias;     /* device, packed biases (fp32) */
