@@ -2,6 +2,23 @@
 // See include/hn_kernels.h for the program format and hn_common.h for the register layouts.
 #include "hn_common.h"
 
+// Diagnostic build only (-DHN_PROF): wave 0 of workgroup 0 logs (code, shader clock) pairs into HnMlpArgs.prof.
+#ifdef HN_PROF
+#define HN_STAMP(code)                                                                          \
+  do {                                                                                          \
+    if (prof_on && prof_n < 2040) {                                                             \
+      unsigned long long t__;                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");               \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
+      if (lane == 0) { prof_buf[2 * prof_n] = (code); prof_buf[2 * prof_n + 1] = (long long)t__; } \
+      ++prof_n;                                                                                 \
+    }                                                                                           \
+  } while (0)
+#else
+#define HN_STAMP(code) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // weight stream through LDS (2 x 32 KiB chunks, filled by LDS-DMA, one barrier per chunk)
 // ------------------------------------------------------------------------------------------------
@@ -247,6 +264,11 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   const int r = lane & 31, h = lane >> 5;
   constexpr int PTS = M::WAVES * 32;
   const int ntiles = (a.n_points + PTS - 1) / PTS;
+#ifdef HN_PROF
+  long long* prof_buf = reinterpret_cast<long long*>(a.prof);
+  const bool prof_on = prof_buf != nullptr && blockIdx.x == 0 && wave == 0;
+  int prof_n = 0;
+#endif
 
   WStream<M::WAVES> ws;
   ws.g = reinterpret_cast<const char*>(a.wstream);
@@ -280,6 +302,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
       const HnOpPtr w = hn_op_words(a.ops, op);
       const int code = w[0];
       if (code == HN_OP_LAYER) {
+        HN_STAMP(100 + op);
         const int K32 = w[1] & 255, nG = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
         const int act = (w[1] >> 24) & 15, flags = (w[1] >> 28) & 15;
         const float* bias = bias_lds + w[2];
@@ -312,6 +335,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
           }
         }
         unsigned bits = 0;
+        HN_STAMP(1);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           if (t < NT) {
@@ -321,6 +345,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
             for (int g = 0; g < AUXG; ++g)
               if (g < nG) hn_gemm_blocks<BF16, 2>(acc, aux + g * 2 * M::STEPS32, ws);
+            HN_STAMP(2);
             if (act == HN_ACT_RELU) {
 #pragma unroll
               for (int i = 0; i < 16; ++i) {
@@ -346,11 +371,19 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
               }
             }
             hn_acc_to_frags(acc, nxt + t * M::STEPS32);
+#ifdef HN_PROF
+            if (prof_on) {   // make the stamp wait for the tile's results
+              float x__ = acc[15];
+              asm volatile("v_mov_b32 %0, %0" : "+v"(x__)::"memory");
+            }
+#endif
+            HN_STAMP(3);
             if ((t & 1) || t == NT - 1) {
               if (do_mask) __builtin_nontemporal_store((t & 1) ? bits : bits << 16, mask_base + (t >> 1) * 64);
               bits = 0;
             }
             if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, out_base, t, lane);
+            HN_STAMP(4);
           }
         }
         if (!(flags & HN_LAYER_NO_COMMIT)) {

@@ -3,7 +3,6 @@
 for cfg in "$@"; do
   echo "=== cfg: $cfg"
   env $cfg python -c "import hypernerf_torch_amd._lib as L; L.build(force=True)" || continue
-  env $cfg python tools/kbench.py bf16 2>&1 | grep -E "mlp_|SUM"
-  env $cfg python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | cut -c100-200
+  env $cfg timeout 120 python tools/kbench.py bf16 2>&1 | grep -E "mlp_(forward|backward)\[template_fine|SUM"
 done
 python -c "import hypernerf_torch_amd._lib as L; L.build(force=True)"
