@@ -518,6 +518,85 @@ extern "C" int hn_embed_backward(const float* d_points, int ld, int col0, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// SE(3) exponential-map warp (warping.SE3Field.warp, hypernerf/warping.py:226-238; rigid_body.py:24-83)
+//   theta = |w| ; a = w/theta ; b = v/theta
+//   R = I + sin(theta) [a] + (1 - cos(theta)) [a]^2            (Modern Robotics 3.51)
+//   t = (theta I + (1 - cos(theta)) [a] + (theta - sin(theta)) [a]^2) b      (3.88)
+//   y = R p + t
+// one thread per point; fp32, the same operation order in forward and backward
+// ------------------------------------------------------------------------------------------------
+struct HnV3 { float x, y, z; };
+HN_DEV HnV3 hn_v3(float x, float y, float z) { HnV3 r = {x, y, z}; return r; }
+HN_DEV HnV3 hn_cross(HnV3 a, HnV3 b) { return hn_v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+HN_DEV float hn_dot(HnV3 a, HnV3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+HN_DEV HnV3 hn_add(HnV3 a, HnV3 b) { return hn_v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+HN_DEV HnV3 hn_scale(float s, HnV3 a) { return hn_v3(s * a.x, s * a.y, s * a.z); }
+HN_DEV HnV3 hn_load3(const float* p, size_t i) { return hn_v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+HN_DEV void hn_store3(float* p, size_t i, HnV3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+
+__global__ void hn_se3_forward_kernel(const float* w, const float* v, const float* pts, int n, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const HnV3 wv = hn_load3(w, i), vv = hn_load3(v, i), p = hn_load3(pts, i);
+  const float theta = sqrtf(hn_dot(wv, wv));
+  const HnV3 a = hn_scale(1.0f / theta, wv), b = hn_scale(1.0f / theta, vv);
+  const float s = sinf(theta), c = 1.0f - cosf(theta), d = theta - s;
+  const HnV3 q = hn_cross(a, p), r = hn_cross(a, q), m = hn_cross(a, b), nn = hn_cross(a, m);
+  HnV3 y = hn_add(p, hn_add(hn_scale(s, q), hn_scale(c, r)));
+  y = hn_add(y, hn_add(hn_scale(theta, b), hn_add(hn_scale(c, m), hn_scale(d, nn))));
+  hn_store3(out, i, y);
+}
+
+__global__ void hn_se3_backward_kernel(const float* w, const float* v, const float* pts, const float* gout, int n,
+                                       float* dw, float* dv, float* dp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const HnV3 wv = hn_load3(w, i), vv = hn_load3(v, i), p = hn_load3(pts, i), g = hn_load3(gout, i);
+  const float theta = sqrtf(hn_dot(wv, wv)), inv = 1.0f / theta;
+  const HnV3 a = hn_scale(inv, wv), b = hn_scale(inv, vv);
+  const float sn = sinf(theta), cs = cosf(theta), c = 1.0f - cs, d = theta - sn;
+  const HnV3 q = hn_cross(a, p), r = hn_cross(a, q), m = hn_cross(a, b), nn = hn_cross(a, m);
+  const HnV3 ga = hn_cross(g, a);                  // g x a
+  const HnV3 gaa = hn_cross(ga, a);                // (g x a) x a
+  // y = p + s q + c r + theta b + c m + d n
+  const HnV3 g_p = hn_add(g, hn_add(hn_scale(sn, ga), hn_scale(c, gaa)));
+  const HnV3 g_b = hn_add(hn_scale(theta, g), hn_add(hn_scale(c, ga), hn_scale(d, gaa)));
+  HnV3 g_a = hn_scale(sn, hn_cross(p, g));
+  g_a = hn_add(g_a, hn_scale(c, hn_add(hn_cross(q, g), hn_cross(p, ga))));
+  g_a = hn_add(g_a, hn_scale(c, hn_cross(b, g)));
+  g_a = hn_add(g_a, hn_scale(d, hn_add(hn_cross(m, g), hn_cross(b, ga))));
+  // ds = cos, dc = sin, dd = 1 - cos = c ; the explicit theta of `theta b`
+  float g_theta = cs * hn_dot(q, g) + sn * hn_dot(r, g) + hn_dot(b, g) + sn * hn_dot(m, g) + c * hn_dot(nn, g);
+  // a = w / theta, b = v / theta
+  g_theta -= inv * (hn_dot(g_a, a) + hn_dot(g_b, b));
+  const HnV3 g_w = hn_add(hn_scale(inv, g_a), hn_scale(g_theta, a));   // d theta / d w = a
+  const HnV3 g_v = hn_scale(inv, g_b);
+  if (dw != nullptr) hn_store3(dw, i, g_w);
+  if (dv != nullptr) hn_store3(dv, i, g_v);
+  if (dp != nullptr) hn_store3(dp, i, g_p);
+}
+
+extern "C" int hn_se3_apply_forward(const float* w, const float* v, const float* points, int n_points, float* out,
+                                    hnStream_t stream) {
+  if (n_points <= 0) return -2;
+  if (w == nullptr || v == nullptr || points == nullptr || out == nullptr) return -3;
+  hipLaunchKernelGGL(hn_se3_forward_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, v,
+                     points, n_points, out);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hn_se3_apply_backward(const float* w, const float* v, const float* points, const float* g_out,
+                                     int n_points, float* d_w, float* d_v, float* d_points, hnStream_t stream) {
+  if (n_points <= 0) return -2;
+  if (w == nullptr || v == nullptr || points == nullptr || g_out == nullptr) return -3;
+  hipLaunchKernelGGL(hn_se3_backward_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, v,
+                     points, g_out, n_points, d_w, d_v, d_points);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // hardware layout probe (run once on a real MI355X by tests/test_gpu_probe.py)
 // ------------------------------------------------------------------------------------------------
 __global__ void hn_probe_kernel(float* out_bf16, float* out_f32, float* out_glds, const float* src) {

@@ -344,6 +344,47 @@ def composite(rgb, raw, noise, z, dirs, warped=None, variant=0, white_bg=False, 
 
 
 # --------------------------------------------------------------------------------------------
+# SE(3) exponential-map warp
+# --------------------------------------------------------------------------------------------
+class _Se3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, v, points):
+        L.require_gpu(w, v, points)
+        L.load()
+        w_c, v_c, p_c = (t.detach().reshape(-1, 3).contiguous().float() for t in (w, v, points))
+        n = p_c.shape[0]
+        if w_c.shape[0] != n or v_c.shape[0] != n:
+            raise L.HnError("se3_apply: w, v and points must have the same number of rows")
+        out = torch.empty_like(p_c)
+        L.launch("hn_se3_apply_forward", L.ptr(w_c), L.ptr(v_c), L.ptr(p_c), C.c_int(n), L.ptr(out),
+                 L.stream_handle())
+        ctx.saved = (w_c, v_c, p_c)
+        ctx.shapes = (w.shape, v.shape, points.shape)
+        return out.view(points.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        L.load()
+        w_c, v_c, p_c = ctx.saved
+        g = g.reshape(-1, 3).contiguous()
+        need = ctx.needs_input_grad
+        d_w = torch.empty_like(w_c) if need[0] else None
+        d_v = torch.empty_like(v_c) if need[1] else None
+        d_p = torch.empty_like(p_c) if need[2] else None
+        L.launch("hn_se3_apply_backward", L.ptr(w_c), L.ptr(v_c), L.ptr(p_c), L.ptr(g), C.c_int(p_c.shape[0]),
+                 L.ptr(d_w) if d_w is not None else None, L.ptr(d_v) if d_v is not None else None,
+                 L.ptr(d_p) if d_p is not None else None, L.stream_handle())
+        sw, sv, sp = ctx.shapes
+        return (d_w.view(sw) if d_w is not None else None, d_v.view(sv) if d_v is not None else None,
+                d_p.view(sp) if d_p is not None else None)
+
+
+def se3_apply(w: torch.Tensor, v: torch.Tensor, points: torch.Tensor) -> torch.Tensor:
+    """y = exp([S] theta) . p with theta = |w|, S = (w, v) / theta, per point (reference: warping.py:226-238)."""
+    return _Se3Fn.apply(w, v, points)
+
+
+# --------------------------------------------------------------------------------------------
 # stand-alone positional encoders
 # --------------------------------------------------------------------------------------------
 class _PosencFn(torch.autograd.Function):

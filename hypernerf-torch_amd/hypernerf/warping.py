@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as F
-from ..machine import AuxSpec, GradIn, OutSpec, Program, copy_features, posenc_features
+from ..machine import AuxSpec, GradIn, OutSpec, Program, copy_features, posenc_features, posenc_jax_features
 from . import model_utils, modules
 
 
@@ -80,11 +80,19 @@ class TranslationField(nn.Module):
 
 
 class SE3Field(nn.Module):
-    """SE(3) warp field (reference: hypernerf/warping.py:128-272).
+    """SE(3) warp field (reference: hypernerf/warping.py:128-272) — BASELINE config 5.
 
-    The reference class is never instantiated by its model and its `warp` only "works" for a single point
-    and returns ones.  Construction (sub-modules, state_dict keys, initialisers) follows
-    the reference; `warp` is not wired to the HIP machine yet — parity for it is unpinned upstream.
+    The reference class is never instantiated by its model (`models.py:234` hard-codes TranslationField) and its
+    own `warp` only runs for a single point and then returns ones because of layout bugs in rigid_body
+    (SURVEY.md §8a-19), so there is no reference output to pin: this implements what the code states it computes
+    — posenc (model_utils.py:255-274, quirks included) -> trunk MLP -> w_net / v_net -> exp_se3 -> R p + t, per
+    point, the metadata embedding ignored as upstream does (warping.py:223-224) — and is checked against the
+    oracle's restatement of the same formulas ("parity unpinned").  Use it by assigning
+    `model.warp_field = SE3Field(in_ch=3)`.
+
+    Kernels: the trunk (posenc + 7 layers, >80 % of the field's arithmetic) is one program of the HIP MLP machine;
+    the two 128 -> 128 -> 3 heads are plain library GEMMs (rocBLAS through torch.nn.functional.linear) because both
+    read the same trunk output; the exponential map and the rigid transform are `hn_se3_apply_*`.
     """
 
     def __init__(self, in_ch=1, out_ch=1):
@@ -121,10 +129,37 @@ class SE3Field(nn.Module):
                                  width=self.translation_width, hidden_activation=self.activation,
                                  hidden_norm=self.norm, hidden_init=self.default_init,
                                  output_init=self.translation_init, output_channels=3)
+        self._calls = {}
+
+    def _trunk_call(self, pts_grad: bool) -> F.ProgramCall:
+        call = self._calls.get(pts_grad)
+        if call is None:
+            if pts_grad:
+                raise NotImplementedError("gradient w.r.t. the input points of the warp field is not needed by the "
+                                          "reference's training path and not implemented")
+            aux = AuxSpec(posenc_jax_features(0, range(self.in_ch_pts), self.min_deg, self.max_deg,
+                                              self.use_posenc_identity, pts_grad))
+            layers = modules.mlp_layers(self.trunk, "trunk", aux, None, OutSpec(0, 0, "none", wide=True),
+                                        GradIn(4, 0))
+            call = F.ProgramCall(Program(layers, name="SE3Field.trunk"), [False], [self.trunk_width], [("g", 0)])
+            self._calls[pts_grad] = call
+        return call
+
+    @staticmethod
+    def _head(mlp: "modules.MLP", x: torch.Tensor) -> torch.Tensor:
+        for lin in mlp.linears:
+            x = torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+        return torch.nn.functional.linear(x, mlp.logit_layer.weight, mlp.logit_layer.bias)
 
     def warp(self, points: torch.Tensor, metadata_embed: torch.Tensor, extra_params: Dict[str, Any]):
-        raise NotImplementedError("SE3Field.warp: BASELINE config 5 is scheduled after the translation-field path "
-                                  "(SURVEY.md §8c: no working reference to pin it)")
+        """points (..., 3) -> warped points (..., 3); `metadata_embed` is ignored (reference: warping.py:223-224)."""
+        lead = points.shape[:-1]
+        ge = torch.is_grad_enabled()
+        flat = points.reshape(-1, self.in_ch_pts)
+        (trunk_out,) = F.run_program(self._trunk_call(bool(points.requires_grad and ge)), [flat], 1)
+        w = self._head(self.w_net, trunk_out)
+        v = self._head(self.v_net, trunk_out)
+        return F.se3_apply(w, v, flat.detach() if not (points.requires_grad and ge) else flat).view(*lead, 3)
 
     def forward(self, points, metadata, extra_params, return_jacobian: bool = False):
         out = {'warped_points': self.warp(points, metadata, extra_params)}

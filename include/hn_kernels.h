@@ -278,6 +278,16 @@ int hn_embed_gather(const float* table, const int64_t* idx, int n_rays, int dim,
 int hn_embed_backward(const float* d_points, int ld, int col0, const int64_t* idx, int n_rays,
                       int n_samples, int dim, int n_rows, float* d_table, hnStream_t stream);
 
+/* SE(3) exponential-map warp of warping.SE3Field.warp (hypernerf/warping.py:226-238 with rigid_body.exp_se3,
+ * rigid_body.py:55-83, applied per point): theta = |w|, a = w/theta, b = v/theta,
+ * y = p + sin(theta) a x p + (1-cos(theta)) a x (a x p) + theta b + (1-cos(theta)) a x b + (theta-sin(theta)) a x (a x b).
+ * w, v, points, out: (n_points, 3) fp32 row-major.  The backward writes the gradients w.r.t. w, v and points
+ * (each may be NULL). */
+int hn_se3_apply_forward(const float* w, const float* v, const float* points, int n_points, float* out,
+                         hnStream_t stream);
+int hn_se3_apply_backward(const float* w, const float* v, const float* points, const float* g_out, int n_points,
+                          float* d_w, float* d_v, float* d_points, hnStream_t stream);
+
 /* Debug/probe: runs one MFMA of each kind on identifiable data (layout self-test on real hardware). */
 int hn_probe_mfma(float* out_bf16_acc, float* out_f32_acc, float* out_glds, hnStream_t stream);
 

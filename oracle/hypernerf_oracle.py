@@ -267,7 +267,10 @@ class ModelCfg:
                  noise_std=None, use_warp=True, use_nerf_embed=True, use_alpha_cond=True,
                  use_rgb_cond=False, hyper_slice_method=None, hyper_slice_out_dim=4,
                  GLO_dim=8, share_GLO=True, xyz_fourier_dim=10, hyper_fourier_dim=6,
-                 view_fourier_dim=4):
+                 view_fourier_dim=4, warp_kind="translation"):
+        # warp_kind is not a reference constructor argument: the reference hard-codes TranslationField
+        # (models.py:234); "se3" stands for BASELINE config 5 (`model.warp_field = SE3Field(...)`).
+        self.warp_kind = warp_kind
         self.near, self.far = near, far
         self.nc, self.nf = n_samples_coarse, n_samples_fine
         self.noise_std = noise_std
@@ -305,7 +308,10 @@ def _render_level(p: Params, cfg: ModelCfg, level: str, pts, z, dirs, viewdirs, 
     if not use_warp:
         warped = pts
     else:
-        spatial = translation_field(p, "warp_field", pts, we)              # :495-512
+        if cfg.warp_kind == "se3":
+            spatial = se3_field(p, "warp_field", pts)                      # warping.py:212-240 (unpinned)
+        else:
+            spatial = translation_field(p, "warp_field", pts, we)          # :495-512
         if cfg.slice == "axis_aligned_plane":                              # :533-534
             hyper = he
         elif cfg.slice == "bendy_sheet":                                   # :535-539

@@ -405,3 +405,99 @@ def test_weights_are_repacked_after_fused_optimizer_step(use_arena):
         assert_close(out1_train, ref, 1e-6, "training forward after optimizer step")
     finally:
         HN.set_precision("bf16")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: SE3Field warp + axis-aligned slice ("parity unpinned" upstream: checked against the oracle's
+# restatement of the formulas the reference's code states)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [0.7, 1e-2])
+def test_se3_apply_matches_oracle_exp_map(scale):
+    """hn_se3_apply_forward/backward against torch autograd through oracle.exp_se3 (rigid_body.py:55-83), fp32.
+    Tolerance 1e-4 of the tensor scale (forward) / 1e-3 of the largest gradient entry."""
+    from hypernerf_torch_amd import functional as F
+    n, seed = 777, 31
+    w = H.normal(seed, "se3w", (n, 3)) * scale
+    v = H.normal(seed, "se3v", (n, 3)) * scale
+    pts = H.uniform(seed, "se3p", (n, 3), -1.0, 1.0)
+    g = H.normal(seed, "se3g", (n, 3))
+    wr, vr, pr = (t.clone().requires_grad_(True) for t in (w, v, pts))
+    theta = torch.norm(wr, dim=-1)
+    R, pvec = O.exp_se3(torch.cat([wr / theta[:, None], vr / theta[:, None]], dim=-1), theta)
+    ref = (R @ pr[..., None])[..., 0] + pvec
+    (ref * g).sum().backward()
+    wd, vd, pd = (t.clone().to(DEV).requires_grad_(True) for t in (w, v, pts))
+    out = F.se3_apply(wd, vd, pd)
+    (out * g.to(DEV)).sum().backward()
+    assert_close(out, ref, 1e-4, "se3 warped points")
+    assert_grad_close(wd.grad, wr.grad, 1e-3, "d w")
+    assert_grad_close(vd.grad, vr.grad, 1e-3, "d v")
+    assert_grad_close(pd.grad, pr.grad, 1e-3, "d points")
+
+
+@pytest.mark.gpu
+def test_se3_field_warp_vs_oracle():
+    """SE3Field.warp (trunk on the HIP machine, heads, exp-map kernel) against oracle.se3_field; fp32 <= 1e-4,
+    parameter gradients <= 1e-3 of each tensor's largest entry."""
+    HN.set_precision("fp32")
+    try:
+        f = warping.SE3Field(in_ch=3)
+        sd = load_hash(f, 41)
+        f = f.to(DEV)
+        pts = H.uniform(41, "se3pts", (6, 50, 3), -1.0, 1.0)
+        g = H.normal(41, "se3go", (6, 50, 3))
+        p = {"wf." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = O.se3_field(p, "wf", pts)
+        (ref * g).sum().backward()
+        out = f.warp(pts.to(DEV), None, {"warp_alpha": None})
+        assert out.shape == (6, 50, 3)
+        (out * g.to(DEV)).sum().backward()
+        assert_close(out, ref, 1e-4, "SE3Field.warp")
+        for k, prm in f.named_parameters():
+            assert_grad_close(prm.grad, p["wf." + k].grad, 1e-3, f"SE3Field d {k}")
+        assert set(f(pts.to(DEV), None, {"warp_alpha": None}).keys()) == {"warped_points"}
+    finally:
+        HN.set_precision("bf16")
+
+
+@pytest.mark.gpu
+def test_config5_se3_warp_axis_aligned_model_vs_oracle():
+    """Config 5 end to end: NerfModel with `warp_field = SE3Field(3)` and hyper_slice_method='axis_aligned_plane'
+    against the oracle (fp32, same draws): outputs <= 1e-4, gradients <= 1e-2 of each tensor's largest entry."""
+    HN.set_precision("fp32")
+    try:
+        kw = dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_nerf_embed=False,
+                  use_alpha_cond=False)
+        nc = nf = 16
+        b, seed = 40, 53
+        m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, view_fourier_dim=6, **kw)
+        m.warp_field = warping.SE3Field(in_ch=3)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        sd = H.fill_state_dict(shapes, seed)
+        for k in sd:        # small rigid motions: the template re-encodes warped points with sin(2^9 x)
+            if k.startswith(("warp_field.w_net.logit_layer", "warp_field.v_net.logit_layer")):
+                sd[k] = sd[k] * 0.02
+        m.load_state_dict(sd)
+        m = m.to(DEV)
+        o, d, idx = rays_for(seed, b)
+        rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1),
+               "noise_coarse": H.normal(seed, "n1", (b, nc, 1)) * 0.5,
+               "noise_fine": H.normal(seed, "n2", (b, nc + nf, 1)) * 0.5}
+        cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, view_fourier_dim=6,
+                         warp_kind="se3", **kw)
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = O.nerf_model_forward(p, cfg, o, d, idx, rng)
+        gt = H.uniform(seed, "gt", (b, 3), 0, 1)
+        O.mse_loss(ref, gt).backward()
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        out = m(rays, {}, rng={k: v.to(DEV) for k, v in rng.items()})
+        for k in ("rgb", "depth", "acc", "weights", "warped_points"):
+            assert_close(out["coarse"][k], ref["coarse"][k], 1e-4, f"config5 coarse/{k}")
+        loss = ((out["coarse"]["rgb"] - gt.to(DEV)) ** 2).mean() + ((out["fine"]["rgb"] - gt.to(DEV)) ** 2).mean()
+        loss.backward()
+        for k, prm in m.named_parameters():
+            assert_grad_close(prm.grad, p[k].grad, 1e-2, f"config5 d {k}")
+    finally:
+        HN.set_precision("bf16")
