@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12                             # HBM3E bytes/s, same guide
 
 
 def parse():
@@ -175,24 +176,49 @@ def main():
         progs["TranslationField"] = (macs_per_point(warp_prog), all_pts)
         progs["HyperSheetMLP"] = (macs_per_point(sheet_prog), all_pts)
         flops_per_step = sum(2.0 * m * p for m, p in progs.values())        # per machine kernel and step
+        # the weight-gradient kernel streams every stash tile once: its algorithmic bytes are what its job list reads
+        mode = 1 if a.precision == "bf16" else 0
+        tile_bytes = 2048 if a.precision == "bf16" else 4096
+        prog_of = {"template_coarse": [c for k, c in model._template_calls.items() if k[0] == "coarse"][0].program,
+                   "template_fine": [c for k, c in model._template_calls.items() if k[0] == "fine"][0].program}
+        wgrad_bytes = 0.0
+        for prog, pts_list in ((prog_of["template_coarse"], [b * a.nc]), (prog_of["template_fine"], [b * (a.nc + a.nf)]),
+                               (warp_prog, [b * a.nc, b * (a.nc + a.nf)]), (sheet_prog, [b * a.nc, b * (a.nc + a.nf)])):
+            for pts in pts_list:
+                j = prog.wgrad_jobs(mode, pts)
+                wgrad_bytes += float(((j["n_nt"] + j["n_kt"]).astype("int64") * (j["blk1"] - j["blk0"])).sum()) * tile_bytes
         kern = {}
         for sym in ("hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad"):
-            ks = [k for k in tot if k.startswith(sym + "[")]
+            ks = [k for k in tot if k.startswith(sym + "[") or k.startswith(sym + "_batched[")]
             kern[sym] = (sum(tot[k] for k in ks) / a.steps, sum(len(times[k]) for k in ks) / a.steps)
+        names = {"hn_mlp_forward": "hn_mlp_fwd_kernel", "hn_mlp_backward": "hn_mlp_bwd_kernel",
+                 "hn_mlp_wgrad": "hn_wgrad_kernel"}
+        per_kernel = {}
+        for sym, (ms_step, launches) in kern.items():
+            mf = flops_per_step / (ms_step * 1e-3)
+            e = {"ms_per_step": ms_step, "launches_per_step": launches,
+                 "mfma": {"achieved": mf / 1e12, "peak": PEAK[a.precision] / 1e12, "unit": "TFLOP/s",
+                          "frac": mf / PEAK[a.precision], "algorithmic_flops_per_step": flops_per_step}}
+            if sym == "hn_mlp_wgrad":
+                bw = wgrad_bytes / (ms_step * 1e-3)
+                e["hbm"] = {"achieved": bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bw / HBM_PEAK,
+                            "algorithmic_bytes_per_step": wgrad_bytes}
+            per_kernel[names[sym]] = e
         dom = max(kern, key=lambda k: kern[k][0])
         ms_step, launches = kern[dom]
-        avg_ms = ms_step / launches
-        ach = flops_per_step / (ms_step * 1e-3)
-        res["roofline"] = {"bound": "mfma", "kernel": {"hn_mlp_forward": "hn_mlp_fwd_kernel<true>",
-                                                       "hn_mlp_backward": "hn_mlp_bwd_kernel<true>",
-                                                       "hn_mlp_wgrad": "hn_wgrad_kernel<true>"}[dom]
-                           if a.precision == "bf16" else dom,
-                           "achieved": ach / 1e12, "peak": PEAK[a.precision] / 1e12, "unit": "TFLOP/s",
-                           "frac": ach / PEAK[a.precision], "traffic": None,
-                           "avg_launch_ms": avg_ms, "launches_per_step": launches,
-                           "algorithmic_flops_per_launch": flops_per_step / launches,
-                           "note": "achieved = algorithmic GEMM FLOPs of all launches of this kernel in a step / their "
-                                   "summed HIP-event duration; HBM traffic per launch: profiles/r01_pmc_per_kernel.csv",
+        pk = per_kernel[names[dom]]
+        bound = "hbm" if "hbm" in pk else "mfma"       # the weight-gradient kernel is a pure stream; the others GEMM
+        rl = dict(pk[bound])
+        per_launch = (rl.pop("algorithmic_bytes_per_step", None) or rl.pop("algorithmic_flops_per_step")) / launches
+        res["roofline"] = {"bound": bound, "kernel": names[dom] + ("<true>" if a.precision == "bf16" else "<false>"),
+                           "achieved": rl["achieved"], "peak": rl["peak"], "unit": rl["unit"], "frac": rl["frac"],
+                           "traffic": None, "avg_launch_ms": ms_step / launches, "launches_per_step": launches,
+                           ("algorithmic_bytes_per_launch" if bound == "hbm" else "algorithmic_flops_per_launch"): per_launch,
+                           "note": "dominant kernel by time.  achieved = algorithmic bytes (stash tiles the job list "
+                                   "reads, each once) or GEMM FLOPs of all its launches in a step / their summed "
+                                   "HIP-event duration on the launch stream; measured HBM traffic per launch: "
+                                   "profiles/r01_pmc_per_kernel.csv",
+                           "per_kernel": per_kernel,
                            "kernel_ms_per_step": {k: tot[k] / a.steps for k in sorted(tot, key=tot.get, reverse=True)},
                            "sum_kernel_ms_per_step": sum(tot.values()) / a.steps}
         res["step_tflops"] = 3.0 * flops_per_step / (dt / a.steps) / 1e12

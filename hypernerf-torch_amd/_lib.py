@@ -56,6 +56,14 @@ class HnMlpArgs(C.Structure):
     ]
 
 
+class HnDwBatch(C.Structure):
+    _fields_ = [("jobs", C.c_void_p), ("stash", C.c_void_p), ("grads", C.c_void_p), ("n_jobs", C.c_int32),
+                ("pad", C.c_int32)]
+
+
+HN_MAX_WGRAD_BATCH = 8
+
+
 class HnCompositeArgs(C.Structure):
     _fields_ = [
         ("variant", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("white_bg", C.c_int32),
@@ -80,6 +88,7 @@ DWJOB_DT = np.dtype([("z_off", "<u8"), ("x_off", "<u8"), ("z_nt", "<i4"), ("x_nt
                      ("c_end", "<i4"), ("b_off", "<i4"), ("pad", "<i4")])
 
 EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
+           "hn_mlp_wgrad_batched",
            "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf",
            "hn_embed_gather", "hn_embed_backward", "hn_se3_apply_forward", "hn_se3_apply_backward",
            "hn_probe_mfma"]

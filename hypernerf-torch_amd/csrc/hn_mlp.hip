@@ -701,9 +701,25 @@ HN_DEV void hn_wait_vmcnt(int n) {
 // ONCE by LDS-DMA into a 3-stage ring (a stage = `bps` blocks, <= 32 KiB; 2 stages in flight; counted vmcnt;
 // one raw barrier per stage) and shared by the 8 waves, which own a gn x gk grid of tn x tk (<= 4x2) tile
 // rectangles.  HBM-bound by construction: every stash byte is read exactly once.
+struct HnDwBatchTable {
+  HnDwBatch b[HN_MAX_WGRAD_BATCH];
+  int n;
+};
+
 template <bool BF16>
-__global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwJob* jobs, int n_jobs, const char* stash,
-                                                          float* grads) {
+__global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable tab) {
+  // which batch holds this workgroup's job (<= 8 scalar compares on kernel-argument data)
+  int job_id = blockIdx.x, which = 0;
+#pragma unroll
+  for (int i = 0; i < HN_MAX_WGRAD_BATCH - 1; ++i)
+    if (which == i && i + 1 < tab.n && job_id >= tab.b[i].n_jobs) { job_id -= tab.b[i].n_jobs; which = i + 1; }
+  const HnDwJob* jobs = tab.b[0].jobs;
+  const char* stash = reinterpret_cast<const char*>(tab.b[0].stash);
+  float* grads = tab.b[0].grads;
+  int n_jobs = tab.b[0].n_jobs;
+#pragma unroll
+  for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
+    if (which == i) { jobs = tab.b[i].jobs; stash = reinterpret_cast<const char*>(tab.b[i].stash); grads = tab.b[i].grads; n_jobs = tab.b[i].n_jobs; }
   using M = ModeT<BF16>;
   constexpr int TU = M::TILE_UNITS;
   constexpr size_t TB = TU * 1024;
@@ -711,8 +727,8 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwJob* jobs, i
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if ((int)blockIdx.x >= n_jobs) return;
-  const HnDwJob jb = jobs[blockIdx.x];
+  if (job_id >= n_jobs) return;
+  const HnDwJob jb = jobs[job_id];
   const int c = lane & 31, h = lane >> 5;
   const int gn = jb.pad & 255, gk = (jb.pad >> 8) & 255, bps = (jb.pad >> 16) & 255;
   const int tn = (jb.n_nt + gn - 1) / gn, tk = (jb.n_kt + gk - 1) / gk;   // tiles per wave (<= 4, <= 2)
@@ -853,6 +869,7 @@ extern "C" int hn_abi_sizes(int32_t* out, int n) {
   const int32_t v[8] = {(int32_t)sizeof(HnMlpArgs),      (int32_t)sizeof(HnPackUnit), (int32_t)sizeof(HnPackBias),
                         (int32_t)sizeof(HnDwJob),        (int32_t)sizeof(HnCompositeArgs), (int32_t)sizeof(HnFeat),
                         (int32_t)sizeof(HnSlot),         (int32_t)sizeof(HnSrc)};
+  static_assert(sizeof(HnDwBatch) == 32, "HnDwBatch layout");
   for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   return 8;
 }
@@ -944,22 +961,44 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
   return 0;
 }
 
+static int hn_launch_wgrad(int mode, const HnDwBatchTable& tab, int total, hnStream_t stream) {
+  hn_allow_big_lds();
+  // 4 stages x (<= 16 tiles) : bf16 16 x 2 KiB, fp32 8 x 4 KiB  => 128 KiB
+  const size_t lds = 4 * 32 * 1024;
+  if (mode == HN_MODE_BF16)
+    hipLaunchKernelGGL(hn_wgrad_kernel<true>, dim3(total), dim3(512), lds, (hipStream_t)stream, tab);
+  else if (mode == HN_MODE_F32)
+    hipLaunchKernelGGL(hn_wgrad_kernel<false>, dim3(total), dim3(512), lds, (hipStream_t)stream, tab);
+  else
+    return -2;
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int hn_mlp_wgrad(int mode, const HnDwJob* jobs, int n_jobs, const void* stash, float* grads,
                             hnStream_t stream) {
   if (n_jobs < 0) return -1;
   if (n_jobs == 0) return 0;
   if (jobs == nullptr || stash == nullptr || grads == nullptr) return -3;
-  hn_allow_big_lds();
-  // 3 stages x (<= 16 tiles) : bf16 16 x 2 KiB, fp32 8 x 4 KiB  => 96 KiB
-  const size_t lds = 4 * 32 * 1024;
-  if (mode == HN_MODE_BF16)
-    hipLaunchKernelGGL(hn_wgrad_kernel<true>, dim3(n_jobs), dim3(512), lds, (hipStream_t)stream, jobs, n_jobs,
-                       (const char*)stash, grads);
-  else if (mode == HN_MODE_F32)
-    hipLaunchKernelGGL(hn_wgrad_kernel<false>, dim3(n_jobs), dim3(512), lds, (hipStream_t)stream, jobs, n_jobs,
-                       (const char*)stash, grads);
-  else
-    return -2;
-  HN_CHECK_LAUNCH();
-  return 0;
+  HnDwBatchTable tab = {};
+  tab.b[0].jobs = jobs; tab.b[0].stash = stash; tab.b[0].grads = grads; tab.b[0].n_jobs = n_jobs;
+  tab.n = 1;
+  return hn_launch_wgrad(mode, tab, n_jobs, stream);
+}
+
+extern "C" int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches, int n_batches, hnStream_t stream) {
+  if (n_batches < 0 || n_batches > HN_MAX_WGRAD_BATCH) return -1;
+  if (n_batches > 0 && batches == nullptr) return -3;
+  HnDwBatchTable tab = {};
+  long long total = 0;
+  for (int i = 0; i < n_batches; ++i) {
+    if (batches[i].n_jobs < 0) return -1;
+    if (batches[i].n_jobs == 0) continue;
+    if (batches[i].jobs == nullptr || batches[i].stash == nullptr || batches[i].grads == nullptr) return -3;
+    tab.b[tab.n++] = batches[i];
+    total += batches[i].n_jobs;
+  }
+  if (total == 0) return 0;
+  if (total > 0x7fffffffLL) return -2;
+  return hn_launch_wgrad(mode, tab, (int)total, stream);
 }

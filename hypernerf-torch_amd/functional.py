@@ -13,7 +13,7 @@ import torch
 
 from . import _lib as L
 from .arena import ParamArena
-from .machine import MlpRunner, Program
+from .machine import MlpRunner, PendingWgrad, Program, launch_pending_wgrads
 
 _PRECISION = os.environ.get("HN_PRECISION", "bf16")
 
@@ -100,7 +100,11 @@ class _ProgramFn(torch.autograd.Function):
         wants = [ctx.needs_input_grad[5 + ctx.n_src + j] for j in range(len(prog.params))]
         target = ParamArena.lookup(prog.params) if all(wants) else None
         dsrc, flat = call.runner.backward(ctx.mode, ctx.n_points, ctx.spr, bsrcs, ctx.stash, ctx.masks,
-                                          grad_target=(target[0].grad, target[1]) if target else None)
+                                          grad_target=(target[0].grad, target[1]) if target else None,
+                                          defer=BATCH_WGRADS)
+        if isinstance(flat, PendingWgrad):
+            _defer_wgrad(flat)
+            flat = None
         ctx.stash = ctx.masks = None
         src_grads: List[Optional[torch.Tensor]] = []
         for i, shp in enumerate(ctx.src_shapes):
@@ -132,6 +136,24 @@ class _ProgramFn(torch.autograd.Function):
         pgrads = call.runner.split_grads(flat)
         out_p = [pgrads[j] if wants[j] else None for j in range(len(prog.params))]
         return (None, None, None, None, None, *src_grads, *out_p)
+
+
+# Arena mode: the weight-gradient kernels of all programs of one backward pass run as ONE launch, queued as an
+# autograd end-of-backward callback (they only feed arena.grad, which nothing reads before backward() returns).
+BATCH_WGRADS = True
+_PENDING: List[PendingWgrad] = []
+
+
+def _flush_wgrads():
+    pending = list(_PENDING)
+    _PENDING.clear()
+    launch_pending_wgrads(pending)
+
+
+def _defer_wgrad(p: PendingWgrad):
+    if not _PENDING:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+    _PENDING.append(p)
 
 
 def run_program(call: ProgramCall, srcs: Sequence[Optional[torch.Tensor]], samples_per_ray: int,

@@ -473,9 +473,10 @@ class Program:
         return 2, 4
 
     def wgrad_jobs(self, mode: int, n_points: int, target_jobs: int = 512,
-                   grad_offsets: Optional[Sequence[int]] = None) -> np.ndarray:
+                   grad_offsets: Optional[Sequence[int]] = None, job_bytes: Optional[int] = None) -> np.ndarray:
         """One job per (layer input segment, tile rectangle, block chunk).  The chunks are sized so that the
-        launch is about `target_jobs` workgroups of equal stash bytes (one per CU, a single round)."""
+        launch is about `target_jobs` workgroups of equal stash bytes — or, with `job_bytes`, so that every job
+        streams about that many bytes (the batched launch mixes the jobs of several programs)."""
         offs, _, _ = self.layout(mode, n_points)
         goffs = list(grad_offsets) if grad_offsets is not None else self.grad_offsets()[0]
         nblk = (n_points + 31) // 32
@@ -506,7 +507,11 @@ class Program:
             gn, gk = self._wave_grid(n_nt, n_kt)
             bps = max(1, stage_tiles // (n_nt + n_kt))
             nstage = -(-nblk // bps)
-            share = max(1, min(nstage, round(target_jobs * (n_nt + n_kt) / total_tiles)))
+            if job_bytes is not None:
+                tile_bytes = 2048 if mode == L.HN_MODE_BF16 else 4096
+                share = max(1, min(nstage, round((n_nt + n_kt) * nblk * tile_bytes / job_bytes)))
+            else:
+                share = max(1, min(nstage, round(target_jobs * (n_nt + n_kt) / total_tiles)))
             # split the stages as evenly as possible over `share` jobs
             bounds = [min(nblk, (i * nstage // share) * bps) for i in range(share + 1)]
             bounds[-1] = nblk
@@ -528,6 +533,33 @@ class Program:
 # --------------------------------------------------------------------------------------------
 class _DevTables:
     pass
+
+
+WGRAD_JOB_BYTES = 5 << 20     # stash bytes one job of a batched weight-gradient launch streams (~3 jobs per CU
+                              # and step at config 2; keeps the atomic flushes at a few % of the traffic)
+
+
+class PendingWgrad:
+    """One program's share of a batched weight-gradient launch.  Holds the stash alive until it ran."""
+
+    def __init__(self, mode, jobs_dev, n_jobs, stash, grads):
+        self.mode, self.jobs_dev, self.n_jobs, self.stash, self.grads = mode, jobs_dev, n_jobs, stash, grads
+
+
+def launch_pending_wgrads(pending: Sequence[PendingWgrad]):
+    """hn_mlp_wgrad_batched over the programs of one backward pass (groups of HN_MAX_WGRAD_BATCH per mode)."""
+    by_mode: Dict[int, List[PendingWgrad]] = {}
+    for p in pending:
+        by_mode.setdefault(p.mode, []).append(p)
+    for mode, lst in by_mode.items():
+        lst.sort(key=lambda p: -p.n_jobs)        # the big programs' jobs first
+        for i in range(0, len(lst), L.HN_MAX_WGRAD_BATCH):
+            grp = lst[i:i + L.HN_MAX_WGRAD_BATCH]
+            arr = (L.HnDwBatch * len(grp))()
+            for k, p in enumerate(grp):
+                arr[k].jobs, arr[k].stash, arr[k].grads = p.jobs_dev.data_ptr(), p.stash.data_ptr(), p.grads.data_ptr()
+                arr[k].n_jobs = p.n_jobs
+            L.launch("hn_mlp_wgrad_batched", C.c_int(mode), arr, C.c_int(len(grp)), L.stream_handle(), tag="batched")
 
 
 _OPT_STEPS = [0]
@@ -650,10 +682,12 @@ class MlpRunner:
         L.launch("hn_mlp_forward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         return stash, masks
 
-    def backward(self, mode, n_points, samples_per_ray, srcs, stash, masks, grad_target=None):
+    def backward(self, mode, n_points, samples_per_ray, srcs, stash, masks, grad_target=None, defer=False):
         """Launch backward-data then the weight-gradient kernel.
         grad_target = (flat fp32 buffer, per-parameter offsets): accumulate the weight gradients there (a
-        ParamArena's gradient buffer) instead of into a fresh zero-filled buffer.
+        ParamArena's gradient buffer) instead of into a fresh zero-filled buffer.  With `defer` (and a grad_target)
+        the weight-gradient kernel is NOT launched: a PendingWgrad is returned in place of the gradient buffer,
+        for `launch_pending_wgrads`.
         Returns (dsrc [P, n_dsrc] or None, flat fp32 gradient buffer or None when grad_target was given)."""
         device = stash.device
         d = self._tables(device, mode)       # the streams its forward packed
@@ -664,11 +698,15 @@ class MlpRunner:
                        d.wstream.data_ptr() + d.n_fwd_units * 1024, d.bwd_chunks, srcs, [], stash, masks, dsrc)
         L.launch("hn_mlp_backward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         goffs = tuple(grad_target[1]) if grad_target is not None else None
-        jkey = (str(device), mode, n_points, goffs)
+        deferred = defer and grad_target is not None
+        jkey = (str(device), mode, n_points, goffs, deferred)
         if jkey not in self._jobs:
-            jobs = self.prog.wgrad_jobs(mode, n_points, grad_offsets=goffs)
+            jobs = self.prog.wgrad_jobs(mode, n_points, grad_offsets=goffs,
+                                        job_bytes=WGRAD_JOB_BYTES if deferred else None)
             self._jobs[jkey] = (L.to_device_bytes(jobs, device), len(jobs))
         jobs_dev, n_jobs = self._jobs[jkey]
+        if deferred:        # the caller launches it together with the other programs of this backward pass
+            return dsrc, PendingWgrad(mode, jobs_dev, n_jobs, stash, grad_target[0])
         if grad_target is not None:
             grads, ret = grad_target[0], None
         else:

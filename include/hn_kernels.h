@@ -200,6 +200,19 @@ int hn_mlp_backward(const HnMlpArgs* args, hnStream_t stream);
 int hn_mlp_wgrad(int mode, const HnDwJob* jobs_dev, int n_jobs, const void* stash_dev,
                  float* grad_base_dev, hnStream_t stream);
 
+/* The same for up to HN_MAX_WGRAD_BATCH programs in ONE launch (a training step runs 6 programs; launched one by
+ * one, the small ones cannot fill the chip and every launch pays its own ramp and tail).  Workgroup g works on job
+ * g - first(batch) of the batch that holds it.  `batches` is a HOST array, copied into the kernel arguments. */
+#define HN_MAX_WGRAD_BATCH 8
+typedef struct {
+  const HnDwJob* jobs; /* device */
+  const void* stash;   /* device: the stash the jobs' z_off / x_off refer to */
+  float* grads;        /* device: base the jobs' w_off / b_off refer to */
+  int32_t n_jobs;
+  int32_t pad;
+} HnDwBatch;
+int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches_host, int n_batches, hnStream_t stream);
+
 /* ---- per-ray kernels --------------------------------------------------------------------- */
 
 /* Stratified coarse samples + points.  model_utils.sample_along_rays (hypernerf/model_utils.py:6-41),
