@@ -64,7 +64,9 @@ class _ProgramFn(torch.autograd.Function):
             if s is None:
                 flat_srcs.append(None)
                 continue
-            s2 = s.detach().reshape(-1, s.shape[-1]).contiguous()
+            s2 = s.detach()
+            if s2.dim() != 2 or s2.stride(-1) != 1:          # row-strided 2-D views are read in place (ld = stride)
+                s2 = s2.reshape(-1, s.shape[-1]).contiguous()
             if not per_ray:
                 n_points = s2.shape[0] if n_points is None else n_points
                 if s2.shape[0] != n_points:
@@ -77,6 +79,7 @@ class _ProgramFn(torch.autograd.Function):
         ctx.call, ctx.mode, ctx.spr, ctx.n_src, ctx.n_points = call, mode, samples_per_ray, n_src, n_points
         ctx.flat_srcs = flat_srcs
         ctx.src_shapes = [None if s is None else s.shape for s in srcs]
+        ctx.src_tags = [None if s is None else getattr(s, "_hn_embed", None) for s in srcs]
         ctx.stash, ctx.masks = stash, masks
         ctx.outs = outs
         return tuple(outs)
@@ -92,7 +95,7 @@ class _ProgramFn(torch.autograd.Function):
                 g = gouts[k]
                 if g is None:
                     g = torch.zeros_like(ctx.outs[k])
-                bsrcs.append((g.contiguous(), False))
+                bsrcs.append((g if (g.dim() == 2 and g.stride(-1) == 1) else g.contiguous(), False))
             else:
                 bsrcs.append((ctx.outs[k], False))
         # parameters attached to a ParamArena: accumulate into its gradient buffer, return nothing through autograd
@@ -118,6 +121,9 @@ class _ProgramFn(torch.autograd.Function):
             width = shp[-1]
             if call.src_per_ray[i]:
                 n_rays = ctx.n_points // ctx.spr
+                if _scatter_embed_grad(ctx.src_tags[i], dsrc, cols, n_rays, ctx.spr, width):
+                    src_grads.append(None)       # went straight into the embedding table's arena gradient
+                    continue
                 g = sum_samples(dsrc, cols, n_rays, ctx.spr, width)
             else:
                 key = ("colidx", i)
@@ -227,7 +233,31 @@ class _EmbedFn(torch.autograd.Function):
 
 
 def embed_lookup(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-    return _EmbedFn.apply(table, idx)
+    out = _EmbedFn.apply(table, idx)
+    # lets a program that consumes this per-ray embedding send its gradient straight to the table (see
+    # _scatter_embed_grad); ordinary autograd through _EmbedFn.backward stays valid for every other consumer
+    out._hn_embed = (table, idx.reshape(-1).to(torch.int64))
+    return out
+
+
+def _scatter_embed_grad(tag, d_points, cols, n_rays, n_samples, width) -> bool:
+    """d_table[idx[b], c] += sum_s d_points[b*S + s, slot(c)] in ONE kernel, when the per-ray source is the output
+    of embed_lookup on a table that lives in a ParamArena and all `width` components form one run of slots.
+    Replaces a per-ray reduction (+ zero fill) followed by the scatter-add of _EmbedFn.backward."""
+    if tag is None:
+        return False
+    table, idx = tag
+    if not isinstance(table, torch.nn.Parameter) or ParamArena.lookup([table]) is None:
+        return False
+    items = sorted(cols.items())
+    if len(items) != width or width != table.shape[1] or idx.numel() != n_rays:
+        return False
+    if any(c != k or s != items[0][1] + k for k, (c, s) in enumerate(items)):
+        return False
+    L.launch("hn_embed_backward", L.ptr(d_points), C.c_int(d_points.shape[1]), C.c_int(items[0][1]), L.ptr(idx),
+             C.c_int(n_rays), C.c_int(n_samples), C.c_int(width), C.c_int(table.shape[0]), L.ptr(table.grad),
+             L.stream_handle())
+    return True
 
 
 # --------------------------------------------------------------------------------------------

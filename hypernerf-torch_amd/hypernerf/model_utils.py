@@ -111,7 +111,7 @@ def prepare_ray_dict(rays: torch.Tensor) -> dict:
     idx = torch.ones((b, 1), dtype=torch.long, device=rays.device)
     if use_meta:
         idx = rays[:, 8].type(torch.long)
-    metadata = {k: idx.clone() for k in ('warp', 'camera', 'appearance', 'time')}
+    metadata = {k: idx for k in ('warp', 'camera', 'appearance', 'time')}     # read-only downstream: one tensor
     return {"origins": rays[:, :3], "directions": rays[:, 3:6], "viewdirs": None, "metadata": metadata}
 
 

@@ -136,7 +136,10 @@ class GLOEmbed(nn.Module):
         if inputs.shape[-1] == 1:
             inputs = torch.squeeze(inputs, dim=-1)
         out = F.embed_lookup(self.embed.weight, inputs)
-        return out.view(*inputs.shape, self.embedding_dim)
+        res = out.view(*inputs.shape, self.embedding_dim)
+        if res.dim() == 2:
+            res._hn_embed = out._hn_embed      # the view carries the tag (functional._scatter_embed_grad)
+        return res
 
 
 def nerf_mlp_layers(m: "NerfMLP", prefix: str, input_aux: AuxSpec, alpha_aux: Optional[AuxSpec],
