@@ -121,7 +121,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
            "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    for macro in ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS"):          # build-time tuning knobs (A/B experiments)
+    for macro in ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX"):          # build-time tuning knobs (A/B experiments)
         if os.environ.get(macro):
             cmd.insert(1, f"-D{macro}={os.environ[macro]}")
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -786,8 +786,12 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     for (int i = 0; i < MAXSLOT; ++i) {
       if ((sinfo[i] >> 1) < nblk_s) {
         const char* src = stash + sbase[i] + (unsigned long long)b0 * ((sinfo[i] & 1) ? zstride : xstride);
+#ifndef HN_WGRAD_AUX
+#define HN_WGRAD_AUX 2      /* nt: every stash byte is read once, do not keep it in L2 / MALL */
+#endif
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0,
+                                         HN_WGRAD_AUX);
       }
     }
   };
