@@ -247,6 +247,20 @@ typedef const __attribute__((address_space(4))) int* HnOpPtr;
 HN_DEV HnOpPtr hn_op_words(const int* ops, int op) {
   return (HnOpPtr)(uintptr_t)(ops + (size_t)op * HN_OP_WORDS);
 }
+// the 8 words of one op in scalar registers; the words of op+1 are fetched at the START of op (one s_load_dwordx8
+// whose latency hides behind the layer) instead of at the top of the next iteration, where nothing could hide it
+struct HnOpWords {
+  int v[HN_OP_WORDS];
+  HN_DEV int operator[](int i) const { return v[i]; }
+};
+HN_DEV HnOpWords hn_load_op(const int* ops, int op, int n_ops) {
+  HnOpWords w;
+  const HnOpPtr p = hn_op_words(ops, op < n_ops ? op : n_ops - 1);
+#pragma unroll
+  for (int i = 0; i < HN_OP_WORDS; ++i) w.v[i] = p[i];
+  if (op >= n_ops) w.v[0] = -1;     // no such op
+  return w;
+}
 
 
 // ------------------------------------------------------------------------------------------------
@@ -298,8 +312,10 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
     hn_stage_sources(srcv, a, p, ray, lane);
     ws.start();
 
+    HnOpWords w_next = hn_load_op(a.ops, 0, a.n_ops);
     for (int op = 0; op < a.n_ops; ++op) {
-      const HnOpPtr w = hn_op_words(a.ops, op);
+      const HnOpWords w = w_next;
+      w_next = hn_load_op(a.ops, op + 1, a.n_ops);
       const int code = w[0];
       if (code == HN_OP_LAYER) {
         HN_STAMP(100 + op);
@@ -315,11 +331,8 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
           const HnSlot sl = a.slots[w[4]];
           mask_base = a.masks + sl.off / 4 + (size_t)blk * sl.nt * 64 + lane;
         }
-        HnOpPtr out_w = nullptr;
-        if (op + 1 < a.n_ops) {
-          const HnOpPtr nw = hn_op_words(a.ops, op + 1);
-          if (nw[0] == HN_OP_OUT) out_w = nw;
-        }
+        const bool has_out = w_next[0] == HN_OP_OUT;    // head layer: its <=4 outputs leave from the accumulator
+        const HnOpWords out_w = w_next;
         Frag aux[AUXG * 2 * M::STEPS32];
 #pragma unroll
         for (int g = 0; g < AUXG; ++g) {
@@ -353,7 +366,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
                 acc[i] = __int_as_float(max(__float_as_int(acc[i]), 0));  // relu on the bit pattern: one v_max_i32
               }
             }
-            if (out_w != nullptr && t == 0 && h == 0 && valid) {
+            if (has_out && t == 0 && h == 0 && valid) {
               // the OUT op that follows a head layer: <= 4 fp32 columns straight from the accumulator
               const HnDst d = a.dst[out_w[1]];
               const int n = out_w[3];
@@ -465,8 +478,10 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
     hn_stage_sources(srcv, a, p, ray, lane);
     ws.start();
 
+    HnOpWords w_next = hn_load_op(a.ops, 0, a.n_ops);
     for (int op = 0; op < a.n_ops; ++op) {
-      const HnOpPtr w = hn_op_words(a.ops, op);
+      const HnOpWords w = w_next;
+      w_next = hn_load_op(a.ops, op + 1, a.n_ops);
       const int code = w[0];
       if (code == HN_BOP_LOAD) {
         // dZ (<= 4 columns) of an output layer -> one 32-feature tile

@@ -15,6 +15,8 @@ Vocabulary
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from dataclasses import dataclass, field
@@ -535,7 +537,7 @@ class _DevTables:
     pass
 
 
-WGRAD_JOB_BYTES = 5 << 20     # stash bytes one job of a batched weight-gradient launch streams (~3 jobs per CU
+WGRAD_JOB_BYTES = int(float(os.environ.get("HN_WGRAD_JOB_MB", 5)) * (1 << 20))     # stash bytes one job of a batched weight-gradient launch streams (~3 jobs per CU
                               # and step at config 2; keeps the atomic flushes at a few % of the traffic)
 
 
