@@ -518,6 +518,59 @@ extern "C" int hn_embed_backward(const float* d_points, int ld, int col0, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// On-device ray generation (datasets/ray_utils.py:5-93 + the row layout of datasets/llff.py:244-264):
+// pixel (col i, row j) -> camera direction ((i - W/2)/f, -(j - H/2)/f, -1) -> world (c2w 3x4) -> normalised;
+// origin = c2w[:, 3]; optional NDC transform (near plane 1.0 in the reference's call); one thread per pixel writes
+// the whole (8|9)-float ray row [o, d, near, far(, image id)] — 36 B/pixel, HBM bound.
+// ------------------------------------------------------------------------------------------------
+__global__ void hn_generate_rays_kernel(int H, int W, float focal, const float* c2w, int ndc, float ndc_near,
+                                        float near, float far, float image_id, int row_floats, float* rays) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= H * W) return;
+  const int j = pix / W, i = pix - j * W;
+  const float dx = __fdiv_rn(__fsub_rn((float)i, __fdiv_rn((float)W, 2.0f)), focal);
+  const float dy = -__fdiv_rn(__fsub_rn((float)j, __fdiv_rn((float)H, 2.0f)), focal);
+  const float dz = -1.0f;
+  float d[3], o[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    d[k] = __fadd_rn(__fadd_rn(__fmul_rn(dx, c2w[4 * k]), __fmul_rn(dy, c2w[4 * k + 1])), __fmul_rn(dz, c2w[4 * k + 2]));
+    o[k] = c2w[4 * k + 3];
+  }
+  const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = __fdiv_rn(d[k], nrm);
+  if (ndc) {   // get_ndc_rays, ray_utils.py:52-93
+    const float t = __fdiv_rn(-__fadd_rn(ndc_near, o[2]), d[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = __fadd_rn(o[k], __fmul_rn(t, d[k]));
+    const float ox_oz = __fdiv_rn(o[0], o[2]), oy_oz = __fdiv_rn(o[1], o[2]);
+    const float sx = __fdiv_rn(-1.0f, __fdiv_rn((float)W, __fmul_rn(2.0f, focal)));
+    const float sy = __fdiv_rn(-1.0f, __fdiv_rn((float)H, __fmul_rn(2.0f, focal)));
+    const float o0 = __fmul_rn(sx, ox_oz), o1 = __fmul_rn(sy, oy_oz);
+    const float o2 = __fadd_rn(1.0f, __fdiv_rn(__fmul_rn(2.0f, ndc_near), o[2]));
+    const float d0 = __fmul_rn(sx, __fsub_rn(__fdiv_rn(d[0], d[2]), ox_oz));
+    const float d1 = __fmul_rn(sy, __fsub_rn(__fdiv_rn(d[1], d[2]), oy_oz));
+    const float d2 = __fsub_rn(1.0f, o2);
+    o[0] = o0; o[1] = o1; o[2] = o2; d[0] = d0; d[1] = d1; d[2] = d2;
+  }
+  float* r = rays + (size_t)pix * row_floats;
+  r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = d[0]; r[4] = d[1]; r[5] = d[2]; r[6] = near; r[7] = far;
+  if (row_floats > 8) r[8] = image_id;
+}
+
+extern "C" int hn_generate_rays(int H, int W, float focal, const float* c2w, int ndc, float ndc_near, float near,
+                                float far, float image_id, int row_floats, float* rays, hnStream_t stream) {
+  if (H <= 0 || W <= 0 || !(focal > 0.0f) || (row_floats != 8 && row_floats != 9)) return -2;
+  if (c2w == nullptr || rays == nullptr) return -3;
+  const int n = H * W;
+  hipLaunchKernelGGL(hn_generate_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, focal,
+                     c2w, ndc, ndc_near, near, far, image_id, row_floats, rays);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // SE(3) exponential-map warp (warping.SE3Field.warp, hypernerf/warping.py:226-238; rigid_body.py:24-83)
 //   theta = |w| ; a = w/theta ; b = v/theta
 //   R = I + sin(theta) [a] + (1 - cos(theta)) [a]^2            (Modern Robotics 3.51)

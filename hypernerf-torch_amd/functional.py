@@ -396,6 +396,26 @@ def composite(rgb, raw, noise, z, dirs, warped=None, variant=0, white_bg=False, 
 
 
 # --------------------------------------------------------------------------------------------
+# on-device ray generation
+# --------------------------------------------------------------------------------------------
+def generate_rays(h: int, w: int, focal: float, c2w: torch.Tensor, near: float, far: float, ndc: bool = False,
+                  ndc_near: float = 1.0, image_id: Optional[int] = None) -> torch.Tensor:
+    """(h*w, 8|9) ray rows [o, d, near, far(, image id)] of one image, generated on the GPU
+    (reference: datasets/ray_utils.py get_ray_directions / get_rays / get_ndc_rays, datasets/llff.py:244-264)."""
+    L.require_gpu(c2w)
+    L.load()
+    if tuple(c2w.shape) != (3, 4):
+        raise L.HnError("c2w must be (3, 4)")
+    c = c2w.detach().contiguous().float()
+    cols = 9 if image_id is not None else 8
+    rays = torch.empty(h * w, cols, dtype=torch.float32, device=c2w.device)
+    L.launch("hn_generate_rays", C.c_int(h), C.c_int(w), C.c_float(focal), L.ptr(c), C.c_int(int(ndc)),
+             C.c_float(ndc_near), C.c_float(near), C.c_float(far), C.c_float(float(image_id or 0)), C.c_int(cols),
+             L.ptr(rays), L.stream_handle())
+    return rays
+
+
+# --------------------------------------------------------------------------------------------
 # SE(3) exponential-map warp
 # --------------------------------------------------------------------------------------------
 class _Se3Fn(torch.autograd.Function):

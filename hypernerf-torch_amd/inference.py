@@ -1,0 +1,72 @@
+"""Evaluation-side drivers of the render path (reference: eval.py:77-101 `batched_inference`, the image assembly of
+eval.py:139-166 and train.py:166-182).
+
+`batched_inference` keeps the reference's signature and result (every per-level tensor concatenated over chunks).
+`render_image` is what an MI355X wants instead: it keeps only the per-ray outputs an image needs (the (B,S,7) point
+tensors the reference also concatenates are pure HBM traffic), uses chunks that fill the GPU, and shards the rays
+of the image over the ranks of a data-parallel job (one all-gather of pixels, dist.all_gather_pixels).
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Dict, Sequence
+
+import torch
+
+from . import dist as hdist
+from .hypernerf import model_utils
+
+_EXTRA = {'nerf_alpha': None, 'warp_alpha': None, 'hyper_alpha': None, 'hyper_sheet_alpha': None}
+
+
+@torch.no_grad()
+def batched_inference(model, rays_dict, N_samples=None, N_importance=None, use_disp=False, chunk=1024 * 32,
+                      white_back=False) -> Dict:
+    """Render all rays of `rays_dict` in chunks of `chunk` rays and concatenate every output.  N_samples,
+    N_importance, use_disp and white_back are accepted and ignored exactly as the reference ignores them (the model
+    carries those settings); unlike the reference, `chunk` is honoured (eval.py:84 overwrites it with 1024)."""
+    n = rays_dict["origins"].shape[0]
+    pieces = defaultdict(list)
+    for start in range(0, n, chunk):
+        out = model(model_utils.extract_rays_batch(rays_dict, start, start + chunk), dict(_EXTRA))
+        for level, tensors in out.items():
+            pieces[level].append(tensors)
+    return {level: model_utils.concat_ray_batch(chunks) for level, chunks in pieces.items()}
+
+
+@torch.no_grad()
+def render_image(model, rays: torch.Tensor, chunk: int = 16384, level: str = 'fine',
+                 keys: Sequence[str] = ('rgb', 'depth', 'acc'), group=None) -> Dict[str, torch.Tensor]:
+    """rays (N, 8|9) of one image -> {key: (N, ...)} for the requested per-ray outputs of `level`.
+    With torch.distributed initialised every rank renders a contiguous 1/world slice and the pixels are gathered
+    with one all-gather per key (slices are padded to equal length)."""
+    n = rays.shape[0]
+    world = torch.distributed.get_world_size(group) if hdist.dist.is_available() and hdist.dist.is_initialized() else 1
+    rank = torch.distributed.get_rank(group) if world > 1 else 0
+    lo, hi = hdist.shard_range(n, rank, world)
+    per = -(-n // world)                                  # padded slice length, equal on all ranks
+    mine = rays[lo:hi]
+    outs = {k: [] for k in keys}
+    for start in range(0, mine.shape[0], chunk):
+        rd = model_utils.prepare_ray_dict(mine[start:start + chunk])
+        res = model(rd, dict(_EXTRA))[level]
+        for k in keys:
+            outs[k].append(res[k])
+    result = {}
+    for k in keys:
+        if outs[k]:
+            x = torch.cat(outs[k], dim=0)
+        else:       # a rank without rays (more ranks than rays): shape from a zero-length template
+            x = torch.zeros((0, 3) if k == 'rgb' else (0,), dtype=torch.float32, device=rays.device)
+        if world > 1:
+            pad = per - x.shape[0]
+            if pad:
+                x = torch.cat([x, x.new_zeros((pad,) + tuple(x.shape[1:]))], dim=0)
+            full = hdist.all_gather_pixels(x, group)
+            parts = []
+            for r in range(world):
+                a, b = hdist.shard_range(n, r, world)
+                parts.append(full[r * per:r * per + (b - a)])
+            x = torch.cat(parts, dim=0)
+        result[k] = x
+    return result

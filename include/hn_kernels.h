@@ -291,6 +291,13 @@ int hn_embed_gather(const float* table, const int64_t* idx, int n_rays, int dim,
 int hn_embed_backward(const float* d_points, int ld, int col0, const int64_t* idx, int n_rays,
                       int n_samples, int dim, int n_rows, float* d_table, hnStream_t stream);
 
+/* All rays of one H x W image on the device: get_ray_directions + get_rays (+ get_ndc_rays when `ndc`)
+ * (datasets/ray_utils.py:5-93) and the ray-row layout of datasets/llff.py:244-264:
+ * rays[(j*W + i)] = [origin(3), direction(3), near, far(, image_id)], row_floats = 8 or 9.
+ * c2w: (3,4) row-major fp32 on the device.  `ndc_near` is get_ndc_rays' near plane (the reference passes 1.0). */
+int hn_generate_rays(int H, int W, float focal, const float* c2w_dev, int ndc, float ndc_near, float near,
+                     float far, float image_id, int row_floats, float* rays_dev, hnStream_t stream);
+
 /* SE(3) exponential-map warp of warping.SE3Field.warp (hypernerf/warping.py:226-238 with rigid_body.exp_se3,
  * rigid_body.py:55-83, applied per point): theta = |w|, a = w/theta, b = v/theta,
  * y = p + sin(theta) a x p + (1-cos(theta)) a x (a x p) + theta b + (1-cos(theta)) a x b + (theta-sin(theta)) a x (a x b).

@@ -529,3 +529,47 @@ def se3_field(p: Params, prefix: str, pts: Tensor, min_deg=0, max_deg=8):
     v = v / theta[..., None]
     R, pvec = exp_se3(torch.cat([w, v], dim=-1), theta)
     return (R @ pts[..., None])[..., 0] + pvec
+
+
+# --------------------------------------------------------------------------------------------
+# ray generation (datasets/ray_utils.py) — SURVEY.md §8 f2
+# --------------------------------------------------------------------------------------------
+def ray_directions(H: int, W: int, focal: float) -> Tensor:
+    """get_ray_directions, datasets/ray_utils.py:5-25.  kornia.create_meshgrid(H, W, normalized_coordinates=False)
+    (third-party, absent here: pixel-index grid, x = column, y = row) is restated with torch.meshgrid."""
+    j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    return torch.stack([(i - W / 2) / focal, -(j - H / 2) / focal, -torch.ones_like(i)], -1)
+
+
+def rays_from_pose(directions: Tensor, c2w: Tensor):
+    """get_rays, datasets/ray_utils.py:28-49."""
+    d = directions @ c2w[:, :3].T
+    d = d / torch.norm(d, dim=-1, keepdim=True)
+    o = c2w[:, 3].expand(d.shape)
+    return o.reshape(-1, 3), d.reshape(-1, 3)
+
+
+def ndc_rays(H: int, W: int, focal: float, near: float, rays_o: Tensor, rays_d: Tensor):
+    """get_ndc_rays, datasets/ray_utils.py:52-93."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    ox_oz = rays_o[..., 0] / rays_o[..., 2]
+    oy_oz = rays_o[..., 1] / rays_o[..., 2]
+    o0 = -1. / (W / (2. * focal)) * ox_oz
+    o1 = -1. / (H / (2. * focal)) * oy_oz
+    o2 = 1. + 2. * near / rays_o[..., 2]
+    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - ox_oz)
+    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - oy_oz)
+    d2 = 1 - o2
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+def image_rays(H: int, W: int, focal: float, c2w: Tensor, near: float, far: float, ndc: bool, image_id=None):
+    """The (H*W, 8|9) ray rows datasets/llff.py:244-264 builds for one image."""
+    o, d = rays_from_pose(ray_directions(H, W, focal), c2w)
+    if ndc:
+        o, d = ndc_rays(H, W, focal, 1.0, o, d)
+    cols = [o, d, near * torch.ones_like(o[:, :1]), far * torch.ones_like(o[:, :1])]
+    if image_id is not None:
+        cols.append(float(image_id) * torch.ones_like(o[:, :1]))
+    return torch.cat(cols, 1)

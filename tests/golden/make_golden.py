@@ -430,9 +430,36 @@ def g_misc():
          psnr_f=-10 * torch.log10(mse))
 
 
+def g_rays():
+    """datasets/ray_utils.py.  kornia is absent: its create_meshgrid(H, W,
+    normalized_coordinates=False) — a (1,H,W,2) grid of pixel indices, x (column) first — is stubbed."""
+    k = types.ModuleType("kornia")
+
+    def create_meshgrid(h, w, normalized_coordinates=True):
+        assert not normalized_coordinates
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32),
+                                indexing="ij")
+        return torch.stack([xs, ys], -1)[None]
+    k.create_meshgrid = create_meshgrid
+    sys.modules["kornia"] = k
+    import importlib.util          # the file itself: datasets/__init__.py pulls torchvision / PIL datasets in
+    spec = importlib.util.spec_from_file_location("ref_ray_utils", os.path.join(REF, "datasets", "ray_utils.py"))
+    R_rays = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R_rays)
+    hh, ww, focal = 6, 9, 7.25
+    dirs = R_rays.get_ray_directions(hh, ww, focal)
+    rot = H.normal(15, "rot", (3, 3))
+    q, _ = torch.linalg.qr(rot)
+    c2w = torch.cat([q, H.uniform(15, "pos", (3, 1), -0.5, 0.5) + torch.tensor([[0.0], [0.0], [2.0]])], 1)
+    o, d = R_rays.get_rays(dirs, c2w)
+    no, nd = R_rays.get_ndc_rays(hh, ww, focal, 1.0, o, d)
+    save("g15_rays", H=np.int64(hh), W=np.int64(ww), focal=np.float32(focal), c2w=c2w, directions=dirs,
+         rays_o=o, rays_d=d, ndc_o=no, ndc_d=nd)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["posenc", "mlp", "glo", "fields", "sample", "volrend", "pdf",
-                             "model", "legacy", "misc"]
+                             "model", "legacy", "misc", "rays"]
     for w in which:
         print("golden:", w)
         globals()["g_" + w]()

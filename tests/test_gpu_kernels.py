@@ -169,3 +169,26 @@ def test_cpu_tensor_fails_loudly():
     o, d, _ = rays_for(1, 4)
     with pytest.raises(L.HnError):
         MU.sample_along_rays(o, d, 8, 0.0, 1.0, True, False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndc", [False, True])
+def test_generate_rays_vs_golden_and_oracle(golden_dir, ndc):
+    """hn_generate_rays against the reference's own ray_utils outputs (tests/golden/g15_rays.npz) and, at a real
+    image size, against the oracle.  Tolerance 2e-6 of the tensor scale (3-term dot products in a different order)."""
+    import numpy as np
+    from hypernerf_torch_amd import functional as F
+    from oracle import hypernerf_oracle as O
+    g = np.load(os.path.join(golden_dir, "g15_rays.npz"))
+    hh, ww, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    c2w = torch.from_numpy(g["c2w"])
+    rays = F.generate_rays(hh, ww, focal, c2w.to(DEV), near=0.0, far=1.0, ndc=ndc, image_id=5)
+    assert rays.shape == (hh * ww, 9)
+    ro, rd = (g["ndc_o"], g["ndc_d"]) if ndc else (g["rays_o"], g["rays_d"])
+    assert_close(rays[:, 0:3], torch.from_numpy(ro), 2e-6, "origins")
+    assert_close(rays[:, 3:6], torch.from_numpy(rd), 2e-6, "directions")
+    assert torch.equal(rays[:, 6:9].cpu(), torch.tensor([0.0, 1.0, 5.0]).expand(hh * ww, 3))
+    big = F.generate_rays(378, 504, 407.5, c2w.to(DEV), near=0.2, far=1.5, ndc=ndc)
+    ref = O.image_rays(378, 504, 407.5, c2w, 0.2, 1.5, ndc)
+    assert big.shape == ref.shape == (378 * 504, 8)
+    assert_close(big, ref, 2e-6, "full image rays")

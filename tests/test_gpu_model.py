@@ -6,6 +6,7 @@ max|a-b| <= 1e-4 * max(1, max|ref|) per tensor.  bf16 mode (bf16 operands, fp32 
 outputs — bf16 has 8 significand bits and the template stacks 14 layers; its acceptance criterion is PSNR
 (bench.py reports the bf16-vs-fp32 PSNR gap), this test only guards against structural errors."""
 import glob
+import math
 import os
 
 import numpy as np
@@ -501,3 +502,57 @@ def test_config5_se3_warp_axis_aligned_model_vs_oracle():
             assert_grad_close(prm.grad, p[k].grad, 1e-2, f"config5 d {k}")
     finally:
         HN.set_precision("bf16")
+
+
+@pytest.mark.gpu
+def test_batched_inference_and_render_image_match_one_shot():
+    """eval.py's chunk loop: chunked rendering == one forward over all rays (deterministic sampling), reference
+    result layout for batched_inference, requested keys only for render_image."""
+    from hypernerf_torch_amd.inference import batched_inference, render_image
+    HN.set_precision("fp32")
+    try:
+        m = models.NerfModel(EMB, n_samples_coarse=16, n_samples_fine=16, noise_std=None, view_fourier_dim=6,
+                             **CASES["bendy_cond"])
+        load_hash(m, 17)
+        m = m.to(DEV).eval()
+        m.use_stratified_sampling = False
+        o, d, idx = rays_for(17, 100)
+        rays = torch.cat([o, d, torch.zeros(100, 1), torch.ones(100, 1), idx.float()[:, None]], dim=1).to(DEV)
+        from hypernerf_torch_amd.hypernerf import model_utils as MU
+        with torch.no_grad():
+            ref = m(MU.prepare_ray_dict(rays), {})
+        res = batched_inference(m, MU.prepare_ray_dict(rays), 16, 16, False, 32, False)
+        assert set(res) == {"coarse", "fine"} and set(res["fine"]) == set(ref["fine"])
+        for lvl in ("coarse", "fine"):
+            for k in ("rgb", "depth", "acc", "weights", "points", "warped_points"):
+                assert res[lvl][k].shape == ref[lvl][k].shape, (lvl, k)
+                assert_close(res[lvl][k], ref[lvl][k], 1e-6, f"chunked {lvl}/{k}")
+        img = render_image(m, rays, chunk=48, keys=("rgb", "depth"))
+        assert set(img) == {"rgb", "depth"} and img["rgb"].shape == (100, 3)
+        assert_close(img["rgb"], ref["fine"]["rgb"], 1e-6, "render_image rgb")
+        assert_close(img["depth"], ref["fine"]["depth"], 1e-6, "render_image depth")
+    finally:
+        HN.set_precision("bf16")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_step_harness(use_graph):
+    """training.TrainStep (reference: train.py training_step): loss falls on a fixed batch, the log has the
+    reference's keys, graph replay and eager stepping agree on the first logged loss."""
+    from hypernerf_torch_amd.training import TrainStep
+    HN.set_precision("bf16")
+    torch.manual_seed(3)
+    m = models.NerfModel(EMB, n_samples_coarse=32, n_samples_fine=32, noise_std=1.0, view_fourier_dim=6,
+                         **CASES["bendy_cond"]).to(DEV)
+    o, d, idx = rays_for(23, 256)
+    rays = torch.cat([o, d, torch.zeros(256, 1), torch.ones(256, 1), idx.float()[:, None]], dim=1).to(DEV)
+    rgbs = H.uniform(23, "rgbs", (256, 3), 0.2, 0.8).to(DEV)
+    ts = TrainStep(m, lr=2e-3, use_graph=use_graph)
+    logs = [ts.step(rays, rgbs) for _ in range(40)]
+    assert set(logs[0]) == {"train/loss", "train/psnr", "lr"}
+    first, last = float(logs[0]["train/loss"]), float(logs[-1]["train/loss"])
+    assert math.isfinite(first) and math.isfinite(last)
+    assert last < 0.6 * first, (first, last)
+    assert float(logs[-1]["train/psnr"]) > float(logs[0]["train/psnr"])
+    assert ts.arena.attached(m.warp_field.mlp.linears[0].weight) is not None

@@ -162,3 +162,32 @@ def test_param_arena_views_and_detach():
     assert float(lin.weight.grad.abs().sum()) == 0.0 and arena.attached(lin.weight) == 0
     lin.weight.grad = None
     assert arena.attached(lin.weight) is None and HN.ParamArena.lookup(params) is None
+
+
+def test_load_ckpt_lightning_and_bare(tmp_path):
+    """Reference checkpoints load unchanged: Lightning layout ({'state_dict': {'nerf.<name>': ...}}, train.py:48) and a
+    bare prefixed state dict, `prefixes_to_ignore`, empty path = no-op (reference: utils/__init__.py:66-89)."""
+    from hypernerf_torch_amd.utils import extract_model_state_dict, load_ckpt
+    emb = {"warp": list(range(10)), "camera": [0], "appearance": list(range(10)), "time": list(range(10))}
+    kw = dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True, view_fourier_dim=6)
+    src = models.NerfModel(emb, **kw)
+    dst = models.NerfModel(emb, **kw)
+    blob = {"epoch": 3, "state_dict": {"nerf." + k: v.clone() for k, v in src.state_dict().items()}}
+    blob["state_dict"]["loss.weight"] = torch.zeros(1)            # other modules of the Lightning system
+    path = os.path.join(tmp_path, "epoch=3.ckpt")
+    torch.save(blob, path)
+    got = extract_model_state_dict(path, "nerf")
+    assert set(got) == set(src.state_dict())
+    load_ckpt(dst, "", "nerf")                                     # no-op
+    assert not torch.equal(dst.warp_field.mlp.linears[0].weight, src.warp_field.mlp.linears[0].weight)
+    arena = HN.ParamArena(dst.parameters())                        # loading goes through the arena views
+    load_ckpt(dst, path, "nerf")
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    assert arena.attached(dst.warp_field.mlp.linears[0].weight) is not None
+    # bare dict + ignored prefix
+    bare = os.path.join(tmp_path, "bare.pt")
+    torch.save({"nerf." + k: v + 1.0 for k, v in src.state_dict().items()}, bare)
+    load_ckpt(dst, bare, "nerf", prefixes_to_ignore=["warp_field"])
+    assert torch.equal(dst.warp_field.mlp.linears[0].weight, src.warp_field.mlp.linears[0].weight)
+    assert torch.equal(dst.hyper_sheet_mlp.mlp.linears[0].weight, src.hyper_sheet_mlp.mlp.linears[0].weight + 1.0)

@@ -318,3 +318,21 @@ def test_g13_misc(golden_dir):
     close(O.mse_loss({"coarse": {"rgb": a}}, gt), g["loss_c"])
     close(O.mse_loss({"coarse": {"rgb": a}, "fine": {"rgb": b}}, gt), g["loss_cf"])
     close(O.psnr(b, gt), g["psnr_f"], rtol=1e-6)
+
+
+def test_g15_rays(golden_dir):
+    """Ray generation (datasets/ray_utils.py) — oracle vs the reference's own outputs; elementwise fp32, so exact up
+    to the 3-term matmul's summation order."""
+    g = load(golden_dir, "g15_rays")
+    hh, ww, focal, c2w = int(g["H"]), int(g["W"]), float(g["focal"]), T(g["c2w"])
+    dirs = O.ray_directions(hh, ww, focal)
+    close(dirs, g["directions"], rtol=0, atol=0)
+    o, d = O.rays_from_pose(dirs, c2w)
+    close(o, g["rays_o"], rtol=0, atol=0)
+    close(d, g["rays_d"], rtol=1e-6, atol=1e-7)
+    no, nd = O.ndc_rays(hh, ww, focal, 1.0, T(g["rays_o"]), T(g["rays_d"]))
+    close(no, g["ndc_o"], rtol=1e-6, atol=1e-7)
+    close(nd, g["ndc_d"], rtol=1e-6, atol=1e-7)
+    rows = O.image_rays(hh, ww, focal, c2w, 0.0, 1.0, True, image_id=7)
+    assert rows.shape == (hh * ww, 9) and float(rows[:, 8].min()) == 7.0
+    close(rows[:, :3], g["ndc_o"], rtol=1e-6, atol=1e-7)
