@@ -392,7 +392,9 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #endif
             HN_STAMP(3);
             if ((t & 1) || t == NT - 1) {
-              if (do_mask) __builtin_nontemporal_store((t & 1) ? bits : bits << 16, mask_base + (t >> 1) * 64);
+              // a plain (cached) store: the backward machine stalls on these words at the top of every layer, and
+              // unlike the once-streamed stash they are small enough (70 MB per step) to survive in L2 / MALL
+              if (do_mask) mask_base[(t >> 1) * 64] = (t & 1) ? bits : bits << 16;
               bits = 0;
             }
             if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, out_base, t, lane);
@@ -437,6 +439,19 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   }
 }
 
+// Backward machine: if the NEXT op is a layer with a ReLU mask, start loading its mask words (raw, not complemented)
+// now.  Returns whether it did.  Words of tile pairs the layer does not have read as 0 (= keep everything).
+HN_DEV bool hn_prefetch_masks(const HnMlpArgs& a, const HnOpWords& wn, int blk, int lane, bool wave_valid,
+                              unsigned* out) {
+  if (wn[0] != HN_BOP_LAYER || wn[4] < 0) return false;
+  const int NT = (wn[1] >> 16) & 255;
+  const HnSlot sl = a.slots[wn[4]];
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd)
+    out[dd] = (2 * dd < NT) ? (wave_valid ? a.masks[sl.off / 4 + ((size_t)blk * sl.nt + dd) * 64 + lane] : 0xffffffffu) : 0u;
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward-data machine
 // ------------------------------------------------------------------------------------------------
@@ -452,6 +467,11 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   const int ntiles = (a.n_points + PTS - 1) / PTS;
   HnFeat* feat_lds = reinterpret_cast<HnFeat*>(smem + 2 * HN_CHUNK_UNITS * 1024);
   float* srcv = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (a.n_comps * 32);
+#ifdef HN_PROF
+  long long* prof_buf = reinterpret_cast<long long*>(a.prof);
+  const bool prof_on = prof_buf != nullptr && blockIdx.x == 0 && wave == 0;
+  int prof_n = 0;
+#endif
   for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
   __syncthreads();
 
@@ -479,10 +499,14 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
     ws.start();
 
     HnOpWords w_next = hn_load_op(a.ops, 0, a.n_ops);
+    unsigned mnext[4] = {0u, 0u, 0u, 0u};
+    bool mnext_ready = false;
     for (int op = 0; op < a.n_ops; ++op) {
       const HnOpWords w = w_next;
       w_next = hn_load_op(a.ops, op + 1, a.n_ops);
       const int code = w[0];
+      HN_STAMP(100 * code + op);
+      if (code != HN_BOP_LAYER && code != HN_BOP_AUX) mnext_ready = false;   // LOAD ops do not prefetch
       if (code == HN_BOP_LOAD) {
         // dZ (<= 4 columns) of an output layer -> one 32-feature tile
         const int n = w[3] & 255;
@@ -547,13 +571,19 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         char* dz_base = do_stash ? hn_slot_base<BF16>(a, w[5], blk) : nullptr;
         unsigned nbits = 0xffffffffu;
         unsigned mbits[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // complemented words: set = keep
-        if (has_mask) {   // all relu masks of the layer up front: one VMEM wait per layer, none per tile
-          const HnSlot sl = a.slots[w[4]];
+        if (has_mask) {
+          if (mnext_ready) {   // fetched while the previous op ran (hn_prefetch_masks): no memory wait here
 #pragma unroll
-          for (int dd = 0; dd < 4; ++dd)
-            if (2 * dd < NT)
-              mbits[dd] = wave_valid ? ~a.masks[sl.off / 4 + ((size_t)blk * sl.nt + dd) * 64 + lane] : 0u;
+            for (int dd = 0; dd < 4; ++dd) mbits[dd] = ~mnext[dd];
+          } else {             // all relu masks of the layer up front: one VMEM wait per layer, none per tile
+            const HnSlot sl = a.slots[w[4]];
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd)
+              if (2 * dd < NT)
+                mbits[dd] = wave_valid ? ~a.masks[sl.off / 4 + ((size_t)blk * sl.nt + dd) * 64 + lane] : 0u;
+          }
         }
+        mnext_ready = false;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           if (t < NT) {
@@ -561,6 +591,10 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             hn_init_acc(acc, nullptr, t, h);
             hn_gemm_k<BF16>(acc, cur, K32, ws);
             if (K32b) hn_gemm_blocks<BF16, 1>(acc, cur2, ws);
+            // the next layer's mask words, issued behind this tile's chunk barrier so that they have the rest of
+            // the layer to arrive (the backward machine used to stall ~3 us on them at the top of every layer)
+            if (t == 0) mnext_ready = hn_prefetch_masks(a, w_next, blk, lane, wave_valid, mnext);
+            HN_STAMP(2);
             if (!(t & 1)) nbits = mbits[t >> 1];
             // dZ of padded points is zero from the LOAD ops on and stays zero: no `valid` select here
 #pragma unroll
@@ -568,6 +602,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
               acc[i] = __int_as_float(__float_as_int(acc[i]) & hn_keep_mask(nbits, t & 1, i));
             hn_acc_to_frags(acc, nxt + t * M::STEPS32);
             if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, dz_base, t, lane);
+            HN_STAMP(4);
           }
         }
 #pragma unroll
@@ -583,6 +618,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
           hn_init_acc(acc, nullptr, 0, h);
           hn_gemm_k<BF16>(acc, cur, K32, ws);
           if (K32b) hn_gemm_blocks<BF16, 1>(acc, cur2, ws);
+          if (tt == 0) mnext_ready = hn_prefetch_masks(a, w_next, blk, lane, wave_valid, mnext);
           // chain rule per feature, then the reduction over the features of each source component as one more
           // matrix product: dacc[slot][point] += S[slot][feature] . G[feature][point]  (S: 0/1 selection block that
           // the host put in the weight stream right behind this tile's weights).  No LDS accumulators: an LDS
@@ -593,6 +629,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
           Frag gfr[M::STEPS32];
           hn_acc_to_frags(acc, gfr);
           hn_gemm_blocks<BF16, 1>(dacc, gfr, ws);
+          HN_STAMP(5);
         }
       }
     }

@@ -148,6 +148,7 @@ class _ProgramFn(torch.autograd.Function):
 # autograd end-of-backward callback (they only feed arena.grad, which nothing reads before backward() returns).
 BATCH_WGRADS = True
 _PENDING: List[PendingWgrad] = []
+_PENDING_TASK = [-1]      # autograd graph-task id the pending entries belong to
 
 
 def _flush_wgrads():
@@ -157,7 +158,11 @@ def _flush_wgrads():
 
 
 def _defer_wgrad(p: PendingWgrad):
+    task = torch._C._current_graph_task_id()
+    if _PENDING and _PENDING_TASK[0] != task:
+        _flush_wgrads()     # left over from a backward pass that did not reach its callback (an exception)
     if not _PENDING:
+        _PENDING_TASK[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
     _PENDING.append(p)
 

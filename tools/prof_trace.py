@@ -19,11 +19,12 @@ rays = {"origins": o.cuda(), "directions": d.cuda(), "viewdirs": None,
 for _ in range(2):
     out = m(rays, {}); (out["fine"]["rgb"].sum() + out["coarse"]["rgb"].sum()).backward()
 torch.cuda.synchronize()
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "hn_mlp_forward"      # or hn_mlp_backward
 L.PROF_BUFFER = torch.zeros(4096, dtype=torch.int64, device="cuda")
 orig = L.launch
 traces = {}
 def launch(name, *a, tag=""):
-    if name == "hn_mlp_forward":
+    if name == WHICH:
         L.PROF_BUFFER.zero_(); torch.cuda.synchronize()
         orig(name, *a, tag=tag); torch.cuda.synchronize()
         traces[tag] = L.PROF_BUFFER.cpu().view(-1, 2).tolist()
@@ -40,7 +41,7 @@ for tag, tr in traces.items():
     for c, t in tr:
         if c >= 100:
             if line: print("   " + " ".join(line)); line = []
-            print(f" op {c - 100:3d} @ +{t - tr[0][1]}")
+            print(f" op {c % 100:3d} (code {c // 100}) @ +{t - tr[0][1]}")
         line.append(f"{c}:{t - prev}")
         prev = t
     if line: print("   " + " ".join(line))
