@@ -556,3 +556,45 @@ def test_train_step_harness(use_graph):
     assert last < 0.6 * first, (first, last)
     assert float(logs[-1]["train/psnr"]) > float(logs[0]["train/psnr"])
     assert ts.arena.attached(m.warp_field.mlp.linears[0].weight) is not None
+
+
+@pytest.mark.gpu
+def test_config3_sample_counts_vs_oracle_and_edge_batches():
+    """BASELINE config 3's sample counts (64 coarse + 128 fine = 192-sample fine level: the widest compositing scan
+    and inverse-CDF merge) against the oracle in fp32, and ragged / minimal batches (2 rays, 33 rays: partial
+    workgroups; a single ray hits the reference's own GLOEmbed squeeze quirk, modules.py:162-163) through forward +
+    backward."""
+    HN.set_precision("fp32")
+    try:
+        kw = CASES["bendy_cond"]
+        nc, nf, b, seed = 64, 128, 12, 61
+        m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, view_fourier_dim=6, **kw)
+        sd = load_hash(m, seed)
+        m = m.to(DEV)
+        o, d, idx = rays_for(seed, b)
+        rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1),
+               "noise_coarse": H.normal(seed, "n1", (b, nc, 1)) * 0.5,
+               "noise_fine": H.normal(seed, "n2", (b, nc + nf, 1)) * 0.5}
+        cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, view_fourier_dim=6, **kw)
+        ref = O.nerf_model_forward({k: v.clone() for k, v in sd.items()}, cfg, o, d, idx, rng)
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        out = m(rays, {}, rng={k: v.to(DEV) for k, v in rng.items()})
+        assert out["fine"]["weights"].shape == (b, nc + nf)
+        for k in ("rgb", "depth", "acc", "weights"):
+            assert_close(out["coarse"][k], ref["coarse"][k], 1e-4, f"config3 coarse/{k}")
+        same = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).float().mean().item()
+        assert same > 0.999, f"only {same:.4f} of fine-sample indices agree"
+        for k in ("rgb", "depth", "acc"):
+            assert_close(out["fine"][k], ref["fine"][k], 5e-4, f"config3 fine/{k}")
+        for nb in (2, 33):
+            o2, d2, idx2 = rays_for(seed + nb, nb)
+            r2 = {"origins": o2.to(DEV), "directions": d2.to(DEV), "viewdirs": None,
+                  "metadata": {k: idx2.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+            m.zero_grad(set_to_none=True)
+            out2 = m(r2, {})
+            assert out2["fine"]["rgb"].shape == (nb, 3) and torch.isfinite(out2["fine"]["rgb"]).all()
+            ((out2["fine"]["rgb"] ** 2).mean() + (out2["coarse"]["rgb"] ** 2).mean()).backward()
+            assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
+    finally:
+        HN.set_precision("bf16")
