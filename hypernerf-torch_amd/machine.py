@@ -565,6 +565,7 @@ def launch_pending_wgrads(pending: Sequence[PendingWgrad]):
 
 
 _OPT_STEPS = [0]
+BACKWARD_SERIAL = [0]      # bumped by every MlpRunner.backward
 
 
 def _count_optimizer_steps(optimizer, args, kwargs):
@@ -605,7 +606,7 @@ class MlpRunner:
             d.wstream = torch.empty(d.n_units * 1024, dtype=torch.uint8, device=device)
             d.bias = torch.zeros(max(32, self.prog.bias_len), dtype=torch.float32, device=device)
             d.sel = torch.from_numpy(self.prog.selection_matrix()).to(device)
-            d.ptr_key, d.ptrs, d.pack_key = None, None, None
+            d.ptr_key, d.ptrs, d.pack_key, d.pack_backward = None, None, None, -1
             self._dev[key] = d
         return d
 
@@ -620,12 +621,15 @@ class MlpRunner:
         return tuple(key)
 
     def pack(self, device, mode, force: bool = False):
-        """(Re)pack both weight streams: always when `force` (every training forward — a fused optimizer step
-        leaves no trace on the tensors), otherwise only if a parameter is known to have changed."""
+        """(Re)pack both weight streams if a parameter is known to have changed, and — with `force`, i.e. on training
+        forwards — also whenever a backward pass of ANY program has run since the last pack: parameters change
+        between a backward and the next forward, and a fused optimizer step leaves no trace on the tensors.  (The
+        coarse- and fine-level forwards of one step therefore share one pack.)"""
         d = self._tables(device, mode)
         key = self._param_key()
-        if d.pack_key == key and not force:
+        if d.pack_key == key and not (force and d.pack_backward != BACKWARD_SERIAL[0]):
             return d
+        d.pack_backward = BACKWARD_SERIAL[0]
         for p in self.prog.params:
             L.require_gpu(p)
             if p.dtype != torch.float32 or not p.is_contiguous():
@@ -692,6 +696,7 @@ class MlpRunner:
         for `launch_pending_wgrads`.
         Returns (dsrc [P, n_dsrc] or None, flat fp32 gradient buffer or None when grad_target was given)."""
         device = stash.device
+        BACKWARD_SERIAL[0] += 1
         d = self._tables(device, mode)       # the streams its forward packed
         dsrc = None
         if self.prog.n_dsrc > 0:
