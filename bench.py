@@ -50,10 +50,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU over RCCL ("nccl" on ROCm).  HN_DIST_BACKEND=gloo + more ranks than GPUs is a debugging
+    # aid only: it runs the N>1 code path (graph capture, gradient all-reduce, eager Adam) on a single-GPU box.
+    local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local)
+        dist.init_process_group(os.environ.get("HN_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local)
 
     import hypernerf_torch_amd as HN
@@ -161,7 +164,8 @@ def main():
         # second pass: the same steps with HIP events around every C-ABI launch (on the launch stream)
         L.KERNEL_TIMES = {}
         for _ in range(a.steps):
-            eager_step()
+            fwd_bwd()           # rank-local: no collective here, the other ranks are not in this pass
+            opt.step()
         times = L.collect_kernel_times()
         L.KERNEL_TIMES = None
         tot = {k: sum(v) for k, v in times.items()}
