@@ -76,10 +76,9 @@ def main():
     # parameters and gradients live in one flat arena each: the kernels accumulate dW straight into it, Adam
     # steps one tensor, and data parallelism all-reduces the gradient buffer in place.
     # The optimizer step is part of the captured graph on one GPU; with N>1 the gradient all-reduce sits between
-    # the captured forward+backward and an eager fused Adam
+    # the captured forward+backward and a second captured graph holding the fused Adam step
     arena = HN.ParamArena(model.parameters())
-    opt = torch.optim.Adam([arena.flat_param], lr=5e-4, eps=1e-8, fused=True,
-                           capturable=(use_graph and world == 1))
+    opt = torch.optim.Adam([arena.flat_param], lr=5e-4, eps=1e-8, fused=True, capturable=use_graph)
     bucket = arena
     loss_fn = MSELoss()
 
@@ -118,12 +117,14 @@ def main():
         if world == 1:
             step = GraphedStep(whole_step, warmup=3)
         else:
+            # two graphs around the one collective: forward+backward | all-reduce of the gradient buffer | Adam
             gfb = GraphedStep(fwd_bwd, warmup=3)
+            gopt = GraphedStep(opt.step, warmup=1)
 
             def step():
                 res = gfb()
                 bucket.all_reduce_mean()
-                opt.step()
+                gopt()
                 return res
     else:
         step = eager_step
