@@ -67,13 +67,13 @@ HN_MAX_WGRAD_BATCH = 8
 class HnCompositeArgs(C.Structure):
     _fields_ = [
         ("variant", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("white_bg", C.c_int32),
-        ("sample_at_infinity", C.c_int32), ("warped_ld", C.c_int32), ("pad0", C.c_int32), ("pad1", C.c_int32),
+        ("sample_at_infinity", C.c_int32), ("warped_ld", C.c_int32), ("has_dust", C.c_int32), ("dust_threshold", C.c_float),
         ("rgb", C.c_void_p), ("raw", C.c_void_p), ("noise", C.c_void_p), ("z", C.c_void_p), ("dirs", C.c_void_p),
         ("ray_ld", C.c_int64), ("warped", C.c_void_p),
         ("out_rgb", C.c_void_p), ("out_depth", C.c_void_p), ("out_acc", C.c_void_p), ("out_weights", C.c_void_p),
         ("out_med_depth", C.c_void_p), ("out_med_points", C.c_void_p),
         ("g_rgb", C.c_void_p), ("g_depth", C.c_void_p), ("g_acc", C.c_void_p), ("g_weights", C.c_void_p),
-        ("d_rgb", C.c_void_p), ("d_raw", C.c_void_p),
+        ("d_rgb", C.c_void_p), ("d_raw", C.c_void_p), ("keep", C.c_void_p),
     ]
 
 

@@ -212,7 +212,13 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
       }
       const float dz = (s + 1 < S) ? (zn - zz) : last;
       const float dd = dz * dnorm;
-      const float sigma = a.variant == 0 ? hn_softplus(raw) : (a.variant == 1 ? fmaxf(raw, 0.0f) : raw);
+      float sigma = a.variant == 0 ? hn_softplus(raw) : (a.variant == 1 ? fmaxf(raw, 0.0f) : raw);
+      // filter_sigma (reference models.py:35-63): densities below the dust threshold and outside the bounding box
+      // (a 0/1 mask the host builds from the sample points) are dropped; the factor is constant for the gradient
+      float kfac = 1.0f;
+      if (a.has_dust != 0 && !(sigma >= a.dust_threshold)) kfac = 0.0f;
+      if (a.keep != nullptr && in) kfac *= a.keep[row + s];
+      sigma *= kfac;
       float al = in ? (1.0f - expf(-sigma * dd)) : 0.0f;
       const float o = in ? (1.0f - al + eps) : 1.0f;
       // exclusive product scan: T_s = prod_{j<s} om_j
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
       const float T = carry * ex;
       carry *= __shfl(inc, 63, 64);
       const float w = al * T;
-      alpha[k] = al; om[k] = o; trans[k] = T; wgt[k] = w; pre[k] = raw; dist[k] = dd;
+      alpha[k] = al; om[k] = o; trans[k] = T; wgt[k] = w; pre[k] = raw; dist[k] = dd * kfac;   // d sigma' = kfac d sigma
       if (!BACKWARD) {
         if (in) {
           a.out_weights[row + s] = w;

@@ -333,7 +333,8 @@ def sample_pdf(weights, z, u, origins=None, directions=None, want_points=True, b
 # --------------------------------------------------------------------------------------------
 class _CompositeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median):
+    def forward(ctx, rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median,
+                dust_threshold=None, keep=None):
         L.require_gpu(rgb, raw, z, dirs)
         L.load()
         b, s = z.shape
@@ -349,6 +350,9 @@ class _CompositeFn(torch.autograd.Function):
         a.rgb, a.raw, a.noise, a.z = rgb_c.data_ptr(), raw_c.data_ptr(), (noise_c.data_ptr() if noise_c is not None else 0), z_c.data_ptr()
         a.dirs, a.ray_ld = dirs_c.data_ptr(), dirs_c.stride(0)
         a.warped = warped_c.data_ptr() if warped_c is not None else 0
+        keep_c = keep.detach().reshape(b, s).contiguous().float() if keep is not None else None
+        a.has_dust, a.dust_threshold = int(dust_threshold is not None), float(dust_threshold or 0.0)
+        a.keep = keep_c.data_ptr() if keep_c is not None else 0
         o_rgb = torch.empty(b, 3, dtype=torch.float32, device=dev)
         o_depth = torch.empty(b, dtype=torch.float32, device=dev)
         o_acc = torch.empty(b, dtype=torch.float32, device=dev)
@@ -360,6 +364,7 @@ class _CompositeFn(torch.autograd.Function):
         a.out_med_points = o_mp.data_ptr() if o_mp is not None else 0
         L.launch("hn_composite_forward", C.byref(a), L.stream_handle())
         ctx.saved = (rgb_c, raw_c, noise_c, z_c, dirs_c)
+        ctx.filt = (dust_threshold, keep_c)
         ctx.cfg = (variant, int(white_bg), int(sample_at_infinity), b, s)
         ctx.raw_shape = raw.shape
         outs = [o_rgb, o_depth, o_acc, o_w]
@@ -382,6 +387,9 @@ class _CompositeFn(torch.autograd.Function):
         a.rgb, a.raw, a.z = rgb_c.data_ptr(), raw_c.data_ptr(), z_c.data_ptr()
         a.noise = noise_c.data_ptr() if noise_c is not None else 0
         a.dirs, a.ray_ld = dirs_c.data_ptr(), dirs_c.stride(0)
+        dust, keep_c = ctx.filt
+        a.has_dust, a.dust_threshold = int(dust is not None), float(dust or 0.0)
+        a.keep = keep_c.data_ptr() if keep_c is not None else 0
         keep = []
         for name, g in (("g_rgb", g_rgb), ("g_depth", g_depth), ("g_acc", g_acc), ("g_weights", g_w)):
             if g is not None:
@@ -391,13 +399,15 @@ class _CompositeFn(torch.autograd.Function):
         d_raw = torch.empty_like(raw_c)
         a.d_rgb, a.d_raw = d_rgb.data_ptr(), d_raw.data_ptr()
         L.launch("hn_composite_backward", C.byref(a), L.stream_handle())
-        return d_rgb, d_raw.view(ctx.raw_shape), None, None, None, None, None, None, None, None
+        return d_rgb, d_raw.view(ctx.raw_shape), None, None, None, None, None, None, None, None, None, None
 
 
 def composite(rgb, raw, noise, z, dirs, warped=None, variant=0, white_bg=False, sample_at_infinity=True,
-              want_median=True):
-    """Returns (rgb (B,3), depth (B), acc (B), weights (B,S)[, med_depth (B)[, med_points (B)]])."""
-    return _CompositeFn.apply(rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median)
+              want_median=True, dust_threshold=None, keep=None):
+    """Returns (rgb (B,3), depth (B), acc (B), weights (B,S)[, med_depth (B)[, med_points (B)]]).
+    dust_threshold / keep (B,S 0/1): the reference's filter_sigma (models.py:35-63) applied to the activated density."""
+    return _CompositeFn.apply(rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median,
+                              dust_threshold, keep)
 
 
 # --------------------------------------------------------------------------------------------

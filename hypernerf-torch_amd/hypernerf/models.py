@@ -259,9 +259,16 @@ class NerfModel(nn.Module):
                        metadata_encoded=False, return_warp_jacobian=False, use_sample_at_infinity=False,
                        render_opts=None, noise=None):
         """One level of the render (reference: models.py:587-671)."""
+        # filter_sigma (reference models.py:35-63, call site :650) runs inside the compositing kernel: the dust
+        # threshold as a scalar, the bounding box as a 0/1 mask over the sample points
+        dust, keep = None, None
         if render_opts is not None:
-            raise NotImplementedError("render_opts: density filtering happens inside the fused compositing kernel "
-                                      "and is not wired yet (None on every call the reference makes)")
+            if 'dust_threshold' in render_opts:
+                dust = float(render_opts.get('dust_threshold', 0.0))
+            if 'bounding_box' in render_opts:
+                xmin, xmax, ymin, ymax, zmin, zmax = render_opts['bounding_box']
+                keep = ((points[..., 0] >= xmin) & (points[..., 0] <= xmax) & (points[..., 1] >= ymin)
+                        & (points[..., 1] <= ymax) & (points[..., 2] >= zmin) & (points[..., 2] <= zmax)).float()
         b, s = points.shape[0], points.shape[1]
         out = {'points': points}
         if use_warp:
@@ -290,7 +297,7 @@ class NerfModel(nn.Module):
             noise = torch.randn((b, s, 1), device=points.device, dtype=torch.float32) * self.noise_std
         res = F.composite(rgb.view(b, s, 3), alpha.view(b, s), noise, z_vals, directions, warped, variant=0,
                           white_bg=self.use_white_background, sample_at_infinity=use_sample_at_infinity,
-                          want_median=True)
+                          want_median=True, dust_threshold=dust, keep=keep)
         out['warped_points'] = warped
         out['rgb'], out['depth'], out['acc'], out['weights'], out['med_depth'] = res[0], res[1], res[2], res[3], res[4]
         out['med_points'] = res[5].view(b, 1, 1)

@@ -244,7 +244,9 @@ int hn_posenc(const float* x, int64_t n, int c, const float* freqs, int n_freqs,
  * variant 2 = hypernerf constants, `raw` is an already activated density (stand-alone
  *             model_utils.volumetric_rendering) */
 typedef struct {
-  int32_t variant, n_rays, n_samples, white_bg, sample_at_infinity, warped_ld, pad0, pad1;
+  int32_t variant, n_rays, n_samples, white_bg, sample_at_infinity, warped_ld;
+  int32_t has_dust;     /* filter_sigma (models.py:35-63): drop densities below dust_threshold */
+  float dust_threshold;
   const float* rgb;    /* (B,S,3) */
   const float* raw;    /* (B,S) raw density */
   const float* noise;  /* (B,S) already scaled, or NULL */
@@ -265,6 +267,7 @@ typedef struct {
   const float* g_weights; /* (B,S) or NULL */
   float* d_rgb;           /* (B,S,3) */
   float* d_raw;           /* (B,S) */
+  const float* keep;      /* (B,S) 0/1 density mask (filter_sigma's bounding box) or NULL; forward and backward */
 } HnCompositeArgs;
 int hn_composite_forward(const HnCompositeArgs* a, hnStream_t stream);
 int hn_composite_backward(const HnCompositeArgs* a, hnStream_t stream);

@@ -285,8 +285,22 @@ class ModelCfg:
         self.xyz_f, self.hyper_f, self.view_f = xyz_fourier_dim, hyper_fourier_dim, view_fourier_dim
 
 
+def filter_sigma(points: Tensor, sigma: Tensor, render_opts) -> Tensor:
+    """models.py:35-63: dust threshold and bounding box on the activated density."""
+    if render_opts is None:
+        return sigma
+    if "dust_threshold" in render_opts:
+        sigma = (sigma >= render_opts.get("dust_threshold", 0.0)) * sigma
+    if "bounding_box" in render_opts:
+        x0, x1, y0, y1, z0, z1 = render_opts["bounding_box"]
+        inside = ((points[..., 0] >= x0) & (points[..., 0] <= x1) & (points[..., 1] >= y0) & (points[..., 1] <= y1)
+                  & (points[..., 2] >= z0) & (points[..., 2] <= z1))
+        sigma = inside * sigma
+    return sigma
+
+
 def _render_level(p: Params, cfg: ModelCfg, level: str, pts, z, dirs, viewdirs, idx,
-                  noise, use_warp: bool, sample_at_infinity: bool):
+                  noise, use_warp: bool, sample_at_infinity: bool, render_opts=None):
     """NerfModel.render_samples, hypernerf/models.py:587-671."""
     b, s = pts.shape[:2]
     out = {"points": pts}
@@ -342,6 +356,7 @@ def _render_level(p: Params, cfg: ModelCfg, level: str, pts, z, dirs, viewdirs, 
     if noise is not None:                                                  # model_utils.py:300-317
         alpha = alpha + noise
     sigma = F.softplus(alpha.squeeze(-1))                                  # models.py:491
+    sigma = filter_sigma(pts, sigma, render_opts)                          # models.py:650 (un-warped points)
 
     out["warped_points"] = warped
     out.update(volumetric_rendering(rgb, sigma, z, dirs, white_bg=False,
@@ -352,7 +367,7 @@ def _render_level(p: Params, cfg: ModelCfg, level: str, pts, z, dirs, viewdirs, 
 
 
 def nerf_model_forward(p: Params, cfg: ModelCfg, origins, directions, idx, rng: Dict[str, Tensor],
-                       viewdirs=None, use_warp=True):
+                       viewdirs=None, use_warp=True, render_opts=None):
     """NerfModel.forward, hypernerf/models.py:673-780.
 
     rng: 't_rand' (B,Nc) U[0,1); 'u' (B,Nf) U[0,1); optional 'noise_coarse' (B,Nc,1),
@@ -370,7 +385,7 @@ def nerf_model_forward(p: Params, cfg: ModelCfg, origins, directions, idx, rng: 
         z2, pts2, inds = sample_pdf(mid, coarse["weights"][..., 1:-1], origins, directions,
                                     z, rng["u"])
         out["fine"] = _render_level(p, cfg, "fine", pts2, z2, directions, viewdirs, idx,
-                                    rng.get("noise_fine"), use_warp, True)
+                                    rng.get("noise_fine"), use_warp, True, render_opts)   # fine level only: :768
         out["fine"]["_inds"] = inds
     return out
 

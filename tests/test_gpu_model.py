@@ -598,3 +598,39 @@ def test_config3_sample_counts_vs_oracle_and_edge_batches():
             assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
     finally:
         HN.set_precision("bf16")
+
+
+@pytest.mark.gpu
+def test_render_opts_filter_sigma_vs_oracle():
+    """render_opts (reference models.py:35-63, applied to the fine level only, :768): dust threshold + bounding box
+    inside the compositing kernel against the oracle, forward and gradients, fp32."""
+    HN.set_precision("fp32")
+    try:
+        kw = CASES["bendy_cond"]
+        nc = nf = 24
+        b, seed = 40, 71
+        m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=None, view_fourier_dim=6, **kw)
+        sd = load_hash(m, seed)
+        m = m.to(DEV)
+        o, d, idx = rays_for(seed, b)
+        rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1)}
+        ro = {"dust_threshold": 0.55, "bounding_box": (-0.6, 0.7, -0.8, 0.5, -0.7, 0.9)}
+        cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=None, view_fourier_dim=6, **kw)
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = O.nerf_model_forward(p, cfg, o, d, idx, rng, render_opts=ro)
+        plain = O.nerf_model_forward({k: v.clone() for k, v in sd.items()}, cfg, o, d, idx, rng)
+        assert float((ref["fine"]["rgb"].detach() - plain["fine"]["rgb"]).abs().max()) > 1e-3      # the filter does something
+        gt = H.uniform(seed, "gt", (b, 3), 0, 1)
+        O.mse_loss(ref, gt).backward()
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        out = m(rays, {}, render_opts=ro, rng={k: v.to(DEV) for k, v in rng.items()})
+        for k in ("rgb", "depth", "acc", "weights"):
+            assert_close(out["coarse"][k], ref["coarse"][k], 1e-4, f"render_opts coarse/{k}")
+            assert_close(out["fine"][k], ref["fine"][k], 5e-4, f"render_opts fine/{k}")
+        loss = ((out["coarse"]["rgb"] - gt.to(DEV)) ** 2).mean() + ((out["fine"]["rgb"] - gt.to(DEV)) ** 2).mean()
+        loss.backward()
+        for k, prm in m.named_parameters():
+            assert_grad_close(prm.grad, p[k].grad, 1e-2, f"render_opts d {k}")
+    finally:
+        HN.set_precision("bf16")
