@@ -78,7 +78,8 @@ def main():
     # The optimizer step is part of the captured graph on one GPU; with N>1 the gradient all-reduce sits between
     # the captured forward+backward and a second captured graph holding the fused Adam step
     arena = HN.ParamArena(model.parameters())
-    opt = torch.optim.Adam([arena.flat_param], lr=5e-4, eps=1e-8, fused=True, capturable=use_graph)
+    # HIP fused Adam over the arena: one launch updates all parameters and clears the gradient buffer for the next step
+    opt = HN.ArenaAdam(arena, lr=5e-4, eps=1e-8, zero_grad=True)
     bucket = arena
     loss_fn = MSELoss()
 
@@ -96,8 +97,7 @@ def main():
         rd = model_utils.prepare_ray_dict(rays)
         out = model(rd, extra)
         loss = loss_fn(out, target)
-        arena.zero_grad()
-        loss.backward()
+        loss.backward()             # accumulates into arena.grad, which the previous opt.step() left zeroed
         return out, loss
 
     def eager_step():

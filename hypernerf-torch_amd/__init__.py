@@ -13,6 +13,7 @@ All device arithmetic runs in hand-written HIP kernels behind the C ABI in inclu
 """
 from . import _lib
 from .arena import ParamArena
+from .optim import ArenaAdam
 from .functional import get_precision, set_precision
 
 __version__ = "0.1.0"

@@ -59,11 +59,16 @@ class ParamArena:
         # what the optimizer steps: one tensor whose gradient is the gradient buffer
         self.flat_param = torch.nn.Parameter(self.data)
         self.flat_param.grad = self.grad
+        self._bumps = 0
 
     # ---- queries used by the kernels' autograd wrappers -----------------------------------------
     def version(self) -> int:
         """Changes whenever the parameter values were updated through the arena (in-place optimizer step)."""
-        return self.flat_param._version + self.data._version
+        return self.flat_param._version + self.data._version + self._bumps
+
+    def bump(self):
+        """Called by updates torch cannot see (the HIP Adam kernel writes the buffer directly)."""
+        self._bumps += 1
 
     def attached(self, p: torch.nn.Parameter) -> Optional[int]:
         """Offset (floats) of p's gradient inside `grad`, or None if p.grad is no longer the arena view."""

@@ -577,6 +577,63 @@ extern "C" int hn_generate_rays(int H, int W, float focal, const float* c2w, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused Adam over a flat parameter arena (torch.optim.Adam semantics, utils.get_optimizer's default):
+// one pass over p, g, m, v (28 B/parameter, HBM bound), the step counter lives on the device so the launch can be
+// captured in a HIP graph, and the gradient is zeroed on the way out (saves the separate fill of the next step).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hn_adam_kernel(float* p, float* g, float* m, float* v, long long n, float lr,
+                                                       float beta1, float beta2, float eps, float weight_decay,
+                                                       const float* step, int zero_grad) {
+  // `step` already holds the number of THIS update (hn_adam_tick runs first on the same stream)
+  const float t = step[0];
+  const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<f32x4*>(g + i);
+      f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float gk = gg[k] + weight_decay * pp[k];
+        mm[k] = beta1 * mm[k] + (1.0f - beta1) * gk;
+        vv[k] = beta2 * vv[k] + (1.0f - beta2) * gk * gk;
+        pp[k] -= step_size * mm[k] / (sqrtf(vv[k]) * inv_sqrt_bc2 + eps);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pp;
+      *reinterpret_cast<f32x4*>(m + i) = mm;
+      *reinterpret_cast<f32x4*>(v + i) = vv;
+      if (zero_grad) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      for (long long j = i; j < n; ++j) {
+        float gk = g[j] + weight_decay * p[j];
+        m[j] = beta1 * m[j] + (1.0f - beta1) * gk;
+        v[j] = beta2 * v[j] + (1.0f - beta2) * gk * gk;
+        p[j] -= step_size * m[j] / (sqrtf(v[j]) * inv_sqrt_bc2 + eps);
+        if (zero_grad) g[j] = 0.f;
+      }
+    }
+  }
+}
+__global__ void hn_adam_tick_kernel(float* step) { step[0] += 1.0f; }
+
+extern "C" int hn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, float* step_dev, int zero_grad,
+                            hnStream_t stream) {
+  if (n <= 0) return -2;
+  if (params == nullptr || grads == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || step_dev == nullptr) return -3;
+  if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return -4;
+  hipLaunchKernelGGL(hn_adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(hn_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, zero_grad);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // SE(3) exponential-map warp (warping.SE3Field.warp, hypernerf/warping.py:226-238; rigid_body.py:24-83)
 //   theta = |w| ; a = w/theta ; b = v/theta
 //   R = I + sin(theta) [a] + (1 - cos(theta)) [a]^2            (Modern Robotics 3.51)

@@ -2,8 +2,8 @@
 (reference: train.py:96-114 `forward`, 146-163 `training_step`; optimizer from utils.get_optimizer).
 
 `TrainStep(model, lr=...)` owns what NeRFSystem owns around the model — loss, optimizer — laid out the MI355X way:
-parameters and gradients in a `ParamArena`, fused Adam on one tensor, the whole step (prepare_ray_dict -> model ->
-MSE -> backward -> Adam) captured once into a HIP graph and replayed on fixed input buffers; with
+parameters and gradients in a `ParamArena`, `ArenaAdam` (one kernel for all parameters), the whole step (prepare_ray_dict -> model ->
+MSE -> backward -> fused HIP Adam) captured once into a HIP graph and replayed on fixed input buffers; with
 torch.distributed initialised, rays are expected pre-sharded per rank and the gradient buffer is all-reduced in
 place between the captured forward+backward and the optimizer step.  `step(rays, rgbs)` returns the same log the
 reference's training_step records: {'train/loss', 'train/psnr', 'lr'} (device scalars, no host sync).
@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from .arena import ParamArena
+from .optim import ArenaAdam
 from .graphs import GraphedStep
 from .hypernerf import model_utils
 from .losses import MSELoss, psnr
@@ -31,11 +32,9 @@ class TrainStep:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.group = group
         self.use_graph = use_graph
-        # the optimizer step can live inside the captured graph only when nothing (an all-reduce) sits between
-        # backward and it
-        self.optimizer = torch.optim.Adam([self.arena.flat_param], lr=lr, betas=betas, eps=eps,
-                                          weight_decay=weight_decay, fused=True,
-                                          capturable=use_graph and self.world == 1)
+        # hn_adam_step: one launch for all parameters, clears the gradient buffer on the way out, graph-capturable
+        # (on one GPU it is part of the captured step; with N>1 it follows the gradient all-reduce)
+        self.optimizer = ArenaAdam(self.arena, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, zero_grad=True)
         self.loss_fn = MSELoss()
         self._graph: Optional[GraphedStep] = None
         self._rays = self._rgbs = None
@@ -46,8 +45,7 @@ class TrainStep:
         results = self.model(model_utils.prepare_ray_dict(self._rays), dict(_EXTRA))
         loss = self.loss_fn(results, self._rgbs)
         typ = 'fine' if 'fine' in results else 'coarse'
-        self.arena.zero_grad()
-        loss.backward()
+        loss.backward()          # into arena.grad, left zeroed by the previous optimizer step
         with torch.no_grad():
             self._log = {'train/loss': loss.detach(), 'train/psnr': psnr(results[typ]['rgb'].detach(), self._rgbs)}
 

@@ -294,6 +294,14 @@ int hn_embed_gather(const float* table, const int64_t* idx, int n_rays, int dim,
 int hn_embed_backward(const float* d_points, int ld, int col0, const int64_t* idx, int n_rays,
                       int n_samples, int dim, int n_rows, float* d_table, hnStream_t stream);
 
+/* torch.optim.Adam (the reference's default optimizer, utils/__init__.py get_optimizer) over ONE flat fp32 buffer
+ * (ParamArena): p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), m,v updated first, L2 weight decay added to the
+ * gradient.  `step_dev`: one float on the device holding the number of updates done so far; it is incremented on the
+ * stream before the update (graph-capturable).  zero_grad != 0 clears `grads` in the same pass.  16-byte aligned. */
+int hn_adam_step(float* params_dev, float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, long long n,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, float* step_dev, int zero_grad,
+                 hnStream_t stream);
+
 /* All rays of one H x W image on the device: get_ray_directions + get_rays (+ get_ndc_rays when `ndc`)
  * (datasets/ray_utils.py:5-93) and the ray-row layout of datasets/llff.py:244-264:
  * rays[(j*W + i)] = [origin(3), direction(3), near, far(, image_id)], row_floats = 8 or 9.

@@ -192,3 +192,33 @@ def test_generate_rays_vs_golden_and_oracle(golden_dir, ndc):
     ref = O.image_rays(378, 504, 407.5, c2w, 0.2, 1.5, ndc)
     assert big.shape == ref.shape == (378 * 504, 8)
     assert_close(big, ref, 2e-6, "full image rays")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weight_decay", [0.0, 1e-2])
+def test_arena_adam_matches_torch_adam(weight_decay):
+    """hn_adam_step (ArenaAdam) against torch.optim.Adam over 6 steps on the same gradients: parameters to 1e-6 of
+    their scale, moments likewise; the gradient buffer is cleared by the step; the device step counter counts."""
+    import hypernerf_torch_amd as HN
+    torch.manual_seed(5)
+    shapes = [(37, 19), (19,), (5, 3, 2), (1,), (130, 64)]
+    p1 = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    p2 = [torch.nn.Parameter(p.detach().clone()) for p in p1]
+    ref = torch.optim.Adam(p1, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=weight_decay)
+    arena = HN.ParamArena(p2)
+    opt = HN.ArenaAdam(arena, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=weight_decay)
+    for it in range(6):
+        for a, b in zip(p1, p2):
+            g = torch.randn_like(a) * (0.1 + it)
+            a.grad = g.clone()
+            b.grad.copy_(g)
+        ref.step()
+        opt.step()
+        assert float(arena.grad.abs().max()) == 0.0
+        for a, b in zip(p1, p2):
+            assert_close(b, a, 1e-6, f"step {it} parameters")
+    assert float(opt.step_count) == 6.0
+    st = ref.state[p1[0]]
+    o0, n0 = arena.offsets[0], p1[0].numel()
+    assert_close(opt.exp_avg[o0:o0 + n0].view_as(p1[0]), st["exp_avg"], 1e-6, "exp_avg")
+    assert_close(opt.exp_avg_sq[o0:o0 + n0].view_as(p1[0]), st["exp_avg_sq"], 1e-6, "exp_avg_sq")
