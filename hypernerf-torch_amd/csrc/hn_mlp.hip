@@ -264,6 +264,100 @@ HN_DEV HnOpWords hn_load_op(const int* ops, int op, int n_ops) {
 
 
 // ------------------------------------------------------------------------------------------------
+// Software-pipelined hidden layer for the 128-wide layers (template rgb branch, warp field): 4 input tiles -> 4 output
+// tiles, bias, ReLU, commit.  A 128-wide tile has only 8 MFMAs, so in the generic loop its epilogue, mask and
+// transposed stash (which the matrix pipe idles through) outweigh the products.  Here the products of tile t and the
+// epilogue + stash of tile t-1 are written slot by slot in ONE basic block (two accumulators alternate; sched_barrier
+// keeps the slots apart).  Same take() sequence as the generic path, so barrier counts match across waves.
+// (The same body for the 256-wide layers does not fit 256 registers next to the generic path: DESIGN.md §8.)
+// ------------------------------------------------------------------------------------------------
+// one share of the previous tile's epilogue + stash, written so that share k only needs shares < k:
+//   k = 0..7   elements 2k, 2k+1: mask bit, ReLU, pack to bf16 (fragment k>>2 complete after k = 3 / 7)
+//   k = 8..11  pack the transposed tile z (4 of its 16 values each)
+//   k = 12     the two 16-byte stash stores (+ the mask word of a finished tile pair)
+// The two identity-MFMAs that transpose the tile are issued by the caller before shares 4 and 8.
+template <bool TRAIN, int NT>
+HN_DEV void hn_epilogue_share(int k, int tp, f32x16& a, bf16x8* frag, unsigned& bits, const f32x16& z, bf16x8* zo,
+                              char* out_base, uint32_t* mask_base, int lane) {
+  if (k < 8) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = 2 * k + e;
+      if (TRAIN) bits = hn_push_mask<true>(bits, a[i]);
+      frag[i >> 3][i & 7] = (__bf16)__int_as_float(max(__float_as_int(a[i]), 0));
+    }
+  } else if (TRAIN && k < 12) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * (k - 8) + e;
+      zo[i >> 3][i & 7] = (__bf16)z[i];
+    }
+  } else if (TRAIN && k == 12) {
+    char* dst = out_base + (size_t)tp * 2048 + lane * 16;
+    __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(&zo[0]), reinterpret_cast<u32x4*>(dst));
+    __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(&zo[1]), reinterpret_cast<u32x4*>(dst + 1024));
+    if ((tp & 1) || tp == NT - 1) {
+      mask_base[(tp >> 1) * 64] = (tp & 1) ? bits : bits << 16;
+      bits = 0;
+    }
+  }
+}
+
+template <int K32, int NT, bool TRAIN>
+HN_DEV void hn_layer_pipelined(bf16x8* cur, bf16x8* nxt, const float* bias, WStream<ModeT<true>::WAVES>& ws,
+                               char* out_base, uint32_t* mask_base, int lane) {
+  constexpr int N = 2 * K32;            // MFMAs (= issue slots) per tile
+  constexpr int D = 2;                  // fragment reads in flight
+  constexpr int SHARES = 13;
+  constexpr int PER_SLOT = (SHARES + N - 1) / N;      // 2 for 8 slots
+  const int h = lane >> 5, c = lane & 31;
+  bf16x8 id[2];                          // permuted identity: B operand of the transposing MFMAs
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) id[u][j] = (c == 16 * u + hn_pi16(h, j)) ? (__bf16)1.0f : (__bf16)0.0f;
+  f32x16 acc[2];
+  f32x16 z;
+  bf16x8 zo[2];
+  unsigned bits = 0;
+#pragma unroll
+  for (int t = 0; t <= NT; ++t) {
+    const char* wl = nullptr;
+    if (t < NT) wl = ws.take(N) + lane * 16;        // may pass the chunk barrier (a branch): kept out of the block
+    const int tp = t - 1;
+    bf16x8 q[D];
+    if (t < NT) {
+      hn_init_acc(acc[t & 1], bias, t, h);
+#pragma unroll
+      for (int u = 0; u < D; ++u) q[u] = *reinterpret_cast<const bf16x8*>(wl + u * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      // ---- slot u: one product of tile t, one fragment read ahead, shares of tile t-1's epilogue ----
+      if (t < NT) {
+        acc[t & 1] = hn_mfma_bf16(q[u % D], cur[u], acc[t & 1]);
+        if (u + D < N) q[u % D] = *reinterpret_cast<const bf16x8*>(wl + (u + D) * 1024);
+      }
+      if (t > 0) {
+#pragma unroll
+        for (int e = 0; e < PER_SLOT; ++e) {
+          const int k = u * PER_SLOT + e;
+          if (k < SHARES) {
+            if (TRAIN && k == 4) z = hn_mfma_bf16(nxt[tp * 2], id[0], f32x16{0});
+            if (TRAIN && k == 8) z = hn_mfma_bf16(nxt[tp * 2 + 1], id[1], z);
+            hn_epilogue_share<TRAIN, NT>(k, tp, acc[tp & 1], nxt + tp * 2, bits, z, zo, out_base, mask_base, lane);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NT * 2; ++i) cur[i] = nxt[i];
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward machine
 // ------------------------------------------------------------------------------------------------
 // AUXG: generated-feature groups (64 features each) a layer may have.  Their fragments stay in registers across the
@@ -349,6 +443,17 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         }
         unsigned bits = 0;
         HN_STAMP(1);
+        if constexpr (BF16) {
+          // plain 128 -> 128 ReLU layers (template rgb branch, warp field) take the pipelined body (adding the 64-wide
+          // shape as well tips the register allocator into spilling inside the generic path: measured 7 % slower)
+          const bool plain = nG == 0 && act == HN_ACT_RELU && !(flags & HN_LAYER_NO_COMMIT) && !has_out &&
+                             wave_valid && do_stash == do_mask;
+          if (plain && K32 == 4 && NT == 4) {
+            if (do_stash) hn_layer_pipelined<4, 4, true>(cur, nxt, bias, ws, out_base, mask_base, lane);
+            else hn_layer_pipelined<4, 4, false>(cur, nxt, bias, ws, out_base, mask_base, lane);
+            continue;
+          }
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           if (t < NT) {
