@@ -860,6 +860,7 @@ HN_DEV void hn_wait_vmcnt(int n) {
 // rectangles.  HBM-bound by construction: every stash byte is read exactly once.
 struct HnDwBatchTable {
   HnDwBatch b[HN_MAX_WGRAD_BATCH];
+  const int32_t* order;   // optional: workgroup g runs job order[g] & 0xffffff of batch order[g] >> 24
   int n;
 };
 
@@ -867,9 +868,15 @@ template <bool BF16>
 __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable tab) {
   // which batch holds this workgroup's job (<= 8 scalar compares on kernel-argument data)
   int job_id = blockIdx.x, which = 0;
+  if (tab.order != nullptr) {     // host-made global order (heaviest job first across ALL batches)
+    const int o = __builtin_amdgcn_readfirstlane(tab.order[blockIdx.x]);
+    which = o >> 24;
+    job_id = o & 0xffffff;
+  } else {
 #pragma unroll
-  for (int i = 0; i < HN_MAX_WGRAD_BATCH - 1; ++i)
-    if (which == i && i + 1 < tab.n && job_id >= tab.b[i].n_jobs) { job_id -= tab.b[i].n_jobs; which = i + 1; }
+    for (int i = 0; i < HN_MAX_WGRAD_BATCH - 1; ++i)
+      if (which == i && i + 1 < tab.n && job_id >= tab.b[i].n_jobs) { job_id -= tab.b[i].n_jobs; which = i + 1; }
+  }
   const HnDwJob* jobs = tab.b[0].jobs;
   const char* stash = reinterpret_cast<const char*>(tab.b[0].stash);
   float* grads = tab.b[0].grads;
@@ -1147,18 +1154,23 @@ extern "C" int hn_mlp_wgrad(int mode, const HnDwJob* jobs, int n_jobs, const voi
   return hn_launch_wgrad(mode, tab, n_jobs, stream);
 }
 
-extern "C" int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches, int n_batches, hnStream_t stream) {
+extern "C" int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches, int n_batches, const int32_t* order_dev,
+                                    hnStream_t stream) {
   if (n_batches < 0 || n_batches > HN_MAX_WGRAD_BATCH) return -1;
   if (n_batches > 0 && batches == nullptr) return -3;
   HnDwBatchTable tab = {};
   long long total = 0;
   for (int i = 0; i < n_batches; ++i) {
-    if (batches[i].n_jobs < 0) return -1;
-    if (batches[i].n_jobs == 0) continue;
+    if (batches[i].n_jobs < 0 || batches[i].n_jobs > 0xffffff) return -1;
+    if (batches[i].n_jobs == 0) {
+      if (order_dev != nullptr) return -1;      // an order table indexes the batches as passed
+      continue;
+    }
     if (batches[i].jobs == nullptr || batches[i].stash == nullptr || batches[i].grads == nullptr) return -3;
     tab.b[tab.n++] = batches[i];
     total += batches[i].n_jobs;
   }
+  tab.order = order_dev;
   if (total == 0) return 0;
   if (total > 0x7fffffffLL) return -2;
   return hn_launch_wgrad(mode, tab, (int)total, stream);

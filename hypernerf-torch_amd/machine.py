@@ -544,24 +544,38 @@ WGRAD_JOB_BYTES = int(float(os.environ.get("HN_WGRAD_JOB_MB", 5)) * (1 << 20))  
 class PendingWgrad:
     """One program's share of a batched weight-gradient launch.  Holds the stash alive until it ran."""
 
-    def __init__(self, mode, jobs_dev, n_jobs, stash, grads):
+    def __init__(self, mode, jobs_dev, n_jobs, stash, grads, weights):
         self.mode, self.jobs_dev, self.n_jobs, self.stash, self.grads = mode, jobs_dev, n_jobs, stash, grads
+        self.weights = weights          # per job: stash tiles it streams (host numpy, for the global order)
+
+
+_ORDER_CACHE: Dict[tuple, torch.Tensor] = {}
 
 
 def launch_pending_wgrads(pending: Sequence[PendingWgrad]):
-    """hn_mlp_wgrad_batched over the programs of one backward pass (groups of HN_MAX_WGRAD_BATCH per mode)."""
+    """hn_mlp_wgrad_batched over the programs of one backward pass (groups of HN_MAX_WGRAD_BATCH per mode).
+    Jobs run in one global heaviest-first order (a device table cached per set of job lists): the hardware
+    hands workgroups to CUs as they free up, i.e. list scheduling, and longest-first packs it tightest."""
     by_mode: Dict[int, List[PendingWgrad]] = {}
     for p in pending:
         by_mode.setdefault(p.mode, []).append(p)
     for mode, lst in by_mode.items():
-        lst.sort(key=lambda p: -p.n_jobs)        # the big programs' jobs first
+        lst.sort(key=lambda p: -p.n_jobs)
         for i in range(0, len(lst), L.HN_MAX_WGRAD_BATCH):
             grp = lst[i:i + L.HN_MAX_WGRAD_BATCH]
             arr = (L.HnDwBatch * len(grp))()
             for k, p in enumerate(grp):
                 arr[k].jobs, arr[k].stash, arr[k].grads = p.jobs_dev.data_ptr(), p.stash.data_ptr(), p.grads.data_ptr()
                 arr[k].n_jobs = p.n_jobs
-            L.launch("hn_mlp_wgrad_batched", C.c_int(mode), arr, C.c_int(len(grp)), L.stream_handle(), tag="batched")
+            key = tuple((p.jobs_dev.data_ptr(), p.n_jobs) for p in grp)
+            order = _ORDER_CACHE.get(key)
+            if order is None:
+                w = np.concatenate([p.weights for p in grp])
+                ids = np.concatenate([(k << 24) | np.arange(p.n_jobs, dtype=np.int64) for k, p in enumerate(grp)])
+                order = torch.from_numpy(ids[np.argsort(-w, kind="stable")].astype(np.int32)).to(grp[0].stash.device)
+                _ORDER_CACHE[key] = order
+            L.launch("hn_mlp_wgrad_batched", C.c_int(mode), arr, C.c_int(len(grp)), L.ptr(order), L.stream_handle(),
+                     tag="batched")
 
 
 _OPT_STEPS = [0]
@@ -710,10 +724,11 @@ class MlpRunner:
         if jkey not in self._jobs:
             jobs = self.prog.wgrad_jobs(mode, n_points, grad_offsets=goffs,
                                         job_bytes=WGRAD_JOB_BYTES if deferred else None)
-            self._jobs[jkey] = (L.to_device_bytes(jobs, device), len(jobs))
-        jobs_dev, n_jobs = self._jobs[jkey]
+            weights = ((jobs["n_nt"] + jobs["n_kt"]).astype(np.int64) * (jobs["blk1"] - jobs["blk0"]))
+            self._jobs[jkey] = (L.to_device_bytes(jobs, device), len(jobs), weights)
+        jobs_dev, n_jobs, weights = self._jobs[jkey]
         if deferred:        # the caller launches it together with the other programs of this backward pass
-            return dsrc, PendingWgrad(mode, jobs_dev, n_jobs, stash, grad_target[0])
+            return dsrc, PendingWgrad(mode, jobs_dev, n_jobs, stash, grad_target[0], weights)
         if grad_target is not None:
             grads, ret = grad_target[0], None
         else:

@@ -202,7 +202,9 @@ int hn_mlp_wgrad(int mode, const HnDwJob* jobs_dev, int n_jobs, const void* stas
 
 /* The same for up to HN_MAX_WGRAD_BATCH programs in ONE launch (a training step runs 6 programs; launched one by
  * one, the small ones cannot fill the chip and every launch pays its own ramp and tail).  Workgroup g works on job
- * g - first(batch) of the batch that holds it.  `batches` is a HOST array, copied into the kernel arguments. */
+ * g - first(batch) of the batch that holds it — or, with `order_dev` (device, one int32 per job of all batches:
+ * batch << 24 | job), job order_dev[g]: the host's global heaviest-first order, which list-schedules 5 % tighter than
+ * per-batch order.  `batches` is a HOST array, copied into the kernel arguments. */
 #define HN_MAX_WGRAD_BATCH 8
 typedef struct {
   const HnDwJob* jobs; /* device */
@@ -211,7 +213,8 @@ typedef struct {
   int32_t n_jobs;
   int32_t pad;
 } HnDwBatch;
-int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches_host, int n_batches, hnStream_t stream);
+int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches_host, int n_batches, const int32_t* order_dev,
+                         hnStream_t stream);
 
 /* ---- per-ray kernels --------------------------------------------------------------------- */
 
