@@ -916,7 +916,14 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
   }
-  const bool do_bias = jb.b_off >= 0 && wk == 0 && my_n > 0;
+  // bias gradient (db[n] = sum_p dZ[p][n], an all-ones operand): every wave of a row of the wave grid holds the same
+  // dZ tiles, so the bias of tile i goes to the wave with wk == i % gk.  (All of it on the wk == 0 waves put 50 % more
+  // MFMAs on two waves — which share a SIMD — and every stage barrier waited for them: in-kernel trace)
+  unsigned bias_mask = 0;
+  if (jb.b_off >= 0 && my_n > 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < my_n && (i % gk) == wk) bias_mask |= 1u << i;
 
   // Per-wave LDS-DMA slots of one stage, decoded ONCE (the integer divisions by run-time tile counts would
   // otherwise cost ~600 scalar instructions per stage): slot i moves 1 KiB from
@@ -962,15 +969,33 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
 
   // STAGES-1 stages in flight.  Every wave issues the same number of LDS-DMA instructions for every FULL stage,
   // so "all but the youngest k stages landed" is vmcnt(k * per_stage) (the last, partial stage only lowers it).
+#ifdef HN_PROF   // diagnostic build: wave 0 of every 97th workgroup sums the cycles of its four phases per stage
+  long long* prof_buf = (long long*)tab.b[HN_MAX_WGRAD_BATCH - 1].jobs;     // set by hn_set_wgrad_prof
+  const bool prof_on = prof_buf != nullptr && tab.n < HN_MAX_WGRAD_BATCH && (blockIdx.x % 97) == 0 && wave == 0;
+  unsigned long long tw = 0, tb = 0, ti = 0, tc = 0, t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0, t4_ = 0;
+#define HN_TS(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
+#endif
   for (int s0 = 0; s0 < STAGES - 1 && s0 < nstage; ++s0) issue(s0);
   for (int s = 0; s < nstage; ++s) {
     const int younger = min(STAGES - 2, nstage - 1 - s);     // stages issued after stage s that may stay in flight
+#ifdef HN_PROF
+    if (prof_on) HN_TS(t0_);
+#endif
     hn_wait_vmcnt(younger * per_stage);
+#ifdef HN_PROF
+    if (prof_on) HN_TS(t1_);
+#endif
     // raw barrier: __syncthreads() would make hipcc drain vmcnt(0) and with it the stages still in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone finished stage s-1
     __builtin_amdgcn_sched_barrier(0);
+#ifdef HN_PROF
+    if (prof_on) HN_TS(t2_);
+#endif
     if (s + STAGES - 1 < nstage) issue(s + STAGES - 1);   // refill the buffer stage s-1 used
+#ifdef HN_PROF
+    if (prof_on) HN_TS(t3_);
+#endif
     const char* st = smem + (size_t)(s % STAGES) * stage_bytes;
     const int nblk_s = min(bps, nb - s * bps);
     for (int bi = 0; bi < nblk_s; ++bi) {
@@ -987,11 +1012,21 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             if (j < my_k) DwFrag<BF16>::mma(acc[i][j], za, xb[j]);
-          if (do_bias) DwFrag<BF16>::mma_ones(accb[i], za);
+          if (bias_mask & (1u << i)) DwFrag<BF16>::mma_ones(accb[i], za);
         }
       }
     }
+#ifdef HN_PROF
+    if (prof_on) { HN_TS(t4_); tw += t1_ - t0_; tb += t2_ - t1_; ti += t3_ - t2_; tc += t4_ - t3_; }
+#endif
   }
+#ifdef HN_PROF
+  if (prof_on && lane == 0) {
+    long long* o = prof_buf + (blockIdx.x / 97) * 8;
+    o[0] = (long long)tw; o[1] = (long long)tb; o[2] = (long long)ti; o[3] = (long long)tc; o[4] = nstage;
+    o[5] = jb.n_nt * 16 + jb.n_kt; o[6] = bps; o[7] = blockIdx.x;
+  }
+#endif
   // D[n][k]: lane = column k (c), register q -> row rho(q,h)
   if (jb.w_off >= 0) {
     float* G = grads + jb.w_off;
@@ -1009,11 +1044,11 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
                 atomicAdd(G + (size_t)row * jb.ld + col, acc[i][j][q]);
             }
   }
-  if (do_bias && c == 0) {
+  if (bias_mask != 0 && c == 0) {
     float* gb = grads + jb.b_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (i < my_n)
+      if (bias_mask & (1u << i))
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int row = jb.r0 + 32 * (n0 + i) + hn_rho(q, h);
@@ -1129,6 +1164,10 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
   return 0;
 }
 
+#ifdef HN_PROF
+static void* hn_wgrad_prof = nullptr;
+extern "C" void hn_set_wgrad_prof(void* p) { hn_wgrad_prof = p; }     // diagnostic builds only: (64, 8) int64 buffer
+#endif
 static int hn_launch_wgrad(int mode, const HnDwBatchTable& tab, int total, hnStream_t stream) {
   hn_allow_big_lds();
   // 4 stages x (<= 16 tiles) : bf16 16 x 2 KiB, fp32 8 x 4 KiB  => 128 KiB
@@ -1171,6 +1210,9 @@ extern "C" int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches, int n_ba
     total += batches[i].n_jobs;
   }
   tab.order = order_dev;
+#ifdef HN_PROF
+  if (hn_wgrad_prof != nullptr && tab.n < HN_MAX_WGRAD_BATCH) tab.b[HN_MAX_WGRAD_BATCH - 1].jobs = (const HnDwJob*)hn_wgrad_prof;
+#endif
   if (total == 0) return 0;
   if (total > 0x7fffffffLL) return -2;
   return hn_launch_wgrad(mode, tab, (int)total, stream);

@@ -444,7 +444,7 @@ def run_wgrad(prog, mode, jobs, stash, n_grad):
             my_k = min(tk, jb["n_kt"] - k0)
             acc = [[np.zeros((64, 16)) for _ in range(4)] for _ in range(4)]
             accb = [np.zeros((64, 16)) for _ in range(4)]
-            do_bias = jb["b_off"] >= 0 and wk == 0 and my_n > 0
+            has_bias = jb["b_off"] >= 0 and my_n > 0     # tile i's bias goes to the wave with wk == i % gk
             for b in range(jb["blk0"], jb["blk1"]):
                 za = [stash.get_tile(int(jb["z_off"]) + (b * jb["z_nt"] + jb["z_t0"] + n0 + i) * tb)
                       for i in range(max(my_n, 0))]
@@ -459,7 +459,7 @@ def run_wgrad(prog, mode, jobs, stash, n_grad):
                             for g in range(4):
                                 for e in range(4):
                                     acc[i][j] = mfma_f32(za[i][g][:, e], xb[j][g][:, e], acc[i][j])
-                    if do_bias:
+                    if has_bias and (i % gk) == wk:
                         if mode.bf16:
                             for v in range(2):
                                 accb[i] = mfma_bf16(za[i][v], np.ones((64, 8)), accb[i])
@@ -476,7 +476,7 @@ def run_wgrad(prog, mode, jobs, stash, n_grad):
                             col = jb["c0"] + 32 * (k0 + j) + c
                             if 0 <= row < jb["r_end"] and 0 <= col < jb["c_end"] and jb["w_off"] >= 0:
                                 grads[jb["w_off"] + row * jb["ld"] + col] += acc[i][j][l, q]
-                if do_bias:
+                if has_bias and (i % gk) == wk:
                     for l in (0, 32):
                         for q in range(16):
                             row = jb["r0"] + 32 * (n0 + i) + rho(q, l >> 5)
