@@ -581,9 +581,12 @@ extern "C" int hn_generate_rays(int H, int W, float focal, const float* c2w, int
 // one pass over p, g, m, v (28 B/parameter, HBM bound), the step counter lives on the device so the launch can be
 // captured in a HIP graph, and the gradient is zeroed on the way out (saves the separate fill of the next step).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void hn_adam_kernel(float* p, float* g, float* m, float* v, long long n, float lr,
-                                                       float beta1, float beta2, float eps, float weight_decay,
-                                                       const float* step, int zero_grad) {
+__global__ __launch_bounds__(256) void hn_adam_kernel(float* p, float* g, float* m, float* v, long long n,
+                                                       const float* __restrict__ hyper, const float* step,
+                                                       int zero_grad) {
+  // hyper-parameters are read from device memory: a captured launch (HIP graph) follows later changes of lr etc.
+  const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], weight_decay = hyper[4];
+  const float gscale = hyper[5];      // 1 / world size after a SUM all-reduce (1 otherwise)
   // `step` already holds the number of THIS update (hn_adam_tick runs first on the same stream)
   const float t = step[0];
   const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(256) void hn_adam_kernel(float* p, float* g, float*
       f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float gk = gg[k] + weight_decay * pp[k];
+        float gk = gg[k] * gscale + weight_decay * pp[k];
         mm[k] = beta1 * mm[k] + (1.0f - beta1) * gk;
         vv[k] = beta2 * vv[k] + (1.0f - beta2) * gk * gk;
         pp[k] -= step_size * mm[k] / (sqrtf(vv[k]) * inv_sqrt_bc2 + eps);
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(256) void hn_adam_kernel(float* p, float* g, float*
       if (zero_grad) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
       for (long long j = i; j < n; ++j) {
-        float gk = g[j] + weight_decay * p[j];
+        float gk = g[j] * gscale + weight_decay * p[j];
         m[j] = beta1 * m[j] + (1.0f - beta1) * gk;
         v[j] = beta2 * v[j] + (1.0f - beta2) * gk * gk;
         p[j] -= step_size * m[j] / (sqrtf(v[j]) * inv_sqrt_bc2 + eps);
@@ -617,18 +620,19 @@ __global__ __launch_bounds__(256) void hn_adam_kernel(float* p, float* g, float*
 }
 __global__ void hn_adam_tick_kernel(float* step) { step[0] += 1.0f; }
 
-extern "C" int hn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
-                            float beta1, float beta2, float eps, float weight_decay, float* step_dev, int zero_grad,
-                            hnStream_t stream) {
+extern "C" int hn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                            const float* hyper_dev, float* step_dev, int zero_grad, hnStream_t stream) {
   if (n <= 0) return -2;
-  if (params == nullptr || grads == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || step_dev == nullptr) return -3;
+  if (params == nullptr || grads == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || step_dev == nullptr ||
+      hyper_dev == nullptr)
+    return -3;
   if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return -4;
   hipLaunchKernelGGL(hn_adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
   long long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(hn_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, zero_grad);
+                     exp_avg_sq, n, hyper_dev, step_dev, zero_grad);
   HN_CHECK_LAUNCH();
   return 0;
 }

@@ -299,11 +299,13 @@ int hn_embed_backward(const float* d_points, int ld, int col0, const int64_t* id
 
 /* torch.optim.Adam (the reference's default optimizer, utils/__init__.py get_optimizer) over ONE flat fp32 buffer
  * (ParamArena): p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), m,v updated first, L2 weight decay added to the
- * gradient.  `step_dev`: one float on the device holding the number of updates done so far; it is incremented on the
- * stream before the update (graph-capturable).  zero_grad != 0 clears `grads` in the same pass.  16-byte aligned. */
+ * gradient.  `hyper_dev`: 8 floats ON THE DEVICE, [lr, beta1, beta2, eps, weight_decay, grad_scale, 0, 0] — read by the
+ * kernel, so a launch captured in a HIP graph follows a learning-rate schedule (utils/__init__.py:43-46) without
+ * re-capture; grad_scale multiplies the gradient first (1/world after a SUM all-reduce).  `step_dev`: one float on
+ * the device holding the number of updates done so far; it is incremented on the stream before the update.
+ * zero_grad != 0 clears `grads` in the same pass.  Buffers 16-byte aligned. */
 int hn_adam_step(float* params_dev, float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, long long n,
-                 float lr, float beta1, float beta2, float eps, float weight_decay, float* step_dev, int zero_grad,
-                 hnStream_t stream);
+                 const float* hyper_dev, float* step_dev, int zero_grad, hnStream_t stream);
 
 /* All rays of one H x W image on the device: get_ray_directions + get_rays (+ get_ndc_rays when `ndc`)
  * (datasets/ray_utils.py:5-93) and the ray-row layout of datasets/llff.py:244-264:

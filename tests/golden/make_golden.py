@@ -430,6 +430,33 @@ def g_misc():
          psnr_f=-10 * torch.log10(mse))
 
 
+# ---- G16 filter_sigma (hypernerf/models.py:35-63) ------------------------------------------------
+def g_filter():
+    """filter_sigma is never called with render_opts by the reference's own scripts; called directly here so the
+    dust-threshold / bounding-box branch has a pin, and followed by volumetric_rendering (the call order of
+    render_samples, models.py:650-662) so the HIP compositing kernel — which applies the filter in-kernel — can be
+    compared end to end."""
+    b, s = 6, 24
+    o, d, _ = rays_for(16, b)
+    pts = H.uniform(16, "fs_pts", (b, s, 3), -1.0, 1.0)
+    rgb = H.uniform(16, "fs_rgb", (b, s, 3), 0.0, 1.0)
+    sigma = H.uniform(16, "fs_sig", (b, s), 0.0, 4.0)
+    sigma[0, 3] = 0.5                       # exactly at the threshold: kept (>=)
+    z, _ = torch.sort(H.uniform(16, "fs_z", (b, s), 0.0, 1.0), dim=-1)
+    box = (-0.5, 0.75, -0.8, 0.4, -0.25, 1.0)
+    pts[1, 0] = torch.tensor([box[0], box[3], box[5]])      # on the faces: kept (>= / <=)
+    arrs = dict(pts=pts, rgb=rgb, sigma=sigma, z=z, d=d, box=np.asarray(box, dtype=np.float32))
+    cases = {"none": None, "dust": {"dust_threshold": 0.5}, "box": {"bounding_box": box},
+             "both": {"dust_threshold": 0.5, "bounding_box": box}}
+    for tag, opts in cases.items():
+        f = R_models.filter_sigma(pts, sigma, opts)
+        arrs["sigma_" + tag] = f
+        r = R_mu.volumetric_rendering(rgb, f, z, d, use_white_background=False, sample_at_infinity=True)
+        for k, v in r.items():
+            arrs[f"{k}_{tag}"] = v
+    save("g16_filter", **arrs)
+
+
 def g_rays():
     """datasets/ray_utils.py.  kornia is absent: its create_meshgrid(H, W,
     normalized_coordinates=False) — a (1,H,W,2) grid of pixel indices, x (column) first — is stubbed."""
@@ -459,7 +486,7 @@ def g_rays():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["posenc", "mlp", "glo", "fields", "sample", "volrend", "pdf",
-                             "model", "legacy", "misc", "rays"]
+                             "model", "legacy", "misc", "rays", "filter"]
     for w in which:
         print("golden:", w)
         globals()["g_" + w]()

@@ -336,3 +336,17 @@ def test_g15_rays(golden_dir):
     rows = O.image_rays(hh, ww, focal, c2w, 0.0, 1.0, True, image_id=7)
     assert rows.shape == (hh * ww, 9) and float(rows[:, 8].min()) == 7.0
     close(rows[:, :3], g["ndc_o"], rtol=1e-6, atol=1e-7)
+
+
+def test_g16_filter_sigma(golden_dir):
+    """filter_sigma (models.py:35-63) called directly on the reference, then volumetric_rendering."""
+    g = load(golden_dir, "g16_filter")
+    box = tuple(float(v) for v in g["box"])
+    cases = {"none": None, "dust": {"dust_threshold": 0.5}, "box": {"bounding_box": box},
+             "both": {"dust_threshold": 0.5, "bounding_box": box}}
+    for tag, opts in cases.items():
+        f = O.filter_sigma(T(g["pts"]), T(g["sigma"]), opts)
+        assert np.array_equal(f.numpy(), g["sigma_" + tag])
+        r = O.volumetric_rendering(T(g["rgb"]), f, T(g["z"]), T(g["d"]), white_bg=False, sample_at_infinity=True)
+        for k, v in r.items():
+            close(v, g[f"{k}_{tag}"], rtol=1e-6, atol=1e-6)
