@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
-"""Benchmark of the HyperNeRF render hot path on MI355X (BASELINE.json metric).
+"""Benchmark of the HyperNeRF render hot path on MI355X (BASELINE.json metric: ray-samples/s, forward + backward).
 
-    python bench.py --gpus N --steps K --warmup W
-(N>1: launched by torch.distributed.run, one rank per GPU, RCCL).  A "step" = one training step of the
-reference's hot loop on one synthetic ray batch already resident in HBM: NerfModel forward (coarse + fine),
-MSE loss, backward, gradient all-reduce (N>1), Adam step.  Workload at N=1 = BASELINE configs[1]:
-use_warp + bendy_sheet, 1024 rays x (64+64) samples, bf16 MFMA operands / fp32 accumulate.
-Prints ONE JSON line (rank 0).
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,3,5}]
+(N>1: launched by torch.distributed.run, one rank per GPU, RCCL).  A "step" = one training step of the reference's
+hot loop on one synthetic ray batch already resident in HBM: model forward (coarse + fine), MSE loss, backward,
+gradient all-reduce (N>1), Adam step.  Workloads (BASELINE.json `configs`):
+    2 (default, the configuration the metric is quoted on)  NerfModel use_warp + bendy_sheet, 1024 rays x (64+64), bf16
+    3  same model, 16384 rays x (64+128), bf16 (the "saturate the GPU" size)
+    5  SE3Field warp + axis_aligned_plane (hyper_slice_out_dim = GLO_dim = 8) at config-2 shapes, bf16
+    1  legacy nerf_pl render_rays, coarse only, 256 rays x 64 samples, fp32 (the reference's CPU-runnable case)
+The K timed steps are repeated `--repeats` times back to back (each repeat bracketed by barrier + synchronize);
+`value` comes from the MEDIAN repeat, `ms_per_step_repeats` lists all of them.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -25,24 +30,100 @@ import torch.distributed as dist
 PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12                             # HBM3E bytes/s, same guide
 
+CONFIGS = {
+    1: dict(rays=256, nc=64, nf=0, precision="fp32", kind="legacy"),
+    2: dict(rays=1024, nc=64, nf=64, precision="bf16", kind="hypernerf"),
+    3: dict(rays=16384, nc=64, nf=128, precision="bf16", kind="hypernerf"),
+    5: dict(rays=1024, nc=64, nf=64, precision="bf16", kind="se3"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rays", type=int, default=1024)
-    ap.add_argument("--nc", type=int, default=64)
-    ap.add_argument("--nf", type=int, default=64)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--repeats", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=None)
+    ap.add_argument("--nc", type=int, default=None)
+    ap.add_argument("--nf", type=int, default=None)
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
-    return ap.parse_args()
+    a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    for k in ("rays", "nc", "nf", "precision"):
+        if getattr(a, k) is None:
+            setattr(a, k, cfg[k])
+    a.kind = cfg["kind"]
+    return a
 
 
 def macs_per_point(prog):
     return sum(ly.weight.shape[0] * ly.weight.shape[1] for ly in prog.layers)
+
+
+def build_workload(a, dev, rank):
+    """(model-like callable returning (out, loss), parameters, {program name: (program, points per step)})."""
+    import hypernerf_torch_amd as HN
+    from hypernerf_torch_amd.hypernerf import model_utils
+    from hypernerf_torch_amd.losses import MSELoss
+    from gpu_common import EMB
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    b = a.rays
+    o = torch.rand(b, 3, generator=g) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(b, 3, generator=g), dim=-1)
+    ids = torch.randint(0, 100, (b, 1), generator=g).float()
+    target = torch.rand(b, 3, generator=g).to(dev)
+    loss_fn = MSELoss()
+    torch.manual_seed(0)     # identical weights on every rank
+    if a.kind == "legacy":
+        from hypernerf_torch_amd.models import nerf as legacy_nerf
+        from hypernerf_torch_amd.models.rendering import render_rays
+        near, far = torch.full((b, 1), 2.0), torch.full((b, 1), 6.0)
+        rays = torch.cat([o, d, near, far], dim=1).to(dev)
+        coarse = legacy_nerf.NeRF().to(dev)
+        emb = [legacy_nerf.Embedding(3, 10), legacy_nerf.Embedding(3, 4)]
+        params = list(coarse.parameters())
+
+        def fwd_bwd():
+            res = render_rays([coarse], emb, rays, N_samples=a.nc, N_importance=0, perturb=1.0, noise_std=1.0)
+            loss = ((res["rgb_coarse"] - target) ** 2).mean()     # losses.py:10 on the coarse level only
+            loss.backward()
+            return {"fine": {"rgb": res["rgb_coarse"]}}, loss
+
+        def programs():
+            call = coarse._calls[next(iter(coarse._calls))] if hasattr(coarse, "_calls") else None
+            return {} if call is None else {"NeRF": (call.program, b * a.nc)}
+        workload = f"legacy render_rays, NeRF coarse only, {b} rays x {a.nc} samples, fwd+bwd+Adam"
+        return fwd_bwd, params, programs, workload
+    kw = dict(hyper_slice_method="bendy_sheet", use_warp=True, use_nerf_embed=True, use_alpha_cond=True)
+    if a.kind == "se3":
+        kw = dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_warp=True, use_nerf_embed=True,
+                  use_alpha_cond=True)
+    from hypernerf_torch_amd.hypernerf.models import NerfModel
+    model = NerfModel(EMB, near=0.0, far=1.0, n_samples_coarse=a.nc, n_samples_fine=a.nf, noise_std=1.0,
+                      view_fourier_dim=6, **kw)
+    if a.kind == "se3":
+        from hypernerf_torch_amd.hypernerf import warping
+        model.warp_field = warping.SE3Field(in_ch=3)
+    model = model.to(dev)
+    rays = torch.cat([o, d, torch.zeros(b, 1), torch.ones(b, 1), ids], dim=1).to(dev)
+    extra = {'nerf_alpha': None, 'warp_alpha': None, 'hyper_alpha': None, 'hyper_sheet_alpha': None}
+
+    def fwd_bwd():
+        out = model(model_utils.prepare_ray_dict(rays), extra)
+        loss = loss_fn(out, target)
+        loss.backward()             # accumulates into arena.grad, which the previous opt.step() left zeroed
+        return out, loss
+
+    def programs():
+        return {name: (prog, pts) for name, prog, pts in model.compiled_programs(b)}
+    what = "SE3Field warp + axis_aligned_plane" if a.kind == "se3" else "use_warp bendy_sheet"
+    workload = (f"NerfModel {what} nerf_embed+alpha_cond, {b} rays x ({a.nc}+{a.nf}) samples per GPU, fwd+bwd+Adam")
+    return fwd_bwd, list(model.parameters()), programs, workload
 
 
 def main():
@@ -51,7 +132,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # one process per GPU over RCCL ("nccl" on ROCm).  HN_DIST_BACKEND=gloo + more ranks than GPUs is a debugging
-    # aid only: it runs the N>1 code path (graph capture, gradient all-reduce, eager Adam) on a single-GPU box.
+    # aid only: it runs the N>1 code path (graph capture, gradient all-reduce, Adam) on a single-GPU box.
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
@@ -61,51 +142,17 @@ def main():
 
     import hypernerf_torch_amd as HN
     from hypernerf_torch_amd import _lib as L
-    from hypernerf_torch_amd.dist import GradBucket, all_gather_pixels
-    from hypernerf_torch_amd.hypernerf import model_utils
-    from hypernerf_torch_amd.hypernerf.models import NerfModel
-    from hypernerf_torch_amd.losses import MSELoss, psnr
-    from gpu_common import EMB
+    from hypernerf_torch_amd.dist import all_gather_pixels
 
     HN.set_precision(a.precision)
-    torch.manual_seed(0)     # identical weights on every rank
-    model = NerfModel(EMB, near=0.0, far=1.0, n_samples_coarse=a.nc, n_samples_fine=a.nf, noise_std=1.0,
-                      hyper_slice_method="bendy_sheet", use_warp=True, use_nerf_embed=True, use_alpha_cond=True,
-                      view_fourier_dim=6).to(dev)
+    fwd_bwd, params, programs, workload = build_workload(a, dev, rank)
     use_graph = not a.no_graph
-    # parameters and gradients live in one flat arena each: the kernels accumulate dW straight into it, Adam
-    # steps one tensor, and data parallelism all-reduces the gradient buffer in place.
-    # The optimizer step is part of the captured graph on one GPU; with N>1 the gradient all-reduce sits between
-    # the captured forward+backward and a second captured graph holding the fused Adam step
-    arena = HN.ParamArena(model.parameters())
-    # HIP fused Adam over the arena: one launch updates all parameters and clears the gradient buffer for the next step
-    opt = HN.ArenaAdam(arena, lr=5e-4, eps=1e-8, zero_grad=True)
-    bucket = arena
-    loss_fn = MSELoss()
-
-    # synthetic rays (B,9): origins U(-1,1)^3, unit-ish directions, near/far 0/1, image id; rgb targets
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    b = a.rays
-    o = torch.rand(b, 3, generator=g) * 2 - 1
-    d = torch.nn.functional.normalize(torch.randn(b, 3, generator=g), dim=-1)
-    ids = torch.randint(0, 100, (b, 1), generator=g).float()
-    rays = torch.cat([o, d, torch.zeros(b, 1), torch.ones(b, 1), ids], dim=1).to(dev)
-    target = torch.rand(b, 3, generator=g).to(dev)
-    extra = {'nerf_alpha': None, 'warp_alpha': None, 'hyper_alpha': None, 'hyper_sheet_alpha': None}
-
-    def fwd_bwd():
-        rd = model_utils.prepare_ray_dict(rays)
-        out = model(rd, extra)
-        loss = loss_fn(out, target)
-        loss.backward()             # accumulates into arena.grad, which the previous opt.step() left zeroed
-        return out, loss
-
-    def eager_step():
-        out, loss = fwd_bwd()
-        if world > 1:
-            bucket.all_reduce_mean()
-        opt.step()
-        return out, loss
+    # parameters and gradients live in one flat arena each: the kernels accumulate dW straight into it, Adam steps
+    # one tensor, and data parallelism SUM-all-reduces the gradient buffer in place (the 1/N sits in the Adam kernel).
+    arena = HN.ParamArena(params)
+    if world > 1:
+        dist.broadcast(arena.data, src=0)
+    opt = HN.ArenaAdam(arena, lr=5e-4, eps=1e-8, zero_grad=True, grad_scale=1.0 / world)
 
     def whole_step():
         out, loss = fwd_bwd()
@@ -119,15 +166,21 @@ def main():
         else:
             # two graphs around the one collective: forward+backward | all-reduce of the gradient buffer | Adam
             gfb = GraphedStep(fwd_bwd, warmup=3)
+            arena.zero_grad()
             gopt = GraphedStep(opt.step, warmup=1)
 
             def step():
                 res = gfb()
-                bucket.all_reduce_mean()
+                arena.all_reduce_sum()
                 gopt()
                 return res
     else:
-        step = eager_step
+        def step():
+            out, loss = fwd_bwd()
+            if world > 1:
+                arena.all_reduce_sum()
+            opt.step()
+            return out, loss
 
     def barrier():
         if world > 1:
@@ -136,110 +189,156 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out, loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    reps = []
+    for _ in range(max(1, a.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out, loss = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        reps.append(dt)
+    ranks_seen = world
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         all_gather_pixels(out['fine']['rgb'].detach())     # eval-style pixel assembly works on this topology
-    samples = world * b * (a.nc + a.nf) * a.steps
-    value = samples / dt
+        cnt = torch.ones(1, device=dev)
+        dist.all_reduce(cnt)
+        ranks_seen = int(cnt.item())                       # what the collective library itself reports
+    dt = statistics.median(reps)
+    b = a.rays
+    samples_step = world * b * (a.nc + a.nf)
+    value = samples_step * a.steps / dt
 
     res = {
         "metric": "ray-samples/sec (fwd+bwd+Adam), whole job; per-GPU = value/n_gpus",
         "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.precision, "data": "synthetic",
-        "config": {"workload": f"NerfModel use_warp bendy_sheet nerf_embed+alpha_cond, {b} rays x ({a.nc}+{a.nf}) "
-                               f"samples per GPU, fwd+bwd+Adam", "rays_per_gpu": b, "n_samples": a.nc,
-                   "n_importance": a.nf, "parallelism": f"dp{world}", "hip_graph": use_graph},
+        "config": {"workload": workload, "baseline_config": a.config, "rays_per_gpu": b, "n_samples": a.nc,
+                   "n_importance": a.nf, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                   "ranks_seen_by_collective": ranks_seen},
         "per_gpu": value / world, "final_loss": float(loss.detach()),
+        "repeats": len(reps), "ms_per_step_repeats": [1e3 * r / a.steps for r in reps],
+        "ms_per_step_spread": [1e3 * min(reps) / a.steps, 1e3 * max(reps) / a.steps],
     }
 
     if rank == 0 and not a.no_roofline:
-        # second pass: the same steps with HIP events around every C-ABI launch (on the launch stream)
-        L.KERNEL_TIMES = {}
-        for _ in range(a.steps):
-            fwd_bwd()           # rank-local: no collective here, the other ranks are not in this pass
-            opt.step()
-        times = L.collect_kernel_times()
-        L.KERNEL_TIMES = None
-        tot = {k: sum(v) for k, v in times.items()}
-        # group launches by KERNEL (= rocprofv3's per-symbol rows): forward / backward-data / weight-gradient machine
-        progs = {}
-        for lvl, pts in (("coarse", b * a.nc), ("fine", b * (a.nc + a.nf))):
-            call = [c for k, c in model._template_calls.items() if k[0] == lvl][0]
-            progs[f"template_{lvl}"] = (macs_per_point(call.program), pts)
-        warp_prog = model.warp_field._calls[next(iter(model.warp_field._calls))].program
-        sheet_prog = model.hyper_sheet_mlp._calls[next(iter(model.hyper_sheet_mlp._calls))].program
-        all_pts = b * (2 * a.nc + a.nf)
-        progs["TranslationField"] = (macs_per_point(warp_prog), all_pts)
-        progs["HyperSheetMLP"] = (macs_per_point(sheet_prog), all_pts)
-        flops_per_step = sum(2.0 * m * p for m, p in progs.values())        # per machine kernel and step
-        # the weight-gradient kernel streams every stash tile once: its algorithmic bytes are what its job list reads
-        mode = 1 if a.precision == "bf16" else 0
-        tile_bytes = 2048 if a.precision == "bf16" else 4096
-        prog_of = {"template_coarse": [c for k, c in model._template_calls.items() if k[0] == "coarse"][0].program,
-                   "template_fine": [c for k, c in model._template_calls.items() if k[0] == "fine"][0].program}
-        wgrad_bytes = 0.0
-        for prog, pts_list in ((prog_of["template_coarse"], [b * a.nc]), (prog_of["template_fine"], [b * (a.nc + a.nf)]),
-                               (warp_prog, [b * a.nc, b * (a.nc + a.nf)]), (sheet_prog, [b * a.nc, b * (a.nc + a.nf)])):
-            for pts in pts_list:
-                j = prog.wgrad_jobs(mode, pts)
-                wgrad_bytes += float(((j["n_nt"] + j["n_kt"]).astype("int64") * (j["blk1"] - j["blk0"])).sum()) * tile_bytes
-        kern = {}
-        for sym in ("hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad"):
-            ks = [k for k in tot if k.startswith(sym + "[") or k.startswith(sym + "_batched[")]
-            kern[sym] = (sum(tot[k] for k in ks) / a.steps, sum(len(times[k]) for k in ks) / a.steps)
-        names = {"hn_mlp_forward": "hn_mlp_fwd_kernel", "hn_mlp_backward": "hn_mlp_bwd_kernel",
-                 "hn_mlp_wgrad": "hn_wgrad_kernel"}
-        per_kernel = {}
-        for sym, (ms_step, launches) in kern.items():
-            mf = flops_per_step / (ms_step * 1e-3)
-            e = {"ms_per_step": ms_step, "launches_per_step": launches,
-                 "mfma": {"achieved": mf / 1e12, "peak": PEAK[a.precision] / 1e12, "unit": "TFLOP/s",
-                          "frac": mf / PEAK[a.precision], "algorithmic_flops_per_step": flops_per_step}}
-            if sym == "hn_mlp_wgrad":
-                bw = wgrad_bytes / (ms_step * 1e-3)
-                e["hbm"] = {"achieved": bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bw / HBM_PEAK,
-                            "algorithmic_bytes_per_step": wgrad_bytes}
-            per_kernel[names[sym]] = e
-        dom = max(kern, key=lambda k: kern[k][0])
-        ms_step, launches = kern[dom]
-        pk = per_kernel[names[dom]]
-        bound = "hbm" if "hbm" in pk else "mfma"       # the weight-gradient kernel is a pure stream; the others GEMM
-        rl = dict(pk[bound])
-        per_launch = (rl.pop("algorithmic_bytes_per_step", None) or rl.pop("algorithmic_flops_per_step")) / launches
-        res["roofline"] = {"bound": bound, "kernel": names[dom] + ("<true>" if a.precision == "bf16" else "<false>"),
-                           "achieved": rl["achieved"], "peak": rl["peak"], "unit": rl["unit"], "frac": rl["frac"],
-                           "traffic": None, "avg_launch_ms": ms_step / launches, "launches_per_step": launches,
-                           ("algorithmic_bytes_per_launch" if bound == "hbm" else "algorithmic_flops_per_launch"): per_launch,
-                           "note": "dominant kernel by time.  achieved = algorithmic bytes (stash tiles the job list "
-                                   "reads, each once) or GEMM FLOPs of all its launches in a step / their summed "
-                                   "HIP-event duration on the launch stream; measured HBM traffic per launch: "
-                                   "profiles/r01_pmc_per_kernel.csv",
-                           "per_kernel": per_kernel,
-                           "kernel_ms_per_step": {k: tot[k] / a.steps for k in sorted(tot, key=tot.get, reverse=True)},
-                           "sum_kernel_ms_per_step": sum(tot.values()) / a.steps}
-        res["step_tflops"] = 3.0 * flops_per_step / (dt / a.steps) / 1e12
-
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res.update(roofline(a, L, fwd_bwd, opt, programs(), dt / a.steps, b))
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.kind == "hypernerf":
         res["cpu_baseline"] = cpu_baseline(a)
-
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
 
 
+def roofline(a, L, fwd_bwd, opt, progs, step_s, b):
+    """Second, eager pass: the same steps with HIP events around every C-ABI launch (on the launch stream).
+    Definitions: the path is MFMA-bound; algorithmic FLOPs = GEMM MACs x 2 of every Linear layer x
+    evaluated points, the same number for the forward, the backward-data and the weight-gradient products;
+    `roofline` describes the DOMINANT kernel (by time): achieved = its algorithmic FLOPs per launch / its average
+    launch duration, peak = dense MFMA peak of the operand dtype.  The HBM view of the same step sits in `hbm`:
+    algorithmic bytes (§8d: rays, targets, outputs, weights read forward + backward, gradients written), the bytes
+    the design really moves (`stash_bytes`: activations written by forward / backward and read once by the
+    weight-gradient kernel) and, when profiles/ holds a PMC summary for this configuration, the measured traffic."""
+    L.KERNEL_TIMES = {}
+    for _ in range(a.steps):
+        fwd_bwd()           # rank-local: no collective here, the other ranks are not in this pass
+        opt.step()
+    times = L.collect_kernel_times()
+    L.KERNEL_TIMES = None
+    tot = {k: sum(v) for k, v in times.items()}
+    flops_pass = sum(2.0 * macs_per_point(p) * pts for p, pts in progs.values())      # one of fwd / bwd / wgrad
+    mode = 1 if a.precision == "bf16" else 0
+    tile_bytes = 2048 if a.precision == "bf16" else 4096
+    stash_read = 0.0
+    for prog, pts_list in _points_by_program(progs):
+        for pts in pts_list:
+            j = prog.wgrad_jobs(mode, pts)
+            stash_read += float(((j["n_nt"] + j["n_kt"]).astype("int64") * (j["blk1"] - j["blk0"])).sum()) * tile_bytes
+    groups = {"forward": ("hn_mlp_forward", "hn_level_forward"), "backward": ("hn_mlp_backward", "hn_level_backward"),
+              "wgrad": ("hn_mlp_wgrad",)}
+    sym = {"forward": "hn_mlp_fwd_kernel", "backward": "hn_mlp_bwd_kernel", "wgrad": "hn_wgrad_kernel"}
+    per_kernel, kern = {}, {}
+    for g, prefixes in groups.items():
+        ks = [k for k in tot if k.split("[")[0].startswith(prefixes)]
+        if not ks:
+            continue
+        ms_step = sum(tot[k] for k in ks) / a.steps
+        launches = sum(len(times[k]) for k in ks) / a.steps
+        kern[g] = (ms_step, launches)
+        mf = flops_pass / (ms_step * 1e-3)
+        per_kernel[sym[g]] = {"ms_per_step": ms_step, "launches_per_step": launches,
+                              "mfma": {"achieved": mf / 1e12, "peak": PEAK[a.precision] / 1e12, "unit": "TFLOP/s",
+                                       "frac": mf / PEAK[a.precision], "algorithmic_flops_per_step": flops_pass}}
+    out = {}
+    if kern:
+        dom = max(kern, key=lambda k: kern[k][0])
+        ms_step, launches = kern[dom]
+        pk = per_kernel[sym[dom]]["mfma"]
+        traffic = _pmc_traffic(a)
+        # SURVEY.md §8d: rays 36 B + target 12 B + outputs 20 B per ray; weights read once forward and once backward
+        # in the operand dtype; fp32 gradients written once
+        uniq = {id(p): p for p, _ in progs.values()}
+        n_params = sum(sum(q.numel() for q in p.params) for p in uniq.values())
+        alg_bytes = b * 68.0 + 2.0 * n_params * (2 if a.precision == "bf16" else 4) + 4.0 * n_params
+        rl = {"bound": "mfma", "kernel": sym[dom] + ("<true>" if a.precision == "bf16" else "<false>"),
+              "achieved": pk["achieved"], "peak": pk["peak"], "unit": "TFLOP/s", "frac": pk["frac"],
+              "traffic": None, "avg_launch_ms": ms_step / launches, "launches_per_step": launches,
+              "algorithmic_flops_per_launch": flops_pass / launches,
+              "note": "dominant kernel by time; achieved = GEMM FLOPs of its launches in a step (SURVEY.md §8d: 2 x "
+                      "MACs of every Linear x evaluated points) / their summed HIP-event duration on the launch "
+                      "stream; traffic = measured HBM bytes per launch of that kernel (profiles/, PMC passes)",
+              "per_kernel": per_kernel,
+              "kernel_ms_per_step": {k: tot[k] / a.steps for k in sorted(tot, key=tot.get, reverse=True)},
+              "sum_kernel_ms_per_step": sum(tot.values()) / a.steps}
+        hbm = {"algorithmic_bytes_per_step": alg_bytes, "stash_bytes_read_per_step": stash_read,
+               "stash_bytes_moved_per_step": 2.0 * stash_read, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+               "wgrad_stream_achieved": (stash_read / (kern["wgrad"][0] * 1e-3) / 1e9) if "wgrad" in kern else None,
+               "traffic_per_step": None, "wasted_ratio": None}
+        if traffic is not None:
+            hbm["traffic_per_step"] = traffic["bytes_per_step"]
+            hbm["wasted_ratio"] = traffic["bytes_per_step"] / alg_bytes
+            hbm["traffic_source"] = traffic["source"]
+            rl["traffic"] = traffic["per_kernel_launch"].get(sym[dom])
+        out["roofline"] = rl
+        out["hbm"] = hbm
+    out["step_tflops"] = 3.0 * flops_pass / step_s / 1e12
+    out["step_mfma_frac"] = 3.0 * flops_pass / step_s / PEAK[a.precision]
+    return out
+
+
+def _points_by_program(progs):
+    by = {}
+    for name, (prog, pts) in progs.items():
+        by.setdefault(id(prog), (prog, []))[1].append(pts)
+    return list(by.values())
+
+
+def _pmc_traffic(a):
+    """HBM bytes per step measured with rocprofv3 PMC passes on this configuration (tools/collect_profiles.sh ->
+    tools/make_profiles.py -> profiles/rNN_traffic_configC.json), newest round first; None if not collected."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_config{a.config}.json")), reverse=True)
+    for h in hits:
+        try:
+            t = json.load(open(h))
+            if t.get("rays") == a.rays and t.get("nc") == a.nc and t.get("nf") == a.nf:
+                t["source"] = os.path.relpath(h, ROOT)
+                return t
+        except (OSError, ValueError):
+            pass
+    return None
+
+
 def cpu_baseline(a):
-    """The CPU oracle (oracle/hypernerf_oracle.py, validated against the reference's own outputs) timed on
-    this node's host cores on a bounded sample of the same workload, fp32."""
+    """The CPU oracle (oracle/hypernerf_oracle.py, validated against the reference's own outputs) timed on this
+    node's host cores, fp32, forward + backward: on the FULL ray batch of the configuration when that fits the time
+    budget (config 2: 1024 rays), else on a 2048-ray sample (config 3; per-ray-sample rate)."""
     import hashprng as H
     from gpu_common import EMB, rays_for
     from hypernerf_torch_amd.hypernerf.models import NerfModel
@@ -250,32 +349,33 @@ def cpu_baseline(a):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
-    b = 64
+    b = min(a.rays, 2048)
     kw = dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True)
     m = NerfModel(EMB, n_samples_coarse=a.nc, n_samples_fine=a.nf, noise_std=1.0, view_fourier_dim=6, **kw)
     p = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
     cfg = O.ModelCfg(n_samples_coarse=a.nc, n_samples_fine=a.nf, noise_std=1.0, view_fourier_dim=6, **kw)
-    o, d, idx = rays_for(1, b)
-    gt = H.uniform(1, "gt", (b, 3), 0, 1)
 
-    def one():
-        rng = {"t_rand": torch.rand(b, a.nc), "noise_coarse": torch.randn(b, a.nc, 1),
-               "u": torch.rand(b, a.nf), "noise_fine": torch.randn(b, a.nc + a.nf, 1)}
+    def one(n):
+        o, d, idx = rays_for(1, n)
+        gt = H.uniform(1, "gt", (n, 3), 0, 1)
+        rng = {"t_rand": torch.rand(n, a.nc), "noise_coarse": torch.randn(n, a.nc, 1),
+               "u": torch.rand(n, a.nf), "noise_fine": torch.randn(n, a.nc + a.nf, 1)}
         for v in p.values():
             v.grad = None
         out = O.nerf_model_forward(p, cfg, o, d, idx, rng)
         O.mse_loss(out, gt).backward()
 
-    one()
+    one(64)                         # warm-up (thread pool, allocator) on a small batch
     t0 = time.perf_counter()
     n = 0
-    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 50):
-        one()
+    while n < 2 or (time.perf_counter() - t0 < 12.0 and n < 10):
+        one(b)
         n += 1
     dt = (time.perf_counter() - t0) / n
     return {"value": b * (a.nc + a.nf) / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{b} rays x ({a.nc}+{a.nf}) samples, fp32, fwd+bwd (no optimizer), "
-                                      f"{n} timed iterations after 1 warm-up"}
+            "kind": "port", "sample": f"{b} rays x ({a.nc}+{a.nf}) samples (the configuration's batch"
+                                      f"{'' if b == a.rays else ', capped at 2048 rays'}), fp32, fwd+bwd (no "
+                                      f"optimizer), {n} timed iterations after a 64-ray warm-up"}
 
 
 if __name__ == "__main__":

@@ -20,8 +20,8 @@ SOURCES = ["hn_mlp.hip", "hn_render.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hn_kernels.h")
 
 HN_MODE_F32, HN_MODE_BF16 = 0, 1
-HN_MAX_SRC, HN_MAX_DST, HN_MAX_SLOTS = 8, 4, 64
-HN_OP_WORDS, HN_CHUNK_UNITS, HN_DSRC_COMPS = 8, int(os.environ.get("HN_CHUNK_UNITS", 32)), 16
+HN_MAX_SRC, HN_MAX_DST, HN_MAX_SLOTS = 8, 4, 128
+HN_OP_WORDS, HN_CHUNK_UNITS, HN_DSRC_COMPS = 8, int(os.environ.get("HN_CHUNK_UNITS", 32)), 32
 HN_AUXG_MAX = 3
 HN_MAX_COMPS = 32
 
@@ -33,7 +33,8 @@ HN_FEAT_ZERO, HN_FEAT_ID, HN_FEAT_SIN, HN_FEAT_COS, HN_FEAT_SINP, HN_FEAT_ID_DIR
 
 
 class HnSrc(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int32), ("per_ray", C.c_int32)]
+    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int32), ("per_ray", C.c_int32), ("gather_idx", C.c_void_p),
+                ("gather_rows", C.c_int32), ("pad", C.c_int32)]
 
 
 class HnDst(C.Structure):
@@ -52,7 +53,9 @@ class HnMlpArgs(C.Structure):
         ("ops", C.c_void_p), ("wstream", C.c_void_p), ("bias", C.c_void_p), ("feat", C.c_void_p),
         ("stash", C.c_void_p), ("masks", C.c_void_p), ("dsrc", C.c_void_p),
         ("src", HnSrc * HN_MAX_SRC), ("dst", HnDst * HN_MAX_DST), ("slots", HnSlot * HN_MAX_SLOTS),
-        ("prof", C.c_void_p), ("comps", C.c_void_p), ("n_comps", C.c_int32), ("pad1", C.c_int32),
+        ("prof", C.c_void_p), ("comps", C.c_void_p), ("n_comps", C.c_int32), ("embed_reg_mask", C.c_int32),
+        ("embed_grad", C.c_void_p), ("embed_idx", C.c_void_p), ("embed_rows", C.c_int32), ("embed_dim", C.c_int32),
+        ("embed_col", C.c_int8 * 32),
     ]
 
 

@@ -100,8 +100,14 @@ class ParamArena:
     def zero_grad(self):
         self.grad.zero_()
 
+    def all_reduce_sum(self, group=None):
+        """SUM the gradient buffer across ranks: one all-reduce, in place.  The 1/world of the mean is applied by the
+        consumer (ArenaAdam's grad_scale: no separate division launch)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+
     def all_reduce_mean(self, group=None):
-        """Average the gradient buffer across ranks: one all-reduce, in place."""
+        """Average the gradient buffer across ranks: one all-reduce, in place (for optimizers without grad_scale)."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
             self.grad.div_(dist.get_world_size(group))

@@ -66,17 +66,25 @@ struct WStream {
 // ------------------------------------------------------------------------------------------------
 // Per 32-point block the source components a program reads (HnMlpArgs.comps) are staged once into LDS
 // (srcv[ci][point]); a feature then costs two LDS reads (table entry, value) instead of a chain of global loads.
+// A source without a pointer is skipped: its components are published by the program itself (HN_OP_OUT w7).  A per-ray
+// source with a gather index reads row gather_idx[ray] (the GLO lookup); an index outside the table stages NaN.
 HN_DEV void hn_stage_sources(float* srcv, const HnMlpArgs& a, int p, int ray, int lane) {
   const int r = lane & 31, h = lane >> 5;
   for (int ci = h; ci < a.n_comps; ci += 2) {
     const int c = a.comps[ci];
     const int sid = c >> 16, col = c & 0xffff;
-    const float* base = a.src[0].ptr;
-    int ld = a.src[0].ld, pr = a.src[0].per_ray;
-    if (sid == 1) { base = a.src[1].ptr; ld = a.src[1].ld; pr = a.src[1].per_ray; }
-    if (sid == 2) { base = a.src[2].ptr; ld = a.src[2].ld; pr = a.src[2].per_ray; }
-    if (sid == 3) { base = a.src[3].ptr; ld = a.src[3].ld; pr = a.src[3].per_ray; }
-    srcv[ci * 32 + r] = base[(size_t)(pr ? ray : p) * ld + col];
+    HnSrc s = a.src[0];
+    if (sid == 1) s = a.src[1];
+    if (sid == 2) s = a.src[2];
+    if (sid == 3) s = a.src[3];
+    if (s.ptr == nullptr) continue;
+    long long row = s.per_ray ? ray : p;
+    bool ok = true;
+    if (s.gather_idx != nullptr) {
+      row = s.gather_idx[ray];
+      ok = row >= 0 && row < s.gather_rows;
+    }
+    srcv[ci * 32 + r] = ok ? s.ptr[(size_t)row * s.ld + col] : __builtin_nanf("");
   }
 }
 
@@ -488,6 +496,22 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
                 }
               }
             }
+            if (has_out && t == 0 && h == 0 && out_w[7] > 0) {
+              // publish the head's results as staged components of this block (every lane: padded points too)
+              const int n = out_w[3];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (i < n) {
+                  float y = acc[i];
+                  if (out_w[4] == 1) y = 1.0f / (1.0f + expf(-y));
+                  if (out_w[5] >= 0) {
+                    const HnSrc sr = a.src[out_w[5]];
+                    y = __fadd_rn(sr.ptr[(size_t)(sr.per_ray ? ray : p) * sr.ld + out_w[6] + i], y);
+                  }
+                  srcv[(out_w[7] - 1 + i) * 32 + r] = y;
+                }
+              }
+            }
             hn_acc_to_frags(acc, nxt + t * M::STEPS32);
 #ifdef HN_PROF
             if (prof_on) {   // make the stamp wait for the tile's results
@@ -617,19 +641,33 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const int n = w[3] & 255;
         const bool to2 = (w[3] >> 8) & 1;
         float d[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((w[3] >> 9) & 1) {
+          // the gradient later ops left in the source-gradient accumulators for the components this head published:
+          // slots 8q + i sit in registers 4q + i of the h == 0 lanes (row rho(4q + i, 0) = 8q + i)
+          const int q = (w[3] >> 10) & 3;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            d[i] = q == 0 ? dacc[i] : (q == 1 ? dacc[4 + i] : (q == 2 ? dacc[8 + i] : dacc[12 + i]));
+        }
         if (h == 0 && valid) {
-          const HnSrc s = a.src[w[1]];
+          const HnSrc s = a.src[w[1] < 0 ? 0 : w[1]];
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (i < n) {
-              float g = s.ptr[(size_t)p * s.ld + w[2] + i];
+              float g = (w[1] >= 0 && s.ptr != nullptr) ? s.ptr[(size_t)p * s.ld + w[2] + i] : 0.0f;
+              if ((w[3] >> 9) & 1) g += d[i];
               if (w[4] == 1) {
                 const HnSrc ys = a.src[w[5]];
                 const float y = ys.ptr[(size_t)p * ys.ld + w[6] + i];
                 g = g * y * (1.0f - y);
               }
               d[i] = g;
+            } else {
+              d[i] = 0.0f;
             }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) d[i] = 0.0f;
         }
         Frag tmp[M::STEPS32];
         hn_zero_frags(tmp, M::STEPS32);
@@ -739,11 +777,27 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
       }
     }
     // source gradients of this block -> global
-    if (a.n_dsrc > 0 && p0 < a.n_points) {
+    if (a.n_dsrc > 0 && a.dsrc != nullptr && p0 < a.n_points) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int slot = hn_rho(i, h);
         if (slot < a.n_dsrc) a.dsrc[(size_t)p0 * a.n_dsrc + slot] = dacc[i];
+      }
+    }
+    // GLOEmbed backward (modules.py:155-167 under autograd): the block's 32 points belong to one ray, so the
+    // gradient of the gathered row is the sum over the lanes of each half, added once per block and component
+    if (a.embed_reg_mask != 0 && wave_valid) {
+      const long long erow = a.embed_idx[(blk * 32) / a.samples_per_ray];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (a.embed_reg_mask & (1 << i)) {
+          float v = valid ? dacc[i] : 0.0f;
+#pragma unroll
+          for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+          const int col = a.embed_col[hn_rho(i, h)];
+          if (r == 0 && col >= 0 && erow >= 0 && erow < a.embed_rows)
+            atomicAdd(a.embed_grad + (size_t)erow * a.embed_dim + col, v);
+        }
       }
     }
   }
@@ -1073,6 +1127,7 @@ extern "C" int hn_abi_sizes(int32_t* out, int n) {
                         (int32_t)sizeof(HnDwJob),        (int32_t)sizeof(HnCompositeArgs), (int32_t)sizeof(HnFeat),
                         (int32_t)sizeof(HnSlot),         (int32_t)sizeof(HnSrc)};
   static_assert(sizeof(HnDwBatch) == 32, "HnDwBatch layout");
+  static_assert(sizeof(HnSrc) == 32, "HnSrc layout");
   for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   return 8;
 }

@@ -482,9 +482,10 @@ __global__ void hn_embed_gather_kernel(const float* __restrict__ table, const in
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rays * dim) return;
   const int b = i / dim, c = i % dim;
-  int64_t row = idx[b];
-  row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
-  out[i] = table[row * dim + c];
+  // an index outside the table poisons its row with NaN (nn.Embedding raises a device assert there; a silent clamp
+  // would train the wrong row): the loss goes NaN at once instead of rendering a wrong image
+  const int64_t row = idx[b];
+  out[i] = (row < 0 || row >= n_rows) ? __builtin_nanf("") : table[row * dim + c];
 }
 
 __global__ __launch_bounds__(256) void hn_embed_bwd_kernel(const float* __restrict__ d_points, int ld, int col0,
@@ -493,8 +494,8 @@ __global__ __launch_bounds__(256) void hn_embed_bwd_kernel(const float* __restri
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
-  int64_t row = idx[ray];
-  row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+  const int64_t row = idx[ray];
+  if (row < 0 || row >= n_rows) return;       // no row to receive it (the forward already produced NaN)
   for (int c = 0; c < dim; ++c) {
     float v = 0.0f;
     for (int s = lane; s < S; s += 64) v += d_points[((size_t)ray * S + s) * ld + col0 + c];

@@ -50,7 +50,8 @@ class GradBucket:
             return
         from .arena import ParamArena
         arena = ParamArena.lookup(self.params)
-        if arena is not None and arena[0].params == self.params:
+        if arena is not None and len(arena[0].params) == len(self.params) and \
+                all(a is b for a, b in zip(arena[0].params, self.params)):
             arena[0].all_reduce_mean(group)      # the gradients already are one flat buffer: reduce it in place
             return
         self._ensure(self.params[0].device)

@@ -41,28 +41,41 @@ class ProgramCall:
     """A compiled program + how its sources / outputs map to tensors."""
 
     def __init__(self, program: Program, src_per_ray: Sequence[bool], dst_widths: Sequence[int],
-                 grad_srcs: Sequence[Tuple[str, int]]):
-        # grad_srcs[i] describes backward source 4+i: ('g', k) = gradient of output k, ('y', k) = output k
+                 grad_srcs: Sequence[Tuple[str, int]], gather_src: Optional[int] = None,
+                 bwd_src_from_out: Optional[Dict[int, int]] = None):
+        # grad_srcs[i] describes backward source 4+i: ('g', k) = gradient of output k (zeros if autograd has none),
+        # ('go', k) = the same but simply absent when autograd has none, ('y', k) = output k
+        # gather_src: index of a per-ray source given as (table, ray indices): the kernels read table[idx[ray]]
+        # bwd_src_from_out: {source index: output index} — sources the forward publishes itself (no pointer) and
+        # the backward reads back from the forward's output tensor (fused level programs)
         self.program = program
         self.runner = MlpRunner(program)
         self.src_per_ray = list(src_per_ray)
         self.dst_widths = list(dst_widths)
         self.grad_srcs = list(grad_srcs)
+        self.gather_src = gather_src
+        self.bwd_src_from_out = dict(bwd_src_from_out or {})
         self.cache = {}
 
 
 class _ProgramFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, call: ProgramCall, mode: int, samples_per_ray: int, n_src: int, training: bool, *tensors):
+    def forward(ctx, call: ProgramCall, mode: int, samples_per_ray: int, n_src: int, training: bool, gather_idx,
+                *tensors):
         srcs = list(tensors[:n_src])
         L.require_gpu(*[s for s in srcs if s is not None])
         first = next(s for s in srcs if s is not None)
         device = first.device
         n_points = None
         flat_srcs = []
-        for s, per_ray in zip(srcs, call.src_per_ray):
+        for i, (s, per_ray) in enumerate(zip(srcs, call.src_per_ray)):
             if s is None:
                 flat_srcs.append(None)
+                continue
+            if i == call.gather_src:
+                if gather_idx is None or s.dim() != 2:
+                    raise L.HnError("a gathered source needs a (rows, dim) table and int64 ray indices")
+                flat_srcs.append((s.detach().contiguous(), True, gather_idx.reshape(-1).to(torch.int64).contiguous()))
                 continue
             s2 = s.detach()
             if s2.dim() != 2 or s2.stride(-1) != 1:          # row-strided 2-D views are read in place (ld = stride)
@@ -78,6 +91,7 @@ class _ProgramFn(torch.autograd.Function):
         stash, masks = call.runner.forward(mode, n_points, samples_per_ray, flat_srcs, outs, training)
         ctx.call, ctx.mode, ctx.spr, ctx.n_src, ctx.n_points = call, mode, samples_per_ray, n_src, n_points
         ctx.flat_srcs = flat_srcs
+        ctx.tables = {call.gather_src: srcs[call.gather_src]} if call.gather_src is not None else {}
         ctx.src_shapes = [None if s is None else s.shape for s in srcs]
         ctx.src_tags = [None if s is None else getattr(s, "_hn_embed", None) for s in srcs]
         ctx.stash, ctx.masks = stash, masks
@@ -90,29 +104,62 @@ class _ProgramFn(torch.autograd.Function):
         if ctx.stash is None:
             raise L.HnError("backward through a program that ran without training=True")
         bsrcs = list(ctx.flat_srcs) + [None] * (4 - len(ctx.flat_srcs))
+        for i, k in call.bwd_src_from_out.items():
+            bsrcs[i] = (ctx.outs[k], False)
         for kind, k in call.grad_srcs:
-            if kind == "g":
+            if kind in ("g", "go"):
                 g = gouts[k]
                 if g is None:
+                    if kind == "go":
+                        bsrcs.append(None)
+                        continue
                     g = torch.zeros_like(ctx.outs[k])
                 bsrcs.append((g if (g.dim() == 2 and g.stride(-1) == 1) else g.contiguous(), False))
             else:
                 bsrcs.append((ctx.outs[k], False))
         # parameters attached to a ParamArena: accumulate into its gradient buffer, return nothing through autograd
         prog = call.program
-        wants = [ctx.needs_input_grad[5 + ctx.n_src + j] for j in range(len(prog.params))]
+        base = 6 + ctx.n_src
+        wants = [ctx.needs_input_grad[base + j] for j in range(len(prog.params))]
         target = ParamArena.lookup(prog.params) if all(wants) else None
+        # the gathered per-ray source (GLO table): its gradient is reduced and scattered inside the backward machine
+        embed, d_table, table_ret = None, None, None
+        gs = call.gather_src
+        gather_cols = {c: sl for (si, c), sl in prog.dsrc_map.items() if si == gs} if gs is not None else {}
+        if gs is not None and ctx.needs_input_grad[6 + gs] and gather_cols:
+            table = ctx.tables[gs]
+            tt = ParamArena.lookup([table]) if isinstance(table, torch.nn.Parameter) else None
+            if tt is not None:
+                d_table = table.grad                      # the arena's view: accumulate in place
+            else:
+                d_table = table_ret = torch.zeros(table.shape, dtype=torch.float32, device=table.device)
+            if ctx.spr % 32 == 0:
+                embed = (d_table, ctx.flat_srcs[gs][2], gs)
+        others = [i for i, shp in enumerate(ctx.src_shapes)
+                  if shp is not None and i != gs and ctx.needs_input_grad[6 + i]
+                  and any(si == i for (si, _c) in prog.dsrc_map)]
+        want_dsrc = bool(others) or (d_table is not None and embed is None)
         dsrc, flat = call.runner.backward(ctx.mode, ctx.n_points, ctx.spr, bsrcs, ctx.stash, ctx.masks,
                                           grad_target=(target[0].grad, target[1]) if target else None,
-                                          defer=BATCH_WGRADS)
+                                          defer=BATCH_WGRADS, embed=embed, want_dsrc=want_dsrc)
         if isinstance(flat, PendingWgrad):
             _defer_wgrad(flat)
             flat = None
         ctx.stash = ctx.masks = None
         src_grads: List[Optional[torch.Tensor]] = []
         for i, shp in enumerate(ctx.src_shapes):
-            if shp is None or not ctx.needs_input_grad[5 + i]:
+            if shp is None or not ctx.needs_input_grad[6 + i]:
                 src_grads.append(None)
+                continue
+            if i == gs:
+                if d_table is not None and embed is None:     # ragged rays: per-ray reduction + scatter as two launches
+                    width = shp[-1]
+                    n_rays = ctx.n_points // ctx.spr
+                    rows = sum_samples(dsrc, gather_cols, n_rays, ctx.spr, width)
+                    L.launch("hn_embed_backward", L.ptr(rows), C.c_int(width), C.c_int(0), L.ptr(ctx.flat_srcs[gs][2]),
+                             C.c_int(n_rays), C.c_int(1), C.c_int(width), C.c_int(shp[0]), L.ptr(d_table),
+                             L.stream_handle())
+                src_grads.append(table_ret)
                 continue
             cols = {c: s for (si, c), s in prog.dsrc_map.items() if si == i}
             if not cols:
@@ -138,10 +185,10 @@ class _ProgramFn(torch.autograd.Function):
                     g = g * idx[1]
             src_grads.append(g.view(shp))
         if flat is None:
-            return (None, None, None, None, None, *src_grads, *([None] * len(prog.params)))
+            return (None, None, None, None, None, None, *src_grads, *([None] * len(prog.params)))
         pgrads = call.runner.split_grads(flat)
         out_p = [pgrads[j] if wants[j] else None for j in range(len(prog.params))]
-        return (None, None, None, None, None, *src_grads, *out_p)
+        return (None, None, None, None, None, None, *src_grads, *out_p)
 
 
 # Arena mode: the weight-gradient kernels of all programs of one backward pass run as ONE launch, queued as an
@@ -168,12 +215,14 @@ def _defer_wgrad(p: PendingWgrad):
 
 
 def run_program(call: ProgramCall, srcs: Sequence[Optional[torch.Tensor]], samples_per_ray: int,
-                precision: Optional[str] = None) -> Tuple[torch.Tensor, ...]:
+                precision: Optional[str] = None, gather_idx: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:
+    """srcs[call.gather_src], if any, is the (rows, dim) table itself and `gather_idx` the (B,) int64 row per ray."""
     L.load()
     params = call.program.params
     training = torch.is_grad_enabled() and (any(s is not None and s.requires_grad for s in srcs) or
                                             any(p.requires_grad for p in params))
-    return _ProgramFn.apply(call, mode_of(precision), int(samples_per_ray), len(srcs), training, *srcs, *params)
+    return _ProgramFn.apply(call, mode_of(precision), int(samples_per_ray), len(srcs), training, gather_idx, *srcs,
+                            *params)
 
 
 _ARANGE: Dict[tuple, torch.Tensor] = {}

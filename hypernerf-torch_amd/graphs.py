@@ -28,4 +28,8 @@ class GraphedStep:
 
     def __call__(self):
         self.graph.replay()
+        # the replay may have stepped an optimizer (parameters changed behind Python's back): packed weight streams
+        # of inference forwards that follow must be rebuilt
+        from . import machine
+        machine.note_parameters_changed()
         return self.out

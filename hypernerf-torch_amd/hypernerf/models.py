@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import functional as F
-from ..machine import AuxSpec, Program, copy_features, posenc_features
+from ..machine import AuxSpec, GradIn, OutSpec, Program, copy_features, posenc_features
 from . import model_utils, modules, warping
 
 
@@ -225,6 +225,88 @@ class NerfModel(nn.Module):
             self._template_calls[key] = call
         return call
 
+    # ---- fused level program -------------------------------------------------------------------
+    FUSE_LEVELS = True      # warp field -> hyper sheet -> template as ONE launch per level where the model allows it
+
+    def _can_fuse_level(self, use_warp: bool, metadata_encoded: bool, metadata) -> bool:
+        """One launch per level needs: a TranslationField warp, hyper coordinates from the sheet MLP (or none), and
+        ONE GLO table + index for every embedding the level consumes (the only constructible configuration of the
+        reference, share_GLO: models.py:167-186), looked up by the kernels themselves."""
+        if not (self.FUSE_LEVELS and use_warp and self.use_warp) or metadata_encoded:
+            return False
+        if not isinstance(self.warp_field, warping.TranslationField):
+            return False
+        if self.hyper_slice_method not in ('bendy_sheet', 'none'):
+            return False
+        if self.hyper_slice_method == 'bendy_sheet' and not self.hyper_use_warp_embed:
+            return False
+        if self.use_nerf_embed and not self.hyper_use_warp_embed:
+            return False
+        if metadata.get('hyper_point') is not None:
+            return False
+        return self.hyper_sheet_out_dim <= 4 or self.hyper_slice_method == 'none'
+
+    def _level_call(self, level: str) -> F.ProgramCall:
+        """The whole level as one program of the MLP machine (reference: map_points models.py:545-581 followed by
+        query_template models.py:447-493).  Sources: 0 = sample points (P,3), 1 = viewdirs (B,3), 2 = the GLO table
+        (gathered with the ray's index), 3 = the warped points — published by the warp / sheet heads in the forward
+        launch (they never leave the workgroup), read back from the output tensor in the backward launch.
+        Outputs: 0 = warped points (P, 3+H), 1 = rgb (P,3), 2 = alpha (P,1)."""
+        key = ("level", level)
+        call = self._template_calls.get(key)
+        if call is None:
+            m = self.nerf_mlps_fine if level == 'fine' else self.nerf_mlps_coarse
+            G = self.GLO_dim
+            wf = self.warp_field
+            layers = modules.mlp_layers(wf.mlp, "warp_field.mlp", wf.input_aux(0, 2, False, True), None,
+                                        OutSpec(0, 0, "none", residual=(0, 0), publish=(3, 0)),
+                                        GradIn(7, 0, from_dsrc=(3, 0)))
+            h = 0
+            if self.hyper_slice_method == 'bendy_sheet':
+                hs = self.hyper_sheet_mlp
+                h = hs.out_ch
+                layers += modules.mlp_layers(hs.mlp, "hyper_sheet_mlp.mlp", hs.input_aux(0, 2, False, True), None,
+                                             OutSpec(0, 3, "none", publish=(3, 3)), GradIn(7, 3, from_dsrc=(3, 3)))
+            feats = posenc_features(3, range(3), self.xyz_freq, True)
+            if h:
+                feats += posenc_features(3, range(3, 3 + h), self.hyper_freq, True)
+            if len(feats) != m.in_ch:
+                raise RuntimeError(f"template input has {len(feats)} channels, the MLP expects {m.in_ch}")
+            rgb_feats = posenc_features(1, range(3), self.dir_freq, False) if self.use_viewdirs else []
+            alpha_aux = None
+            if self.use_nerf_embed:
+                if self.use_alpha_condition:
+                    alpha_aux = AuxSpec(copy_features(2, range(G), True))
+                if self.use_rgb_condition:
+                    rgb_feats += copy_features(2, range(G), True)
+            layers += modules.nerf_mlp_layers(m, f"nerf_mlps_{level}", AuxSpec(feats), alpha_aux,
+                                              AuxSpec(rgb_feats) if rgb_feats else None, dst_rgb=1, dst_alpha=2)
+            call = F.ProgramCall(Program(layers, name=f"level_{level}"), [False, True, True, False], [3 + h, 3, 1],
+                                 [("g", 1), ("g", 2), ("y", 1), ("go", 0)], gather_src=2, bwd_src_from_out={3: 0})
+            self._template_calls[key] = call
+        return call
+
+    def compiled_programs(self, n_rays: int):
+        """[(name, machine.Program, points evaluated per forward pass of `n_rays` rays)] of the programs this model has
+        compiled so far (i.e. after a forward pass) — what bench.py prices the MFMA roofline with."""
+        nc, nf = self.num_coarse_samples, self.num_fine_samples
+        out = []
+        fused = False
+        for key, call in self._template_calls.items():
+            if key[0] == "level":
+                out.append((f"level_{key[1]}", call.program, n_rays * (nc if key[1] == 'coarse' else nc + nf)))
+                fused = True
+            else:
+                out.append((f"template_{key[0]}", call.program, n_rays * (nc if key[0] == 'coarse' else nc + nf)))
+        if fused:
+            return [o for o in out if o[0].startswith("level_")]
+        both = n_rays * (2 * nc + nf)
+        for attr, name in (("warp_field", "warp_field"), ("hyper_sheet_mlp", "hyper_sheet_mlp")):
+            mod = getattr(self, attr, None)
+            for call in getattr(mod, "_calls", {}).values():
+                out.append((name, call.program, both))
+        return out
+
     def get_condition_inputs(self, viewdirs, metadata, metadata_encoded=False):
         """The GLO part of the template conditions (reference: models.py:404-445); view-direction encoding is
         generated inside the template machine."""
@@ -271,6 +353,19 @@ class NerfModel(nn.Module):
                         & (points[..., 1] <= ymax) & (points[..., 2] >= zmin) & (points[..., 2] <= zmax)).float()
         b, s = points.shape[0], points.shape[1]
         out = {'points': points}
+        if self._can_fuse_level(use_warp, metadata_encoded, metadata):
+            if return_warp_jacobian:
+                raise NotImplementedError
+            idx = metadata[self.warp_embed_key]
+            if idx.shape[-1] == 1 and idx.dim() > 1:
+                idx = idx.squeeze(-1)
+            call = self._level_call(level)
+            warped, rgb, alpha = F.run_program(call, [points.reshape(b * s, 3), viewdirs if self.use_viewdirs else None,
+                                                      self.warp_embed.embed.weight, None], s, self.precision,
+                                               gather_idx=idx)
+            warped = warped.view(b, s, -1)
+            return self._composite_level(out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity,
+                                         dust, keep, b, s, points.device)
         if use_warp:
             warp_embed = metadata['encoded_warp'] if metadata_encoded else self.warp_embed(metadata[self.warp_embed_key])
         else:
@@ -293,8 +388,15 @@ class NerfModel(nn.Module):
         call = self._template_call(level, n_ch, ge, ge and n_ch > 3)
         rgb, alpha = F.run_program(call, [warped.reshape(b * s, n_ch), viewdirs if self.use_viewdirs else None,
                                           nerf_embed], s, self.precision)
+        return self._composite_level(out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity,
+                                     dust, keep, b, s, points.device)
+
+    def _composite_level(self, out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity, dust, keep,
+                         b, s, device):
+        """noise_regularize + Softplus + filter_sigma + volumetric_rendering + median-depth gather
+        (models.py:485-489, 650-669) in the compositing kernel."""
         if noise is None and (self.noise_std is not None) and self.noise_std > 0.0 and self.use_stratified_sampling:
-            noise = torch.randn((b, s, 1), device=points.device, dtype=torch.float32) * self.noise_std
+            noise = torch.randn((b, s, 1), device=device, dtype=torch.float32) * self.noise_std
         res = F.composite(rgb.view(b, s, 3), alpha.view(b, s), noise, z_vals, directions, warped, variant=0,
                           white_bg=self.use_white_background, sample_at_infinity=use_sample_at_infinity,
                           want_median=True, dust_threshold=dust, keep=keep)

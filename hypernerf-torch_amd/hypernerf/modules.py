@@ -61,7 +61,7 @@ def mlp_layers(mlp: "MLP", prefix: str, input_aux: Optional[AuxSpec], main_in: O
     if out is not None and not out.wide:
         if out_act == "relu":
             raise NotImplementedError(f"{prefix}: ReLU on a narrow output head")
-        out = OutSpec(out.dst, out.col, out_act, out.residual, False)
+        out = OutSpec(out.dst, out.col, out_act, out.residual, False, out.publish)
         layers.append(Layer(f"{prefix}.logit_layer", lg.weight, lg.bias, main=(0, mlp.width), act="none",
                             commit=False, out=out, grad_in=grad_in))
     else:
@@ -143,18 +143,18 @@ class GLOEmbed(nn.Module):
 
 
 def nerf_mlp_layers(m: "NerfMLP", prefix: str, input_aux: AuxSpec, alpha_aux: Optional[AuxSpec],
-                    rgb_aux: Optional[AuxSpec]) -> List[Layer]:
+                    rgb_aux: Optional[AuxSpec], dst_rgb: int = 0, dst_alpha: int = 1) -> List[Layer]:
     """Layer list of NerfMLP.forward (hypernerf/modules.py:266-298): trunk -> bottleneck ->
-    {alpha head, rgb MLP}.  dst 0 = rgb (P,3), dst 1 = alpha (P,1); backward sources 4 = d rgb,
+    {alpha head, rgb MLP}.  dst `dst_rgb` = rgb (P,3), dst `dst_alpha` = alpha (P,1); backward sources 4 = d rgb,
     5 = d alpha, 6 = rgb (for sigmoid')."""
     layers = mlp_layers(m.trunk_mlp, f"{prefix}.trunk_mlp", input_aux, None, None, None)
     bw = m.bottleneck_mlp.weight.shape[0]
     layers.append(Layer(f"{prefix}.bottleneck_mlp", m.bottleneck_mlp.weight, m.bottleneck_mlp.bias,
                         main=(0, m.trunk_width), act="none"))
     layers.append(Layer(f"{prefix}.alpha_mlp", m.alpha_mlp.weight, m.alpha_mlp.bias, main=(0, bw), aux=alpha_aux,
-                        aux_c0=bw, act="none", commit=False, out=OutSpec(1, 0, "none"), grad_in=GradIn(5, 0)))
+                        aux_c0=bw, act="none", commit=False, out=OutSpec(dst_alpha, 0, "none"), grad_in=GradIn(5, 0)))
     rgb_act = _act_name(m.rgb_mlp.output_activation, prefix + ".rgb_mlp")
-    layers += mlp_layers(m.rgb_mlp, f"{prefix}.rgb_mlp", rgb_aux, bw, OutSpec(0, 0, rgb_act),
+    layers += mlp_layers(m.rgb_mlp, f"{prefix}.rgb_mlp", rgb_aux, bw, OutSpec(dst_rgb, 0, rgb_act),
                          GradIn(4, 0, (6, 0) if rgb_act == "sigmoid" else None))
     return layers
 

@@ -70,3 +70,35 @@ def render_image(model, rays: torch.Tensor, chunk: int = 16384, level: str = 'fi
             x = torch.cat(parts, dim=0)
         result[k] = x
     return result
+
+
+@torch.no_grad()
+def evaluate_images(model, images, chunk: int = 16384, white_back: bool = False, save_dir=None, group=None) -> Dict:
+    """The per-image loop of the reference's eval.py:145-178 on the GPU: for every sample {'rays': (H*W, 8|9),
+    'rgbs': (H*W, 3) optional, 'hw': (H, W) optional} render the fine level in chunks, form the (H, W, 3) image,
+    its 8-bit version (eval.py:165 `(img*255).astype(uint8)`) and, when ground truth is present, the PSNR
+    (metrics.psnr, eval.py:169-172).  Returns {'images': [uint8 (H,W,3) CPU tensors], 'depths': [...],
+    'psnrs': [float], 'mean_psnr': float | None}.  With `save_dir` the 8-bit frames are also written as binary PPM
+    (no image library in the hot path; the reference writes PNG through imageio, which is IO glue out of scope).
+    `white_back` is accepted and ignored as in the reference's batched_inference (eval.py:77-85)."""
+    from .losses import psnr as _psnr
+    imgs, depths, psnrs = [], [], []
+    for i, sample in enumerate(images):
+        rays = sample['rays']
+        res = render_image(model, rays, chunk=chunk, keys=('rgb', 'depth'), group=group)
+        n = rays.shape[0]
+        h, w = sample.get('hw', (1, n))
+        img = res['rgb'].view(h, w, 3)
+        img8 = (img * 255).to(torch.uint8).cpu()          # truncation, like numpy's astype(uint8) on [0, 1] data
+        imgs.append(img8)
+        depths.append(torch.nan_to_num(res['depth'].view(h, w)).cpu())
+        if sample.get('rgbs') is not None:
+            gt = sample['rgbs'].to(img.device).view(h, w, 3)
+            psnrs.append(float(_psnr(gt, img)))
+        if save_dir is not None:
+            import os
+            os.makedirs(save_dir, exist_ok=True)
+            with open(os.path.join(save_dir, f"{i:03d}.ppm"), "wb") as f:
+                f.write(f"P6 {w} {h} 255\n".encode() + img8.numpy().tobytes())
+    return {'images': imgs, 'depths': depths, 'psnrs': psnrs,
+            'mean_psnr': (sum(psnrs) / len(psnrs)) if psnrs else None}

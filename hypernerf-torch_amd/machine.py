@@ -102,13 +102,21 @@ class OutSpec:
     act: str = "none"                       # 'none' | 'sigmoid'
     residual: Optional[Tuple[int, int]] = None   # (src index, col)
     wide: bool = False
+    # (src, col0): the n results are ALSO published as the staged components (src, col0 + i) of the block, so that
+    # later layers of the same program can encode them (fused level: warp field / hyper sheet -> template).  The
+    # forward launch gets no pointer for that source; the backward launch reads it from the forward's output tensor.
+    publish: Optional[Tuple[int, int]] = None
+    publish_ci: int = -1                    # set by the program
 
 
 @dataclass
 class GradIn:
-    src: int                # backward source index (4..7) holding d(out) per point
+    src: int                # backward source index (4..7) holding d(out) per point; -1 = no external gradient
     col: int = 0
     sigmoid_y: Optional[Tuple[int, int]] = None   # (src index, col) of the forward output y
+    # (src, col0): add the source gradient the rest of the program accumulated for the published components
+    from_dsrc: Optional[Tuple[int, int]] = None
+    dacc_q: int = 0                         # set by the program: accumulator rows 8q .. 8q+3
 
 
 @dataclass
@@ -169,6 +177,31 @@ class Program:
     def _link(self):
         cur: Optional[Layer] = None
         pid = {}
+        # heads that publish their results as staged components get consecutive component indices; heads that take
+        # their gradient from the source-gradient accumulators get rows 8q .. 8q+3 (registers 4q .. 4q+3 of the
+        # lanes with h = 0, where the backward LOAD op needs them)
+        self.reserved_slots = set()
+        q = 0
+        for ly in self.layers:
+            o, gi = ly.out, ly.grad_in
+            if o is not None and o.publish is not None:
+                n = ly.weight.shape[0]
+                if o.wide or n > 4:
+                    raise ValueError(f"{ly.name}: only narrow heads can publish components")
+                o.publish_ci = len(self.comp_map)
+                for i in range(n):
+                    key = (o.publish[0], o.publish[1] + i)
+                    if key in self.comp_map:
+                        raise ValueError(f"{ly.name}: component {key} published twice")
+                    self.comp_map[key] = len(self.comp_map)
+            if gi is not None and gi.from_dsrc is not None:
+                if q >= 4:
+                    raise NotImplementedError("more than 4 heads fed from the source-gradient accumulators")
+                gi.dacc_q = q
+                for i in range(ly.weight.shape[0]):
+                    self.dsrc_map[(gi.from_dsrc[0], gi.from_dsrc[1] + i)] = 8 * q + i
+                self.reserved_slots.update(range(8 * q, 8 * q + 4))
+                q += 1
         for ly in self.layers:
             ly.n_out = ly.weight.shape[0]
             nt_valid = (ly.n_out + 31) // 32
@@ -209,7 +242,8 @@ class Program:
                                 raise NotImplementedError(
                                     f"{ly.name}: more than {L.HN_MAX_COMPS} distinct encoded source components")
                         if ft.need_grad and (ft.src, ft.comp) not in self.dsrc_map:
-                            self.dsrc_map[(ft.src, ft.comp)] = len(self.dsrc_map)
+                            used = set(self.dsrc_map.values()) | self.reserved_slots
+                            self.dsrc_map[(ft.src, ft.comp)] = next(k for k in range(L.HN_DSRC_COMPS + 1) if k not in used)
             if ly.main is None and ly.aux is None:
                 raise ValueError(f"{ly.name}: layer without input")
             total_in = (ly.main[1] if ly.main else 0) + (ly.aux.n if ly.aux else 0)
@@ -217,8 +251,10 @@ class Program:
                 raise ValueError(f"{ly.name}: inputs {total_in} != in_features {ly.weight.shape[1]}")
             if ly.commit:
                 cur = ly
-        if len(self.dsrc_map) > L.HN_DSRC_COMPS:
+        if self.n_dsrc > L.HN_DSRC_COMPS:
             raise NotImplementedError(f"{self.name}: more than {L.HN_DSRC_COMPS} source-gradient components")
+        if len(self.comp_map) > L.HN_MAX_COMPS:
+            raise NotImplementedError(f"{self.name}: more than {L.HN_MAX_COMPS} staged source components")
 
         consumers = {id(l.prev) for l in self.layers if l.prev is not None}
         for ly in self.layers:
@@ -233,7 +269,30 @@ class Program:
 
     @property
     def n_dsrc(self):
-        return len(self.dsrc_map)
+        """Rows of the source-gradient accumulator in use (slot numbers may have gaps: reserved head rows)."""
+        return max(self.dsrc_map.values()) + 1 if self.dsrc_map else 0
+
+    def chains(self) -> List[List[Layer]]:
+        """The layer list cut into chains: a layer without a main input (fed by generated features only) starts a new
+        network whose activations do not depend on `cur` — the warp field, the hyper sheet and the template of a
+        fused level program are three chains."""
+        out: List[List[Layer]] = []
+        for ly in self.layers:
+            if ly.main is None or not out:
+                out.append([])
+            out[-1].append(ly)
+        return out
+
+    def embed_fold(self, src: int):
+        """(register mask, slot -> table column) of the source-gradient rows that belong to per-ray source `src`:
+        what the backward machine needs to reduce them over a block and scatter them into the embedding gradient."""
+        col = [-1] * L.HN_DSRC_COMPS
+        mask = 0
+        for (s_, c), slot in self.dsrc_map.items():
+            if s_ == src:
+                col[slot] = c
+                mask |= 1 << ((slot & 3) + 4 * (slot >> 3))
+        return mask, col
 
     # ---- forward ops --------------------------------------------------------------------------
     def _build_fwd_ops(self) -> np.ndarray:
@@ -261,7 +320,8 @@ class Program:
                     ops.append([L.HN_OP_OUT_WIDE, o.dst, o.col, ly.n_out, ly.nt, 0, 0, 0])
                 else:
                     ops.append([L.HN_OP_OUT, o.dst, o.col, ly.n_out, 1 if o.act == "sigmoid" else 0,
-                                o.residual[0] if o.residual else -1, o.residual[1] if o.residual else 0, 0])
+                                o.residual[0] if o.residual else -1, o.residual[1] if o.residual else 0,
+                                o.publish_ci + 1 if o.publish is not None else 0])
         return np.asarray(ops, dtype=np.int32)
 
     # ---- backward ops -------------------------------------------------------------------------
@@ -271,9 +331,9 @@ class Program:
         return [g for g in range(ly.aux.groups) if any(f.need_grad for f in ly.aux.feats[64 * g:64 * g + 64])]
 
     def _build_bwd_ops(self) -> np.ndarray:
-        """Reverse walk.  Records, next to the ops, the weight blocks each op streams (self.bwd_plan)."""
+        """Reverse walk, chain by chain (last chain first).  Records, next to the ops, the weight blocks each op
+        streams (self.bwd_plan)."""
         ops, plan = [], []
-        items = self.layers
 
         def emit_load(ly: Layer, to2: bool):
             gi = ly.grad_in
@@ -283,7 +343,10 @@ class Program:
                 ops.append([L.HN_BOP_LOAD_WIDE, gi.src, gi.col, ly.n_out, ly.nt, ly.mask_slot, 0, ly.dz_slot])
             else:
                 sy = gi.sigmoid_y
-                ops.append([L.HN_BOP_LOAD, gi.src, gi.col, ly.n_out | (256 if to2 else 0), 1 if sy else 0,
+                w3 = ly.n_out | (256 if to2 else 0)
+                if gi.from_dsrc is not None:
+                    w3 |= 512 | gi.dacc_q << 10
+                ops.append([L.HN_BOP_LOAD, gi.src, gi.col, w3, 1 if sy else 0,
                             sy[0] if sy else 0, sy[1] if sy else 0, ly.dz_slot])
             plan.append(("load",))
 
@@ -294,30 +357,33 @@ class Program:
                             0, 0, 0, 0])
                 plan.append(("aux", ly, g, from2))
 
-        final = items[-1]
-        emit_load(final, False)
-        emit_aux(final, False)
-        consumer = final
-        while consumer.prev is not None:
-            P = consumer.prev
-            heads = [h for h in items if (not h.commit) and h.prev is P and h is not consumer and h is not final]
-            if len(heads) > 1:
-                raise NotImplementedError("more than one side head on one activation")
-            head = heads[0] if heads else None
-            if head is not None:
-                emit_load(head, True)
-                emit_aux(head, True)
-            mask = P.mask_slot if P.act == "relu" else -1
-            ops.append([L.HN_BOP_LAYER, consumer.nt | (1 if head else 0) << 8 | P.nt << 16, 0, 0, mask, P.dz_slot,
-                        0, 0])
-            plan.append(("layer", consumer, head, P))
-            consumer = P
-            emit_aux(P, False)
-        # every head must have been visited
-        seen = {id(p[1]) for p in plan if p[0] == "layer"} | {id(p[2]) for p in plan if p[0] == "layer" and p[2]}
-        for ly in items:
-            if not ly.commit and ly is not final and id(ly) not in seen:
-                raise NotImplementedError(f"{ly.name}: head without a later consumer of its input")
+        for items in reversed(self.chains()):
+            final = items[-1]
+            if final.out is None:
+                raise ValueError(f"{final.name}: the last layer of a chain must produce an output")
+            emit_load(final, False)
+            emit_aux(final, False)
+            consumer = final
+            while consumer.prev is not None:
+                P = consumer.prev
+                heads = [h for h in items if (not h.commit) and h.prev is P and h is not consumer and h is not final]
+                if len(heads) > 1:
+                    raise NotImplementedError("more than one side head on one activation")
+                head = heads[0] if heads else None
+                if head is not None:
+                    emit_load(head, True)
+                    emit_aux(head, True)
+                mask = P.mask_slot if P.act == "relu" else -1
+                ops.append([L.HN_BOP_LAYER, consumer.nt | (1 if head else 0) << 8 | P.nt << 16, 0, 0, mask, P.dz_slot,
+                            0, 0])
+                plan.append(("layer", consumer, head, P))
+                consumer = P
+                emit_aux(P, False)
+            # every head must have been visited
+            seen = {id(p[1]) for p in plan if p[0] == "layer"} | {id(p[2]) for p in plan if p[0] == "layer" and p[2]}
+            for ly in items:
+                if not ly.commit and ly is not final and id(ly) not in seen:
+                    raise NotImplementedError(f"{ly.name}: head without a later consumer of its input")
         self.bwd_plan = plan
         return np.asarray(ops, dtype=np.int32)
 
@@ -433,7 +499,8 @@ class Program:
         for i, f in enumerate(self.feat_table):
             slot = self.dsrc_map.get((f.src, f.comp), -1) + 1 if f.need_grad else 0
             if f.kind != L.HN_FEAT_ZERO and (f.src, f.comp) not in self.comp_map:
-                feat[i] = (f.src << 8 | L.HN_FEAT_ID_DIRECT << 12 | slot << 16 | f.comp << 24, np.float32(f.freq))
+                word = f.src << 8 | L.HN_FEAT_ID_DIRECT << 12 | slot << 16 | f.comp << 24       # comp >= 128 sets bit 31
+                feat[i] = (int(np.uint32(word).view(np.int32)), np.float32(f.freq))
                 continue
             ci = self.comp_map.get((f.src, f.comp), 0)
             feat[i] = (ci | f.kind << 12 | slot << 16, np.float32(f.freq))
@@ -586,6 +653,13 @@ def _count_optimizer_steps(optimizer, args, kwargs):
     _OPT_STEPS[0] += 1
 
 
+def note_parameters_changed():
+    """Invalidate every packed weight stream.  For updates no Python-visible counter sees: a HIP-graph replay that
+    contains the optimizer launch changes the parameters without running ArenaAdam.step's body, so whoever replays
+    such a graph (graphs.GraphedStep, training.TrainStep) calls this afterwards."""
+    _OPT_STEPS[0] += 1
+
+
 try:    # any torch optimizer step invalidates packed weights (inference after training; training repacks anyway)
     from torch.optim.optimizer import register_optimizer_step_post_hook
     register_optimizer_step_post_hook(_count_optimizer_steps)
@@ -658,7 +732,7 @@ class MlpRunner:
         return d
 
     def _args(self, d, mode, n_points, samples_per_ray, training, ops, n_ops, wstream_ptr, n_chunks, srcs, dsts,
-              stash, masks, dsrc):
+              stash, masks, dsrc, embed=None):
         a = L.HnMlpArgs()
         a.mode, a.n_points, a.samples_per_ray, a.training = mode, n_points, samples_per_ray, int(training)
         a.n_ops, a.n_chunks, a.n_dsrc = n_ops, n_chunks, self.prog.n_dsrc if dsrc is not None else 0
@@ -673,11 +747,24 @@ class MlpRunner:
         for i, s in enumerate(srcs):
             if s is None:
                 continue
-            t, per_ray = s
+            t, per_ray = s[0], s[1]
             L.require_gpu(t)
             if t.dtype != torch.float32 or t.stride(-1) != 1:
                 raise L.HnError("sources must be fp32 with unit inner stride")
             a.src[i].ptr, a.src[i].ld, a.src[i].per_ray = t.data_ptr(), t.stride(-2) if t.dim() > 1 else 1, int(per_ray)
+            if len(s) > 2 and s[2] is not None:       # gathered per-ray source: row = idx[ray] of a (rows, dim) table
+                idx = s[2]
+                L.require_gpu(idx)
+                if idx.dtype != torch.int64 or not idx.is_contiguous():
+                    raise L.HnError("gather indices must be contiguous int64")
+                a.src[i].gather_idx, a.src[i].gather_rows = idx.data_ptr(), t.shape[0]
+        if embed is not None:       # (gradient table, indices, source index): GLOEmbed's backward inside the machine
+            g_tab, idx, src_i = embed
+            mask, col = self.prog.embed_fold(src_i)
+            a.embed_reg_mask, a.embed_grad, a.embed_idx = mask, g_tab.data_ptr(), idx.data_ptr()
+            a.embed_rows, a.embed_dim = g_tab.shape[0], g_tab.shape[1]
+            for k in range(L.HN_DSRC_COMPS):
+                a.embed_col[k] = col[k]
         for i, t in enumerate(dsts):
             if t is None:
                 continue
@@ -702,21 +789,27 @@ class MlpRunner:
         L.launch("hn_mlp_forward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         return stash, masks
 
-    def backward(self, mode, n_points, samples_per_ray, srcs, stash, masks, grad_target=None, defer=False):
+    def backward(self, mode, n_points, samples_per_ray, srcs, stash, masks, grad_target=None, defer=False,
+                 embed=None, want_dsrc=True):
         """Launch backward-data then the weight-gradient kernel.
         grad_target = (flat fp32 buffer, per-parameter offsets): accumulate the weight gradients there (a
         ParamArena's gradient buffer) instead of into a fresh zero-filled buffer.  With `defer` (and a grad_target)
         the weight-gradient kernel is NOT launched: a PendingWgrad is returned in place of the gradient buffer,
         for `launch_pending_wgrads`.
+        embed = (gradient table (rows, dim), int64 ray indices, source index): reduce the source gradient of that
+        gathered per-ray source inside the kernel and scatter-add it into the table gradient (needs
+        samples_per_ray % 32 == 0).  want_dsrc=False skips the per-point source-gradient tensor altogether.
         Returns (dsrc [P, n_dsrc] or None, flat fp32 gradient buffer or None when grad_target was given)."""
         device = stash.device
         BACKWARD_SERIAL[0] += 1
         d = self._tables(device, mode)       # the streams its forward packed
         dsrc = None
-        if self.prog.n_dsrc > 0:
+        if self.prog.n_dsrc > 0 and want_dsrc:
             dsrc = torch.empty(n_points, self.prog.n_dsrc, dtype=torch.float32, device=device)
+        if embed is not None and samples_per_ray % 32 != 0:
+            raise L.HnError("the in-kernel embedding gradient needs samples_per_ray % 32 == 0")
         a = self._args(d, mode, n_points, samples_per_ray, True, d.bwd_ops, len(self.prog.bwd_ops),
-                       d.wstream.data_ptr() + d.n_fwd_units * 1024, d.bwd_chunks, srcs, [], stash, masks, dsrc)
+                       d.wstream.data_ptr() + d.n_fwd_units * 1024, d.bwd_chunks, srcs, [], stash, masks, dsrc, embed)
         L.launch("hn_mlp_backward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         goffs = tuple(grad_target[1]) if grad_target is not None else None
         deferred = defer and grad_target is not None

@@ -1,82 +1,147 @@
 """The training step of the reference's Lightning system as one replayable GPU program
-(reference: train.py:96-114 `forward`, 146-163 `training_step`; optimizer from utils.get_optimizer).
+(reference: train.py:96-114 `forward` with its chunk loop, 146-163 `training_step`, 116-131 `configure_optimizers`;
+optimizer / scheduler from utils.get_optimizer / get_scheduler, utils/__init__.py:23-59).
 
-`TrainStep(model, lr=...)` owns what NeRFSystem owns around the model — loss, optimizer — laid out the MI355X way:
-parameters and gradients in a `ParamArena`, `ArenaAdam` (one kernel for all parameters), the whole step (prepare_ray_dict -> model ->
-MSE -> backward -> fused HIP Adam) captured once into a HIP graph and replayed on fixed input buffers; with
-torch.distributed initialised, rays are expected pre-sharded per rank and the gradient buffer is all-reduced in
-place between the captured forward+backward and the optimizer step.  `step(rays, rgbs)` returns the same log the
-reference's training_step records: {'train/loss', 'train/psnr', 'lr'} (device scalars, no host sync).
+`TrainStep(model, lr=...)` owns what NeRFSystem owns around the model — loss, optimizer, LR schedule — laid out the
+MI355X way: parameters and gradients in a `ParamArena`, `ArenaAdam` (one kernel for all parameters, hyper-parameters
+and step counter on the device), the whole step (prepare_ray_dict -> model per chunk -> MSE -> backward -> Adam)
+captured once into a HIP graph and replayed on fixed input buffers.  With torch.distributed initialised the initial
+parameters are broadcast from rank 0 (what Lightning's DDP wrapper does), rays are expected pre-sharded per rank,
+the gradient buffer is SUM-all-reduced in place between the captured forward+backward and the optimizer step, and the
+1/world of the mean is folded into the Adam kernel (no separate division launch).
+`step(rays, rgbs)` returns the log the reference's training_step records: {'train/loss', 'train/psnr', 'lr'}
+(device scalars, no host sync).
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
+from . import machine
 from .arena import ParamArena
-from .optim import ArenaAdam
 from .graphs import GraphedStep
 from .hypernerf import model_utils
 from .losses import MSELoss, psnr
+from .optim import ArenaAdam, MultiStepLR
 
 _EXTRA = {'nerf_alpha': None, 'warp_alpha': None, 'hyper_alpha': None, 'hyper_sheet_alpha': None}
 
 
 class TrainStep:
     def __init__(self, model: torch.nn.Module, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, use_graph: bool = True, group=None):
+                 weight_decay: float = 0.0, use_graph: bool = True, group=None, chunk: int = 32 * 1024,
+                 decay_step: Optional[Sequence[int]] = None, decay_gamma: float = 0.1):
         self.model = model
         self.arena = ParamArena(model.parameters())
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.group = group
         self.use_graph = use_graph
+        self.chunk = int(chunk)          # rays per model call (train.py:108-111); the default exceeds any batch size
+        if self.world > 1:
+            # replicas must start identical (Lightning DDP broadcasts module state from rank 0 at wrap time)
+            dist.broadcast(self.arena.data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            self.arena.bump()
         # hn_adam_step: one launch for all parameters, clears the gradient buffer on the way out, graph-capturable
-        # (on one GPU it is part of the captured step; with N>1 it follows the gradient all-reduce)
-        self.optimizer = ArenaAdam(self.arena, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, zero_grad=True)
+        # (on one GPU it is part of the captured step; with N>1 it follows the gradient all-reduce and scales the
+        # summed gradient by 1/world itself)
+        self.optimizer = ArenaAdam(self.arena, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, zero_grad=True,
+                                   grad_scale=1.0 / self.world)
+        # 'steplr' of the reference (utils/__init__.py:43-46): stepped once per epoch by the caller (`epoch_end`)
+        self.scheduler = MultiStepLR(self.optimizer, decay_step, decay_gamma) if decay_step else None
         self.loss_fn = MSELoss()
         self._graph: Optional[GraphedStep] = None
         self._rays = self._rgbs = None
+        self._rng: Optional[Dict[str, torch.Tensor]] = None    # fixed buffers of injected random draws (tests)
         self._log: Dict[str, torch.Tensor] = {}
 
     # ---- the step body (what gets captured) ---------------------------------------------------
     def _forward_backward(self):
-        results = self.model(model_utils.prepare_ray_dict(self._rays), dict(_EXTRA))
-        loss = self.loss_fn(results, self._rgbs)
-        typ = 'fine' if 'fine' in results else 'coarse'
-        loss.backward()          # into arena.grad, left zeroed by the previous optimizer step
+        b = self._rays.shape[0]
+        loss_sum, psnr_in = None, []
+        # the reference renders `chunk` rays at a time and concatenates the results before the loss
+        # (train.py:108-114); mean((rgb-gt)^2) over the batch = sum over chunks of (rays in chunk / B) x chunk mean,
+        # so every chunk is back-propagated on its own (its activations are freed before the next chunk runs)
+        for i in range(0, b, self.chunk):
+            rays, rgbs = self._rays[i:i + self.chunk], self._rgbs[i:i + self.chunk]
+            kw = {} if self._rng is None else {'rng': {k: v[i:i + self.chunk] for k, v in self._rng.items()}}
+            results = self.model(model_utils.prepare_ray_dict(rays), dict(_EXTRA), **kw)
+            w = rays.shape[0] / b
+            loss = self.loss_fn(results, rgbs)
+            (loss if w == 1.0 else loss * w).backward()          # into arena.grad (zeroed by the previous Adam launch)
+            typ = 'fine' if 'fine' in results else 'coarse'
+            with torch.no_grad():
+                loss_sum = loss.detach() * w if loss_sum is None else loss_sum + loss.detach() * w
+                psnr_in.append(results[typ]['rgb'].detach())
         with torch.no_grad():
-            self._log = {'train/loss': loss.detach(), 'train/psnr': psnr(results[typ]['rgb'].detach(), self._rgbs)}
+            pred = psnr_in[0] if len(psnr_in) == 1 else torch.cat(psnr_in, 0)
+            self._log = {'train/loss': loss_sum, 'train/psnr': psnr(pred, self._rgbs)}
 
     def _whole(self):
         self._forward_backward()
         self.optimizer.step()
 
+    def _snapshot(self):
+        o = self.optimizer
+        return [t.clone() for t in (self.arena.data, self.arena.grad, o.exp_avg, o.exp_avg_sq, o.step_count)]
+
+    def _restore(self, snap):
+        o = self.optimizer
+        with torch.no_grad():
+            for dst, src in zip((self.arena.data, self.arena.grad, o.exp_avg, o.exp_avg_sq, o.step_count), snap):
+                dst.copy_(src)
+        self.arena.bump()
+
+    def _capture(self, fn):
+        """Warm-up runs + capture execute `fn` for real; parameters, gradient buffer and optimizer state are put back
+        afterwards so that the first step() applies exactly ONE update (and, with N>1, all-reduces ONE gradient)."""
+        snap = self._snapshot()
+        g = GraphedStep(fn, warmup=2)
+        self._restore(snap)
+        return g
+
     # ---- public -----------------------------------------------------------------------------------
-    def step(self, rays: torch.Tensor, rgbs: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """rays (B, 8|9), rgbs (B, 3) on the GPU; B must stay the same from call to call when graphs are on."""
-        if self._rays is None or self._rays.shape != rays.shape:
+    def step(self, rays: torch.Tensor, rgbs: torch.Tensor, rng: Optional[Dict[str, torch.Tensor]] = None
+             ) -> Dict[str, torch.Tensor]:
+        """rays (B, 8|9), rgbs (B, 3) on the GPU; B must stay the same from call to call when graphs are on.
+        `rng` optionally supplies the random draws of NerfModel.forward ('t_rand', 'u', 'noise_coarse', 'noise_fine',
+        one row per ray) instead of torch's generator: parity runs against the CPU oracle share the draws this way."""
+        if self._rays is None or self._rays.shape != rays.shape or (rng is None) != (self._rng is None):
             self._rays, self._rgbs = rays.clone(), rgbs.clone()
+            self._rng = None if rng is None else {k: v.clone() for k, v in rng.items()}
             self._graph = None
         else:
             self._rays.copy_(rays)
             self._rgbs.copy_(rgbs)
+            if rng is not None:
+                for k, v in rng.items():
+                    self._rng[k].copy_(v)
+        self.optimizer.sync_hyper()      # a replayed Adam launch reads lr & co. from device memory
         if not self.use_graph:
             self._forward_backward()
             if self.world > 1:
-                self.arena.all_reduce_mean(self.group)
+                self.arena.all_reduce_sum(self.group)
             self.optimizer.step()
         elif self.world == 1:
-            if self._graph is None:     # first call: 2 eager warm-up steps (real steps), the capture, then the replay
-                self._graph = GraphedStep(self._whole, warmup=2)
+            if self._graph is None:
+                self._graph = self._capture(self._whole)
             self._graph()
         else:
             if self._graph is None:
-                self._graph = GraphedStep(self._forward_backward, warmup=2)
+                self._graph = self._capture(self._forward_backward)
             self._graph()
-            self.arena.all_reduce_mean(self.group)
+            self.arena.all_reduce_sum(self.group)
             self.optimizer.step()
+        # a replay updates the parameters without running any Python: tell the weight packers (an eval forward
+        # after this must repack — see machine.MlpRunner.pack)
+        self.arena.bump()
+        machine.note_parameters_changed()
         log = {k: v.clone() for k, v in self._log.items()}     # graph outputs are overwritten by the next replay
         log['lr'] = self.optimizer.param_groups[0]['lr']
         return log
+
+    def epoch_end(self):
+        """Advance the LR schedule by one epoch (Lightning steps the scheduler of configure_optimizers per epoch)."""
+        if self.scheduler is not None:
+            self.scheduler.step()

@@ -37,12 +37,12 @@ typedef void* hnStream_t; /* hipStream_t */
 
 #define HN_MAX_SRC 8 /* forward: feature sources 0-3 ; backward: 0-3 same, 4-7 gradient inputs */
 #define HN_MAX_DST 4
-#define HN_MAX_SLOTS 64
+#define HN_MAX_SLOTS 128
 #define HN_OP_WORDS 8
 #ifndef HN_CHUNK_UNITS
 #define HN_CHUNK_UNITS 32 /* weight stream is consumed in chunks of 32 units of 1 KiB */
 #endif
-#define HN_DSRC_COMPS 16  /* per-point source-gradient accumulators in the backward machine */
+#define HN_DSRC_COMPS 32  /* per-point source-gradient accumulators in the backward machine */
 
 /* ---- forward ops: word0 = opcode ---------------------------------------------------------
  * Machine state per wavefront (32 points): `cur` = current hidden activation (<= 256 features) as
@@ -61,7 +61,9 @@ typedef void* hnStream_t; /* hipStream_t */
 #define HN_LAYER_NO_COMMIT 1 /* flags bit0: leave cur untouched (head layers read by an OUT op)      */
 #define HN_LAYER_DIRECT 2    /* flags bit1: the layer's feature groups hold HN_FEAT_ID_DIRECT entries       */
 /* dst[w1][p*ld + w2 + i] = act(accL row i) (+ residual src[w5][.. + w6 + i]), i < w3 <= 4           */
-#define HN_OP_OUT 4      /* w1=dst  w2=col  w3=n  w4=act(0 none,1 sigmoid)  w5=res_src|-1  w6=res_col */
+#define HN_OP_OUT 4      /* w1=dst  w2=col  w3=n  w4=act(0 none,1 sigmoid)  w5=res_src|-1  w6=res_col
+                            w7 = 1 + first staged component the n results are ALSO published to (0 = none): later
+                            layers of the same program encode them as generated features (warp -> template) */
 #define HN_OP_OUT_WIDE 5 /* w1=dst  w2=col  w3=n (<= 32*NT)  w4=NT   (cur features -> dst)            */
 
 /* ---- backward ops ---------------------------------------------------------------------------
@@ -70,7 +72,10 @@ typedef void* hnStream_t; /* hipStream_t */
  *     acc = W[:, 32t..]^T . cur (32*K32 dZ features) + W2[:, 32t..]^T . cur2 (if K32b) ;
  *     nxt[t] = acc * relu'(mask) ; then cur <- nxt.  Stream order per tile: K32 blocks, K32b blocks. */
 #define HN_BOP_LOAD 1      /* w1=src w2=col w3=n(<=4) w4=act'(1 sigmoid: y from src w5 col w6)
-                              w7=stash|-1 ; w3 bit 8 set: destination cur2 instead of cur          */
+                              w7=stash|-1 ; w3 bit 8 set: destination cur2 instead of cur ;
+                              w3 bit 9 set: ADD the source-gradient accumulators of slots 8*((w3>>10)&3) + i — the
+                              gradient that later ops of this program (earlier in forward order) left for the
+                              components this head published (a NULL src then contributes nothing)         */
 #define HN_BOP_LOAD_WIDE 2 /* w1=src  w2=col  w3=n  w4=NT  w5=relu mask slot|-1  w7=stash_slot|-1      */
 #define HN_BOP_LAYER 3     /* w1 = K32 | K32b<<8 | NT<<16 ; w4=mask_slot|-1 w5=stash|-1            */
 /* gradient w.r.t. GENERATED input features: per 32-feature tile of nG*64 features,
@@ -95,9 +100,15 @@ typedef struct {
 #define HN_FEAT_SINP 4 /* sin(freq*x + 0.5*3.1415926): the reference's cosine in model_utils.posenc:262 */
 
 typedef struct {
-  const float* ptr;
+  const float* ptr; /* NULL: the source is absent — its staged components are left to the program itself (HN_OP_OUT
+                       publishes head outputs as components, fused level programs) / its gradient input is zero */
   int32_t ld;      /* row stride in floats */
   int32_t per_ray; /* 1: row index = point / samples_per_ray, 0: row index = point */
+  const int64_t* gather_idx; /* optional (per_ray sources): row index = gather_idx[ray] — the GLO embedding lookup
+                                (modules.GLOEmbed, hypernerf/modules.py:155-167) read straight from the table;
+                                an index outside [0, gather_rows) stages NaN */
+  int32_t gather_rows;
+  int32_t pad;
 } HnSrc;
 
 typedef struct {
@@ -142,7 +153,14 @@ typedef struct {
   uint64_t* prof;        /* diagnostic only (NULL in production): 8 shader-clock sums, see tools/ */
   const int32_t* comps;  /* device, n_comps entries: src << 16 | column */
   int32_t n_comps;
-  int32_t pad1;
+  int32_t embed_reg_mask; /* backward, 0 = off: bit i set = accumulator register i holds (in one lane half or both)
+                             a source-gradient slot of the gathered per-ray source; those are summed over the 32
+                             points of the block (all of ONE ray: samples_per_ray % 32 == 0 is required) and added to
+                             embed_grad[gather_idx[ray]][embed_col[slot]] — GLOEmbed's backward, scatter included */
+  float* embed_grad;      /* (gather_rows, embed_dim) fp32, accumulated with float atomics */
+  const int64_t* embed_idx;
+  int32_t embed_rows, embed_dim;
+  int8_t embed_col[HN_DSRC_COMPS]; /* slot -> column of the table row, -1 = not an embedding component */
 } HnMlpArgs;
 
 /* weight packing: one descriptor per 1-KiB unit of a stream */

@@ -166,7 +166,10 @@ def _source_value(e, srcs, p, ray):
         arr, per_ray = srcs[(e["packed"] >> 8) & 15]
         return arr[ray if per_ray else p, (int(e["packed"]) >> 24) & 255]
     c = int(COMPS[e["packed"] & 255])
-    arr, per_ray = srcs[c >> 16]
+    src = srcs[c >> 16]
+    arr, per_ray = src[0], src[1]
+    if len(src) > 2 and src[2] is not None:          # gathered per-ray source: row = idx[ray]
+        return arr[int(src[2][ray]), c & 0xffff]
     return arr[ray if per_ray else p, c & 0xffff]
 
 
@@ -249,6 +252,16 @@ def run_forward(prog, mode, tables, params, srcs, n_points, spr, dst_widths, tra
     bias = pack_bias(tables["bias"], params, prog.bias_len)
     feat = tables["feat"]
     outs = [np.zeros((n_points, w)) for w in dst_widths]
+    # a source without data is published by the program itself (HN_OP_OUT w7): the published components live in the
+    # block's staged-component store on the device; here they alias the output tensor they are also written to
+    srcs = list(srcs)
+    for i, s_ in enumerate(srcs):
+        if s_ is None and any(ly.out is not None and ly.out.publish is not None and ly.out.publish[0] == i
+                              for ly in prog.layers):
+            pub = [ly.out for ly in prog.layers if ly.out is not None and ly.out.publish is not None
+                   and ly.out.publish[0] == i]
+            assert all(o.col == o.publish[1] for o in pub), "emulator: published columns must equal output columns"
+            srcs[i] = (outs[pub[0].dst], False)
     stash = Stash(mode, prog, n_points)
     nblk = (n_points + 31) // 32
     for blk in range(nblk):
@@ -304,9 +317,13 @@ def run_forward(prog, mode, tables, params, srcs, n_points, spr, dst_widths, tra
                         if w[4] == 1:
                             y = 1.0 / (1.0 + np.exp(-y))
                         if w[5] >= 0:
-                            arr, per_ray = srcs[w[5]]
+                            arr, per_ray = srcs[w[5]][0], srcs[w[5]][1]
                             y = y + arr[ray[l] if per_ray else p[l], w[6] + i]
                         outs[w[1]][p[l], w[2] + i] = y
+                if w[7] > 0:                 # published components: same values, staged per block on the device
+                    for i in range(w[3]):
+                        c = int(COMPS[w[7] - 1 + i])
+                        assert srcs[c >> 16][0] is outs[w[1]] and (c & 0xffff) == w[2] + i
             elif code == 5:
                 n, nt = w[3], w[4]
                 for l in range(64):
@@ -349,12 +366,16 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
             if code == 1:
                 n, to2 = w[3] & 255, (w[3] >> 8) & 1
                 tmp = mode.zero_frags(mode.steps32)
-                arr, _ = srcs[w[1]]
+                arr = srcs[w[1]][0] if (w[1] >= 0 and srcs[w[1]] is not None) else None
+                from_dacc, q = (w[3] >> 9) & 1, (w[3] >> 10) & 3
                 for l in range(32):
                     if not valid[l]:
                         continue
                     for i in range(n):
-                        g = arr[p[l], w[2] + i]
+                        g = arr[p[l], w[2] + i] if arr is not None else 0.0
+                        if from_dacc:            # rows 8q + i sit in registers 4q + i of the h == 0 lanes
+                            assert rho(4 * q + i, 0) == 8 * q + i
+                            g = g + dacc[l, 4 * q + i]
                         if w[4] == 1:
                             y = srcs[w[5]][0][p[l], w[6] + i]
                             g = g * y * (1.0 - y)

@@ -463,13 +463,16 @@ def test_se3_field_warp_vs_oracle():
 
 
 @pytest.mark.gpu
-def test_config5_se3_warp_axis_aligned_model_vs_oracle():
+@pytest.mark.parametrize("cond", [False, True])
+def test_config5_se3_warp_axis_aligned_model_vs_oracle(cond):
     """Config 5 end to end: NerfModel with `warp_field = SE3Field(3)` and hyper_slice_method='axis_aligned_plane'
-    against the oracle (fp32, same draws): outputs <= 1e-4, gradients <= 1e-2 of each tensor's largest entry."""
+    against the oracle (fp32, same draws): outputs <= 1e-4, gradients <= 1e-2 of each tensor's largest entry.
+    With the template GLO condition on, the template differentiates into 3 + 8 + 8 = 19 source components
+    (more than one half of the source-gradient accumulator tile)."""
     HN.set_precision("fp32")
     try:
-        kw = dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_nerf_embed=False,
-                  use_alpha_cond=False)
+        kw = dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_nerf_embed=cond,
+                  use_alpha_cond=cond)
         nc = nf = 16
         b, seed = 40, 53
         m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, view_fourier_dim=6, **kw)

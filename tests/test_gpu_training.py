@@ -1,0 +1,252 @@
+"""GPU tests (MI355X) of the training harness around the hot path (e): the fused Adam follows
+a learning-rate schedule through HIP-graph replays, the first graphed step applies exactly one update, inference after
+graph replays sees the updated weights, an out-of-range GLO index fails loudly, the HIP training loop tracks the CPU
+oracle trained with torch.optim.Adam on the same batches and draws, and 2 data-parallel ranks (gloo, both on this one
+GPU) reproduce the single-rank gradient and stay bit-identical to each other."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import hashprng as H
+import hypernerf_torch_amd as HN
+from gpu_common import DEV, EMB, assert_close, load_hash, rays_for
+from hypernerf_torch_amd import functional as F
+from hypernerf_torch_amd.hypernerf import models
+from hypernerf_torch_amd.training import TrainStep
+from oracle import hypernerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True, view_fourier_dim=6)
+
+
+def ray_rows(seed, b):
+    o, d, idx = rays_for(seed, b)
+    rays = torch.cat([o, d, torch.zeros(b, 1), torch.ones(b, 1), idx.float()[:, None]], dim=1)
+    return o, d, idx, rays
+
+
+def small_model(seed, nc=16, nf=16, noise_std=None, precision="fp32"):
+    HN.set_precision(precision)
+    m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=noise_std, **KW)
+    sd = load_hash(m, seed)
+    return m.to(DEV), sd
+
+
+@pytest.fixture(autouse=True)
+def restore_precision():
+    old = HN.get_precision()
+    yield
+    HN.set_precision(old)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_lr_schedule_reaches_the_captured_adam_launch(use_graph):
+    """lr lived in the kernel arguments and was frozen into the graph.  Now it is read from device memory:
+    with lr = 0 a step must leave every parameter untouched, with lr restored it must move them again; MultiStepLR
+    (utils/__init__.py:43-46) drives it through TrainStep.epoch_end()."""
+    m, _ = small_model(31)
+    _, _, _, rays = ray_rows(31, 64)
+    rgbs = H.uniform(31, "rgbs", (64, 3), 0.1, 0.9).to(DEV)
+    ts = TrainStep(m, lr=1e-3, use_graph=use_graph, decay_step=[1, 2], decay_gamma=0.5)
+    ts.step(rays.to(DEV), rgbs)
+    ts.step(rays.to(DEV), rgbs)
+    p0 = ts.arena.data.clone()
+    ts.optimizer.param_groups[0]["lr"] = 0.0
+    log = ts.step(rays.to(DEV), rgbs)
+    assert log["lr"] == 0.0
+    assert torch.equal(ts.arena.data, p0), "lr = 0 must freeze the parameters (also through a graph replay)"
+    ts.optimizer.param_groups[0]["lr"] = 1e-3
+    ts.step(rays.to(DEV), rgbs)
+    moved = (ts.arena.data - p0).abs().max().item()
+    assert 0.0 < moved <= 1e-3 * 1.05 * 10, moved          # Adam's per-step move is bounded by ~lr (bias-corrected)
+    ts.epoch_end()
+    assert abs(ts.step(rays.to(DEV), rgbs)["lr"] - 5e-4) < 1e-12
+    ts.epoch_end()
+    assert abs(ts.step(rays.to(DEV), rgbs)["lr"] - 2.5e-4) < 1e-12
+    assert float(ts.optimizer.hyper[0]) == pytest.approx(2.5e-4)
+
+
+def test_first_graphed_step_applies_exactly_one_update():
+    """the capture warm-ups used to be real steps (3 updates on the first batch).  Adam's first update
+    moves every parameter by at most lr; after the first step() the device step counter reads 1 and the result
+    equals an eager first step."""
+    _, _, _, rays = ray_rows(32, 64)
+    rgbs = H.uniform(32, "rgbs", (64, 3), 0.1, 0.9).to(DEV)
+    res = {}
+    for use_graph in (False, True):
+        m, sd = small_model(32)
+        m.use_stratified_sampling = False           # no random draws: eager and graph see the same samples
+        ts = TrainStep(m, lr=1e-3, use_graph=use_graph)
+        before = ts.arena.data.clone()
+        ts.step(rays.to(DEV), rgbs)
+        assert float(ts.optimizer.step_count) == 1.0
+        delta = ts.arena.data - before
+        assert float(delta.abs().max()) <= 1e-3 * 1.001
+        res[use_graph] = delta
+    # same update up to the summation order of the weight-gradient atomics (a sign flip needs |g| ~ 1e-7 |g|_typ)
+    diff = (res[True] - res[False]).abs()
+    assert float((diff > 1e-5).float().mean()) < 1e-3, float((diff > 1e-5).float().mean())
+
+
+def test_inference_after_graph_replays_uses_the_updated_weights():
+    """a replay steps the parameters without running Python; the packed weight streams of a following
+    no_grad forward must be rebuilt — every time, not only after the first replay."""
+    m, _ = small_model(33)
+    m.use_stratified_sampling = False
+    o, d, idx, rays = ray_rows(33, 64)
+    rgbs = H.uniform(33, "rgbs", (64, 3), 0.1, 0.9).to(DEV)
+    rd = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+          "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+    ts = TrainStep(m, lr=5e-3, use_graph=True)
+    prev = None
+    for rnd in range(3):
+        ts.step(rays.to(DEV), rgbs)
+        with torch.no_grad():
+            got = m(rd, {})["fine"]["rgb"].clone()
+        fresh = models.NerfModel(EMB, n_samples_coarse=16, n_samples_fine=16, noise_std=None, **KW).to(DEV)
+        fresh.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+        fresh.use_stratified_sampling = False
+        with torch.no_grad():
+            ref = fresh(rd, {})["fine"]["rgb"]
+        assert_close(got, ref, 1e-6, f"eval after replay {rnd}")
+        if prev is not None:
+            assert float((got - prev).abs().max()) > 1e-5, "training did not move the render"
+        prev = got
+
+
+def test_out_of_range_glo_index_poisons_the_output():
+    """nn.Embedding raises a device assert on an out-of-range index (modules.py:155-167); the HIP gather must not
+    silently train another row: the affected rows come out NaN, the gradient of the table stays finite."""
+    tab = torch.nn.Parameter(H.uniform(9, "tab", (10, 8), -1, 1).to(DEV))
+    idx = torch.tensor([0, 3, 10, -1, 9], device=DEV)
+    out = F.embed_lookup(tab, idx)
+    assert torch.isnan(out[2]).all() and torch.isnan(out[3]).all()
+    assert torch.equal(out[[0, 1, 4]], tab.detach()[[0, 3, 9]])
+    out[[0, 1, 4]].sum().backward()
+    assert torch.isfinite(tab.grad).all() and float(tab.grad[[0, 3, 9]].min()) == 1.0
+
+
+def test_training_tracks_the_cpu_oracle():
+    """SURVEY.md §8 f1's pin: the HIP path (fp32 mode, TrainStep: chunk loop + fused Adam + graph replay) and the CPU
+    oracle (autograd + torch.optim.Adam, the reference's optimizer) train 25 steps from the same weights on the same
+    batches with the same random draws; loss curves agree to 2e-3 relative, PSNR to 0.02 dB — the measurable form of
+    the north star's 'PSNR within 0.1 dB of the reference'."""
+    nc = nf = 16
+    b, steps, seed = 96, 25, 41
+    m, sd = small_model(seed, nc, nf, noise_std=0.5)
+    cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, **KW)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    topt = torch.optim.Adam(list(p.values()), lr=5e-4, eps=1e-8)          # utils/__init__.py:29-31
+    ts = TrainStep(m, lr=5e-4, use_graph=True, chunk=40)                   # 96 rays in chunks of 40, 40, 16
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    cpu_loss, hip_loss, cpu_psnr, hip_psnr = [], [], [], []
+    for it in range(steps):
+        o, d, idx, rays = ray_rows(seed + it % 3, b)                       # three batches, cycled
+        gt = 0.5 + 0.5 * torch.sin(3.0 * o + 2.0 * d)                      # a smooth "scene"
+        rng = {"t_rand": H.uniform(seed + it, "t", (b, nc), 0, 1), "u": H.uniform(seed + it, "u", (b, nf), 0, 1),
+               "noise_coarse": H.normal(seed + it, "n1", (b, nc, 1)) * 0.5,
+               "noise_fine": H.normal(seed + it, "n2", (b, nc + nf, 1)) * 0.5}
+        topt.zero_grad()
+        ref = O.nerf_model_forward(p, cfg, o, d, idx, rng)
+        loss = O.mse_loss(ref, gt)
+        loss.backward()
+        topt.step()
+        cpu_loss.append(float(loss))
+        cpu_psnr.append(float(-10 * torch.log10(((ref["fine"]["rgb"].detach() - gt) ** 2).mean())))
+        log = ts.step(rays.to(DEV), gt.to(DEV), rng={k: v.to(DEV) for k, v in rng.items()})
+        hip_loss.append(float(log["train/loss"]))
+        hip_psnr.append(float(log["train/psnr"]))
+    cl, hl = np.array(cpu_loss), np.array(hip_loss)
+    rel = np.abs(hl - cl) / cl
+    print("loss rel err per step:", np.array2string(rel, precision=2))
+    assert rel.max() <= 2e-3, (rel.max(), cl, hl)
+    assert np.abs(np.array(hip_psnr) - np.array(cpu_psnr)).max() <= 0.02
+    assert cl[-3:].mean() < cl[:3].mean(), "the oracle run itself must learn"
+    from gpu_common import _record
+    _record("TrainStep vs CPU oracle + torch Adam: loss curve, 25 steps", "max rel", rel.max(), 2e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# two data-parallel ranks on ONE GPU (gloo): the N>1 code path of TrainStep end to end
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, use_graph, q):
+    for pth in (ROOT, os.path.join(ROOT, "tests")):
+        if pth not in sys.path:
+            sys.path.insert(0, pth)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hypernerf_torch_amd as HN2
+        from hypernerf_torch_amd.dist import shard_rays
+        from hypernerf_torch_amd.training import TrainStep as TS
+        HN2.set_precision("fp32")
+        m = models.NerfModel(EMB, n_samples_coarse=16, n_samples_fine=16, noise_std=None, **KW)
+        load_hash(m, 50 + rank)                  # DIFFERENT weights per rank: TrainStep must broadcast rank 0's
+        m = m.to(DEV)
+        m.use_stratified_sampling = False
+        _, _, _, rays = ray_rows(51, 64)
+        rgbs = H.uniform(51, "rgbs", (64, 3), 0.1, 0.9)
+        ts = TS(m, lr=1e-3, use_graph=use_graph)
+        mine_r, mine_c = shard_rays(rays).to(DEV), shard_rays(rgbs).to(DEV)
+        # gradient of the first step (before Adam consumes it): run the step body by hand
+        ts._rays, ts._rgbs = mine_r.clone(), mine_c.clone()
+        ts._forward_backward()
+        ts.arena.all_reduce_sum()
+        grad = (ts.arena.grad / world).cpu().clone()
+        ts.arena.zero_grad()
+        for _ in range(3):
+            ts.step(mine_r, mine_c)
+        q.put((rank, grad, ts.arena.data.cpu().clone(), float(ts.optimizer.step_count)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_step_two_ranks_match_one_rank(use_graph):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, use_graph, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    got = {}
+    for _ in range(2):
+        rank, grad, data, steps = q.get(timeout=600)
+        got[rank] = (grad, data, steps)
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    assert got[0][2] == got[1][2] == 3.0
+    assert torch.equal(got[0][0], got[1][0]), "the all-reduced gradient must be identical on both ranks"
+    assert torch.equal(got[0][1], got[1][1]), "replicas must stay bit-identical (broadcast at start + same updates)"
+    # one rank on the whole batch, rank 0's weights
+    HN.set_precision("fp32")
+    m = models.NerfModel(EMB, n_samples_coarse=16, n_samples_fine=16, noise_std=None, **KW)
+    load_hash(m, 50)
+    m = m.to(DEV)
+    m.use_stratified_sampling = False
+    _, _, _, rays = ray_rows(51, 64)
+    rgbs = H.uniform(51, "rgbs", (64, 3), 0.1, 0.9)
+    ts = TrainStep(m, lr=1e-3, use_graph=False)
+    ts._rays, ts._rgbs = rays.to(DEV), rgbs.to(DEV)
+    ts._forward_backward()
+    ref = ts.arena.grad.cpu()
+    err = float((got[0][0] - ref).norm() / ref.norm())
+    assert err <= 1e-5, f"mean of the two shard gradients vs the full-batch gradient: rel L2 {err:.2e}"

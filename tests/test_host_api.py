@@ -191,3 +191,59 @@ def test_load_ckpt_lightning_and_bare(tmp_path):
     load_ckpt(dst, bare, "nerf", prefixes_to_ignore=["warp_field"])
     assert torch.equal(dst.warp_field.mlp.linears[0].weight, src.warp_field.mlp.linears[0].weight)
     assert torch.equal(dst.hyper_sheet_mlp.mlp.linears[0].weight, src.hyper_sheet_mlp.mlp.linears[0].weight + 1.0)
+
+
+def test_save_ckpt_writes_the_reference_layout(tmp_path, golden_dir):
+    """utils.save_ckpt (SURVEY.md §8 f3 'export back'): {'state_dict': {'nerf.<name>': fp32 CPU tensor}} with exactly
+    the parameter names the reference's own model has (key list recorded from the reference in the g11 fixtures), so
+    that the reference's `load_ckpt(nerf, path, model_name='nerf')` (utils/__init__.py:83-88: strip 'nerf.', update,
+    load_state_dict) restores it; round trip through load_ckpt here, also from a model living in a ParamArena."""
+    from hypernerf_torch_amd.utils import load_ckpt, save_ckpt
+    g = np.load(os.path.join(golden_dir, "g11_model_bendy_cond_8_8.npz"))
+    kw = dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True, view_fourier_dim=6)
+    src = models.NerfModel(EMB, **kw)
+    arena = HN.ParamArena(src.parameters())
+    path = save_ckpt(src, os.path.join(tmp_path, "epoch=7.ckpt"), model_name="nerf", epoch=7, global_step=1234)
+    blob = torch.load(path, map_location="cpu")
+    assert blob["epoch"] == 7 and blob["global_step"] == 1234
+    assert sorted(blob["state_dict"]) == ["nerf." + k for k in g["keys"].tolist()]
+    for k, v in blob["state_dict"].items():
+        assert v.dtype == torch.float32 and v.device.type == "cpu"
+        assert v.untyped_storage().nbytes() == v.numel() * 4, "arena views must be exported as compact copies"
+    # what the reference's loader does with it (utils/__init__.py:66-88), restated inline
+    ref_side = {k[len("nerf") + 1:]: v for k, v in blob["state_dict"].items() if k.startswith("nerf")}
+    dst = models.NerfModel(EMB, **kw)
+    sd = dst.state_dict()
+    sd.update(ref_side)
+    dst.load_state_dict(sd)
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    dst2 = models.NerfModel(EMB, **kw)
+    load_ckpt(dst2, path, "nerf")
+    assert all(torch.equal(dst2.state_dict()[k], v) for k, v in src.state_dict().items())
+    assert arena.attached(src.warp_field.mlp.linears[0].weight) is not None
+
+
+def test_multistep_lr_matches_torch():
+    """optim.MultiStepLR (the reference's 'steplr', utils/__init__.py:43-46) against torch's scheduler, epoch by
+    epoch, including a resume through state_dict."""
+    from hypernerf_torch_amd.optim import MultiStepLR
+
+    class Dummy:                       # the only thing the scheduler touches
+        def __init__(self, lr):
+            self.param_groups = [{"lr": lr}]
+
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.Adam([p], lr=5e-4)
+    tsch = torch.optim.lr_scheduler.MultiStepLR(topt, milestones=[2, 5, 6], gamma=0.5)
+    mine = Dummy(5e-4)
+    sch = MultiStepLR(mine, [2, 5, 6], 0.5)
+    for epoch in range(9):
+        assert abs(mine.param_groups[0]["lr"] - topt.param_groups[0]["lr"]) < 1e-12, epoch
+        topt.step(); tsch.step(); sch.step()
+        if epoch == 3:
+            state = sch.state_dict()
+            mine = Dummy(123.0)
+            sch = MultiStepLR(mine, [1], 0.1)
+            sch.load_state_dict(state)
+    assert sch.get_last_lr() == [mine.param_groups[0]["lr"]]

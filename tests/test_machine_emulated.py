@@ -165,3 +165,81 @@ def test_wide_raw_input_direct_features_emulated(bf16):
     jobs = prog.wgrad_jobs(1 if bf16 else 0, n)
     _, gtot = prog.grad_offsets()
     check_grads(prog, E.run_wgrad(prog, mode, jobs, stash, gtot), tp, dict(m.named_parameters()))
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+def test_fused_level_program_emulated(bf16):
+    """The whole level as ONE program (warp field -> hyper sheet -> template; models.NerfModel._level_call): heads
+    publish their results as staged components, the template encodes them, the backward walks the three chains in
+    reverse and feeds the warp / sheet heads from the source-gradient accumulators; the GLO table is gathered by ray
+    index.  Small layer widths (the program structure is what is under test), against the oracle + torch autograd:
+    outputs, every weight gradient and the table gradient."""
+    from hypernerf_torch_amd.hypernerf import models
+    torch.manual_seed(0)
+    emb = {"warp": list(range(12)), "camera": [0], "appearance": list(range(12)), "time": list(range(12))}
+    m = models.NerfModel(emb, n_samples_coarse=8, n_samples_fine=8, hyper_slice_method="bendy_sheet",
+                         use_nerf_embed=True, use_alpha_cond=True, xyz_fourier_dim=2, hyper_fourier_dim=1,
+                         view_fourier_dim=1)
+    m.warp_field = warping.TranslationField(in_ch=3, in_ch_embed=8, depth=6, hidden_channels=32)
+    m.hyper_sheet_mlp = modules.HyperSheetMLP(out_ch=4, in_ch_embed=8, depth=6, width=32)
+    m.nerf_mlps_coarse = modules.NerfMLP(in_ch=27, trunk_depth=4, trunk_width=64, rgb_branch_depth=2,
+                                         rgb_branch_width=32, hidden_activation=torch.nn.ReLU(), skips=[2],
+                                         rgb_activation=torch.nn.Sigmoid(), alpha_condition_dim=8, rgb_condition_dim=9,
+                                         alpha_brach_width=32)
+    sd = load_hash(m, 21)
+    b, s = 5, 8
+    n = b * s                      # 40 points: one full block and a partial one
+    pts = H.uniform(7, "pts", (b, s, 3), -1, 1).double()
+    dirs = H.uniform(7, "dirs", (b, 3), -1, 1).double()
+    idx = torch.tensor([3, 11, 0, 3, 7])
+    call = m._level_call("coarse")
+    prog = call.program
+    assert [len(c) for c in prog.chains()] == [7, 7, 10]
+    mode = E.Mode(bf16)
+    tables = prog.host_tables(1 if bf16 else 0)
+    params = np_params(prog)
+    table = sd["warp_embed.embed.weight"]
+    srcs = [(pts.reshape(n, 3).numpy(), False), (dirs.numpy(), True), (table.numpy(), True, idx.numpy()), None]
+    outs, stash = E.run_forward(prog, mode, tables, params, srcs, n, s, [7, 3, 1])
+    tp = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    e = O.glo_embed(tp["warp_embed.embed.weight"], idx)
+    ee = e[:, None, :].expand(b, s, 8)
+    warped = torch.cat([O.translation_field(tp, "warp_field", pts, ee), O.hyper_sheet(tp, "hyper_sheet_mlp", pts, ee)], -1)
+    feat = torch.cat([O.posenc_orig(warped[..., :3], 2), O.posenc_orig(warped[..., 3:], 1)], -1)
+    rgb, alpha = O.nerf_mlp(tp, "nerf_mlps_coarse", feat, e, O.posenc_orig(dirs, 1), trunk_depth=4, rgb_depth=2,
+                            skips=(2,))
+    np.testing.assert_allclose(outs[0].reshape(b, s, 7), warped.detach().numpy(), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(outs[1].reshape(b, s, 3), rgb.detach().numpy(), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(outs[2].reshape(b, s, 1), alpha.detach().numpy(), rtol=1e-9, atol=1e-11)
+    g_rgb = H.uniform(8, "g_rgb", (n, 3), -1, 1).double()
+    g_a = H.uniform(8, "g_a", (n, 1), -1, 1).double()
+    g_w = H.uniform(8, "g_w", (n, 7), -1, 1).double()       # an external gradient on warped_points as well
+    ((rgb.reshape(n, 3) * g_rgb).sum() + (alpha.reshape(n, 1) * g_a).sum() + (warped.reshape(n, 7) * g_w).sum()).backward()
+    bsrcs = srcs[:3] + [(outs[0], False), (g_rgb.numpy(), False), (g_a.numpy(), False), (outs[1], False),
+                        (g_w.numpy(), False)]
+    dsrc = E.run_backward(prog, mode, tables, params, bsrcs, n, s, stash)
+    cols = {c: sl for (si, c), sl in prog.dsrc_map.items() if si == 2}
+    rows = np.stack([dsrc[:, cols[c]].reshape(b, s).sum(1) for c in range(8)], axis=1)
+    d_table = np.zeros(table.shape)
+    np.add.at(d_table, idx.numpy(), rows)
+    np.testing.assert_allclose(d_table, tp["warp_embed.embed.weight"].grad.numpy(), rtol=1e-8, atol=1e-10)
+    mask, col = prog.embed_fold(2)
+    for c, sl in cols.items():
+        assert col[sl] == c and (mask >> ((sl & 3) + 4 * (sl >> 3))) & 1
+    jobs = prog.wgrad_jobs(1 if bf16 else 0, n)
+    _, gtot = prog.grad_offsets()
+    flat = E.run_wgrad(prog, mode, jobs, stash, gtot)
+    check_grads(prog, flat, tp, dict(m.named_parameters()))
+    # without the external gradient the optional source is simply absent
+    bsrcs[7] = None
+    for v in tp.values():
+        v.grad = None
+    e2 = O.glo_embed(tp["warp_embed.embed.weight"], idx)[:, None, :].expand(b, s, 8)
+    w2 = torch.cat([O.translation_field(tp, "warp_field", pts, e2), O.hyper_sheet(tp, "hyper_sheet_mlp", pts, e2)], -1)
+    f2 = torch.cat([O.posenc_orig(w2[..., :3], 2), O.posenc_orig(w2[..., 3:], 1)], -1)
+    r2, a2 = O.nerf_mlp(tp, "nerf_mlps_coarse", f2, e2[:, 0], O.posenc_orig(dirs, 1), trunk_depth=4, rgb_depth=2, skips=(2,))
+    ((r2.reshape(n, 3) * g_rgb).sum() + (a2.reshape(n, 1) * g_a).sum()).backward()
+    stash2 = E.run_forward(prog, mode, tables, params, srcs, n, s, [7, 3, 1])[1]
+    E.run_backward(prog, mode, tables, params, bsrcs, n, s, stash2)
+    flat2 = E.run_wgrad(prog, mode, jobs, stash2, gtot)
+    check_grads(prog, flat2, tp, dict(m.named_parameters()))
