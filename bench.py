@@ -62,7 +62,7 @@ def parse():
 
 
 def macs_per_point(prog):
-    return sum(ly.weight.shape[0] * ly.weight.shape[1] for ly in prog.layers)
+    return sum(ly.n_out * ly.in_features for ly in prog.layers)      # row-stacked layers count all their matrices
 
 
 def build_workload(a, dev, rank):

@@ -77,6 +77,7 @@ class HnCompositeArgs(C.Structure):
         ("out_med_depth", C.c_void_p), ("out_med_points", C.c_void_p),
         ("g_rgb", C.c_void_p), ("g_depth", C.c_void_p), ("g_acc", C.c_void_p), ("g_weights", C.c_void_p),
         ("d_rgb", C.c_void_p), ("d_raw", C.c_void_p), ("keep", C.c_void_p),
+        ("noise_scale", C.c_float), ("pad_", C.c_int32),
     ]
 
 
@@ -94,6 +95,7 @@ EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_
            "hn_mlp_wgrad_batched",
            "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf",
            "hn_embed_gather", "hn_embed_backward", "hn_se3_apply_forward", "hn_se3_apply_backward", "hn_generate_rays", "hn_adam_step",
+           "hn_mse_loss_forward", "hn_mse_loss_backward",
            "hn_probe_mfma"]
 
 _lib = None

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
         zz = a.z[row + s];
         zn = (s + 1 < S) ? a.z[row + s + 1] : 0.f;
         raw = a.raw[row + s];
-        if (a.noise != nullptr) raw += a.noise[row + s];
+        if (a.noise != nullptr) raw = __fadd_rn(raw, __fmul_rn(a.noise[row + s], a.noise_scale));
       }
       const float dz = (s + 1 < S) ? (zn - zz) : last;
       const float dd = dz * dnorm;
@@ -634,6 +634,62 @@ extern "C" int hn_adam_step(float* params, float* grads, float* exp_avg, float* 
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(hn_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                      exp_avg_sq, n, hyper_dev, step_dev, zero_grad);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss head (losses.py:4-14): mean squared error of the coarse and the fine render against the same target
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void hn_mse_fwd_kernel(const float* __restrict__ c, const float* __restrict__ f,
+                                                          const float* __restrict__ gt, long long n,
+                                                          float* __restrict__ loss) {
+  __shared__ float part[2][16];
+  float sc = 0.0f, sf = 0.0f;
+  for (long long i = threadIdx.x; i < n; i += 1024) {
+    const float g = gt[i];
+    const float dc = c[i] - g;
+    sc += dc * dc;
+    if (f != nullptr) { const float df = f[i] - g; sf += df * df; }
+  }
+  sc = hn_wave_sum(sc);
+  sf = hn_wave_sum(sf);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { part[0][wv] = sc; part[1][wv] = sf; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, b = 0.0f;
+    for (int k = 0; k < 16; ++k) { a += part[0][k]; b += part[1][k]; }
+    // mean of each level first, then their sum: the reference adds two nn.MSELoss results
+    loss[0] = a / (float)n + (f != nullptr ? b / (float)n : 0.0f);
+  }
+}
+__global__ void hn_mse_bwd_kernel(const float* __restrict__ c, const float* __restrict__ f,
+                                  const float* __restrict__ gt, long long n, const float* __restrict__ g_loss,
+                                  float* __restrict__ dc, float* __restrict__ df) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = (g_loss != nullptr ? g_loss[0] : 1.0f) * 2.0f / (float)n;
+  const float g = gt[i];
+  dc[i] = (c[i] - g) * s;
+  if (f != nullptr && df != nullptr) df[i] = (f[i] - g) * s;
+}
+extern "C" int hn_mse_loss_forward(const float* coarse, const float* fine, const float* gt, int64_t n, float* loss_out,
+                                   hnStream_t stream) {
+  if (n <= 0) return -2;
+  if (coarse == nullptr || gt == nullptr || loss_out == nullptr) return -3;
+  hipLaunchKernelGGL(hn_mse_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, coarse, fine, gt, (long long)n,
+                     loss_out);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int hn_mse_loss_backward(const float* coarse, const float* fine, const float* gt, int64_t n,
+                                    const float* g_loss, float* d_coarse, float* d_fine, hnStream_t stream) {
+  if (n <= 0) return -2;
+  if (coarse == nullptr || gt == nullptr || d_coarse == nullptr) return -3;
+  if ((fine == nullptr) != (d_fine == nullptr)) return -3;
+  hipLaunchKernelGGL(hn_mse_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, coarse,
+                     fine, gt, (long long)n, g_loss, d_coarse, d_fine);
   HN_CHECK_LAUNCH();
   return 0;
 }

@@ -383,7 +383,7 @@ def sample_pdf(weights, z, u, origins=None, directions=None, want_points=True, b
 class _CompositeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median,
-                dust_threshold=None, keep=None):
+                dust_threshold=None, keep=None, noise_scale=1.0):
         L.require_gpu(rgb, raw, z, dirs)
         L.load()
         b, s = z.shape
@@ -402,6 +402,7 @@ class _CompositeFn(torch.autograd.Function):
         keep_c = keep.detach().reshape(b, s).contiguous().float() if keep is not None else None
         a.has_dust, a.dust_threshold = int(dust_threshold is not None), float(dust_threshold or 0.0)
         a.keep = keep_c.data_ptr() if keep_c is not None else 0
+        a.noise_scale = float(noise_scale)
         o_rgb = torch.empty(b, 3, dtype=torch.float32, device=dev)
         o_depth = torch.empty(b, dtype=torch.float32, device=dev)
         o_acc = torch.empty(b, dtype=torch.float32, device=dev)
@@ -414,6 +415,7 @@ class _CompositeFn(torch.autograd.Function):
         L.launch("hn_composite_forward", C.byref(a), L.stream_handle())
         ctx.saved = (rgb_c, raw_c, noise_c, z_c, dirs_c)
         ctx.filt = (dust_threshold, keep_c)
+        ctx.noise_scale = float(noise_scale)
         ctx.cfg = (variant, int(white_bg), int(sample_at_infinity), b, s)
         ctx.raw_shape = raw.shape
         outs = [o_rgb, o_depth, o_acc, o_w]
@@ -435,6 +437,7 @@ class _CompositeFn(torch.autograd.Function):
         a.variant, a.n_rays, a.n_samples, a.white_bg, a.sample_at_infinity = variant, b, s, white_bg, sai
         a.rgb, a.raw, a.z = rgb_c.data_ptr(), raw_c.data_ptr(), z_c.data_ptr()
         a.noise = noise_c.data_ptr() if noise_c is not None else 0
+        a.noise_scale = ctx.noise_scale
         a.dirs, a.ray_ld = dirs_c.data_ptr(), dirs_c.stride(0)
         dust, keep_c = ctx.filt
         a.has_dust, a.dust_threshold = int(dust is not None), float(dust or 0.0)
@@ -448,15 +451,52 @@ class _CompositeFn(torch.autograd.Function):
         d_raw = torch.empty_like(raw_c)
         a.d_rgb, a.d_raw = d_rgb.data_ptr(), d_raw.data_ptr()
         L.launch("hn_composite_backward", C.byref(a), L.stream_handle())
-        return d_rgb, d_raw.view(ctx.raw_shape), None, None, None, None, None, None, None, None, None, None
+        return d_rgb, d_raw.view(ctx.raw_shape), None, None, None, None, None, None, None, None, None, None, None
 
 
 def composite(rgb, raw, noise, z, dirs, warped=None, variant=0, white_bg=False, sample_at_infinity=True,
-              want_median=True, dust_threshold=None, keep=None):
+              want_median=True, dust_threshold=None, keep=None, noise_scale: float = 1.0):
     """Returns (rgb (B,3), depth (B), acc (B), weights (B,S)[, med_depth (B)[, med_points (B)]]).
+    `noise` (B,S): standard-normal draws, scaled by `noise_scale` inside the kernel (noise_std of noise_regularize).
     dust_threshold / keep (B,S 0/1): the reference's filter_sigma (models.py:35-63) applied to the activated density."""
     return _CompositeFn.apply(rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median,
-                              dust_threshold, keep)
+                              dust_threshold, keep, noise_scale)
+
+
+# --------------------------------------------------------------------------------------------
+# loss head
+# --------------------------------------------------------------------------------------------
+class _MseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coarse, fine, target):
+        L.require_gpu(coarse, target)
+        L.load()
+        c = coarse.detach().contiguous()
+        f = fine.detach().contiguous() if fine is not None else None
+        t = target.detach().contiguous()
+        if c.shape != t.shape or (f is not None and f.shape != t.shape):
+            raise L.HnError("mse_loss: prediction and target shapes differ")
+        loss = torch.empty((), dtype=torch.float32, device=c.device)
+        L.launch("hn_mse_loss_forward", L.ptr(c), L.ptr(f), L.ptr(t), C.c_int64(c.numel()), L.ptr(loss),
+                 L.stream_handle())
+        ctx.saved = (c, f, t)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        L.load()
+        c, f, t = ctx.saved
+        g = g.contiguous().float()
+        dc = torch.empty_like(c)
+        df = torch.empty_like(f) if f is not None else None
+        L.launch("hn_mse_loss_backward", L.ptr(c), L.ptr(f), L.ptr(t), C.c_int64(c.numel()), L.ptr(g), L.ptr(dc),
+                 L.ptr(df), L.stream_handle())
+        return dc, df, None
+
+
+def mse_loss(coarse: torch.Tensor, fine: Optional[torch.Tensor], target: torch.Tensor) -> torch.Tensor:
+    """mean((coarse-target)^2) (+ mean((fine-target)^2)): losses.MSELoss of the reference as one kernel per direction."""
+    return _MseFn.apply(coarse, fine, target)
 
 
 # --------------------------------------------------------------------------------------------

@@ -141,6 +141,7 @@ class NerfModel(nn.Module):
         self.nerf_mlps_coarse = nerf_mlps_coarse
         self.nerf_mlps_fine = nerf_mlps_fine
         self._template_calls: Dict[Any, F.ProgramCall] = {}
+        self._det_u: Dict[Any, torch.Tensor] = {}
         self.precision: Optional[str] = None   # None = package default (functional.set_precision)
 
     # ---- properties of the reference ---------------------------------------------------------
@@ -395,11 +396,13 @@ class NerfModel(nn.Module):
                          b, s, device):
         """noise_regularize + Softplus + filter_sigma + volumetric_rendering + median-depth gather
         (models.py:485-489, 650-669) in the compositing kernel."""
+        scale = 1.0
         if noise is None and (self.noise_std is not None) and self.noise_std > 0.0 and self.use_stratified_sampling:
-            noise = torch.randn((b, s, 1), device=device, dtype=torch.float32) * self.noise_std
+            noise = torch.randn((b, s, 1), device=device, dtype=torch.float32)      # scaled inside the kernel
+            scale = float(self.noise_std)
         res = F.composite(rgb.view(b, s, 3), alpha.view(b, s), noise, z_vals, directions, warped, variant=0,
                           white_bg=self.use_white_background, sample_at_infinity=use_sample_at_infinity,
-                          want_median=True, dust_threshold=dust, keep=keep)
+                          want_median=True, dust_threshold=dust, keep=keep, noise_scale=scale)
         out['warped_points'] = warped
         out['rgb'], out['depth'], out['acc'], out['weights'], out['med_depth'] = res[0], res[1], res[2], res[3], res[4]
         out['med_points'] = res[5].view(b, 1, 1)
@@ -438,7 +441,13 @@ class NerfModel(nn.Module):
                 if self.use_stratified_sampling:
                     u = torch.rand(b, self.num_fine_samples, device=origins.device)
                 else:
-                    u = torch.linspace(0, 1, self.num_fine_samples).to(origins.device).expand(b, -1).contiguous()
+                    # the reference's deterministic draws (model_utils.py:226-227): built on the host with the same
+                    # ATen CPU op, uploaded once per (batch, device) — never inside a stream capture
+                    key = (b, self.num_fine_samples, str(origins.device))
+                    u = self._det_u.get(key)
+                    if u is None:
+                        u = torch.linspace(0, 1, self.num_fine_samples).to(origins.device).expand(b, -1).contiguous()
+                        self._det_u[key] = u
             z_fine, pts_fine, inds, _ = F.sample_pdf(coarse['weights'], z_vals, u, origins, directions)
             fine = self.render_samples('fine', pts_fine, z_fine, directions, viewdirs, metadata, extra_params,
                                        use_warp=use_warp, metadata_encoded=metadata_encoded,

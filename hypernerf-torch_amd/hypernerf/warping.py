@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as F
-from ..machine import AuxSpec, GradIn, OutSpec, Program, copy_features, posenc_features, posenc_jax_features
+from ..machine import AuxSpec, GradIn, Layer, OutSpec, Program, copy_features, posenc_features, posenc_jax_features
 from . import model_utils, modules
 
 
@@ -90,9 +90,9 @@ class SE3Field(nn.Module):
     oracle's restatement of the same formulas ("parity unpinned").  Use it by assigning
     `model.warp_field = SE3Field(in_ch=3)`.
 
-    Kernels: the trunk (posenc + 7 layers, >80 % of the field's arithmetic) is one program of the HIP MLP machine;
-    the two 128 -> 128 -> 3 heads are plain library GEMMs (rocBLAS through torch.nn.functional.linear) because both
-    read the same trunk output; the exponential map and the rigid transform are `hn_se3_apply_*`.
+    Kernels: encoder, trunk and both heads are ONE program of the HIP MLP machine (the two heads' first layers as one
+    row-stacked 128 -> 256 layer, their logit layers as windows on its halves); the exponential map and the rigid
+    transform are `hn_se3_apply_*`.  No library GEMM is involved.
     """
 
     def __init__(self, in_ch=1, out_ch=1):
@@ -131,35 +131,41 @@ class SE3Field(nn.Module):
                                  output_init=self.translation_init, output_channels=3)
         self._calls = {}
 
-    def _trunk_call(self, pts_grad: bool) -> F.ProgramCall:
+    def _field_call(self, pts_grad: bool) -> F.ProgramCall:
+        """ONE program for posenc -> trunk -> both heads (warping.py:212-225): the first Linear of `w_net` and of
+        `v_net` read the same trunk output, so they run as one 128 -> 256 layer whose matrix is the two stacked by
+        rows; each 128 -> 3 logit layer then reads its own half of that activation (a window).  Output (P, 6) =
+        [w | v]."""
         call = self._calls.get(pts_grad)
         if call is None:
-            if pts_grad:
-                raise NotImplementedError("gradient w.r.t. the input points of the warp field is not needed by the "
-                                          "reference's training path and not implemented")
+            if len(self.w_net.linears) != 1 or len(self.v_net.linears) != 1:
+                raise NotImplementedError("SE3Field heads deeper than the reference's (depth 0) are not implemented")
             aux = AuxSpec(posenc_jax_features(0, range(self.in_ch_pts), self.min_deg, self.max_deg,
                                               self.use_posenc_identity, pts_grad))
-            layers = modules.mlp_layers(self.trunk, "trunk", aux, None, OutSpec(0, 0, "none", wide=True),
-                                        GradIn(4, 0))
-            call = F.ProgramCall(Program(layers, name="SE3Field.trunk"), [False], [self.trunk_width], [("g", 0)])
+            layers = modules.mlp_layers(self.trunk, "trunk", aux, None, None, None)
+            tw, hw = self.trunk_width, self.rotation_width
+            if self.translation_width != hw or hw % 32:
+                raise NotImplementedError("SE3Field: rotation and translation heads of different / odd widths")
+            w0, v0 = self.w_net.linears[0], self.v_net.linears[0]
+            layers.append(Layer("heads.linears.0", [w0.weight, v0.weight], [w0.bias, v0.bias], main=(0, tw), act="relu"))
+            wl, vl = self.w_net.logit_layer, self.v_net.logit_layer
+            layers.append(Layer("w_net.logit_layer", wl.weight, wl.bias, main=(0, 2 * hw), act="none", commit=False,
+                                out=OutSpec(0, 0, "none"), grad_in=GradIn(4, 0)))
+            layers.append(Layer("v_net.logit_layer", vl.weight, vl.bias, main=(-hw, 2 * hw), act="none", commit=False,
+                                out=OutSpec(0, 3, "none"), grad_in=GradIn(4, 3)))
+            call = F.ProgramCall(Program(layers, name="SE3Field"), [False], [6], [("g", 0)])
             self._calls[pts_grad] = call
         return call
 
-    @staticmethod
-    def _head(mlp: "modules.MLP", x: torch.Tensor) -> torch.Tensor:
-        for lin in mlp.linears:
-            x = torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
-        return torch.nn.functional.linear(x, mlp.logit_layer.weight, mlp.logit_layer.bias)
-
     def warp(self, points: torch.Tensor, metadata_embed: torch.Tensor, extra_params: Dict[str, Any]):
-        """points (..., 3) -> warped points (..., 3); `metadata_embed` is ignored (reference: warping.py:223-224)."""
+        """points (..., 3) -> warped points (..., 3); `metadata_embed` is ignored (reference: warping.py:223-224).
+        Differentiable w.r.t. the points as well (through the encoder + trunk and through R p + t)."""
         lead = points.shape[:-1]
         ge = torch.is_grad_enabled()
         flat = points.reshape(-1, self.in_ch_pts)
-        (trunk_out,) = F.run_program(self._trunk_call(bool(points.requires_grad and ge)), [flat], 1)
-        w = self._head(self.w_net, trunk_out)
-        v = self._head(self.v_net, trunk_out)
-        return F.se3_apply(w, v, flat.detach() if not (points.requires_grad and ge) else flat).view(*lead, 3)
+        pg = bool(points.requires_grad and ge)
+        (wv,) = F.run_program(self._field_call(pg), [flat], 1)
+        return F.se3_apply(wv[:, 0:3], wv[:, 3:6], flat if pg else flat.detach()).view(*lead, 3)
 
     def forward(self, points, metadata, extra_params, return_jacobian: bool = False):
         out = {'warped_points': self.warp(points, metadata, extra_params)}

@@ -1,23 +1,20 @@
 """Loss head and PSNR of the reference (losses.py:4-14, metrics.py:4-13) — scalar reductions over (B,3) pixels.
 
-Kept in torch: two mean-squared errors per step are not part of the hot path."""
+`MSELoss` is one HIP launch forward (both levels, both means, their sum) and one backward (`hn_mse_loss_*`,
+functional.mse_loss); the metrics (`mse`, `psnr`: logging only, no gradient path in the reference) are torch
+one-liners.  GPU tensors only, like every op of the package."""
 import torch
 from torch import nn
 
-
-def _mean_sq(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-    return torch.nn.functional.mse_loss(pred, target)       # one fused elementwise + one reduction kernel
+from . import functional as F
 
 
 class MSELoss(nn.Module):
     """Sum over the rendered levels of mean((rgb - gt)^2): coarse always, fine when the model produced it."""
 
     def forward(self, inputs, targets):
-        total = _mean_sq(inputs['coarse']['rgb'], targets)
         fine = inputs.get('fine')
-        if fine is not None:
-            total = total + _mean_sq(fine['rgb'], targets)
-        return total
+        return F.mse_loss(inputs['coarse']['rgb'], fine['rgb'] if fine is not None else None, targets)
 
 
 loss_dict = {'mse': MSELoss}

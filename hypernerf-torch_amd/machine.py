@@ -122,9 +122,10 @@ class GradIn:
 @dataclass
 class Layer:
     name: str
-    weight: torch.nn.Parameter
-    bias: Optional[torch.nn.Parameter]
-    main: Optional[Tuple[int, int]] = None      # (first column, n columns) of W applied to `cur`
+    weight: torch.nn.Parameter                  # or a LIST of (rows_i, in) parameters stacked by rows (rows_i % 32 == 0):
+    bias: Optional[torch.nn.Parameter]          # several Linears reading the same input run as one layer (SE3Field heads)
+    main: Optional[Tuple[int, int]] = None      # (first column, n columns) of W applied to `cur`; a NEGATIVE first
+                                                # column -k0 makes the layer read cur[k0:] only (block-sparse window)
     aux: Optional[AuxSpec] = None
     aux_c0: int = 0
     act: str = "none"                           # 'none' | 'relu'
@@ -141,6 +142,14 @@ class Layer:
     mask_slot: int = -1
     out_slot: int = -1      # stash of the output activation
     dz_slot: int = -1       # stash of dZ
+    parts: List[Tuple[int, int, int, int]] = field(default_factory=list)   # (w_id, b_id, first row, rows) per stacked matrix
+    in_features: int = 0
+
+    def part_of_row(self, row: int) -> Tuple[int, int, int, int]:
+        for prt in self.parts:
+            if prt[2] <= row < prt[2] + prt[3]:
+                return prt
+        return self.parts[-1]
 
 
 @dataclass
@@ -185,7 +194,7 @@ class Program:
         for ly in self.layers:
             o, gi = ly.out, ly.grad_in
             if o is not None and o.publish is not None:
-                n = ly.weight.shape[0]
+                n = self._rows(ly)
                 if o.wide or n > 4:
                     raise ValueError(f"{ly.name}: only narrow heads can publish components")
                 o.publish_ci = len(self.comp_map)
@@ -198,24 +207,32 @@ class Program:
                 if q >= 4:
                     raise NotImplementedError("more than 4 heads fed from the source-gradient accumulators")
                 gi.dacc_q = q
-                for i in range(ly.weight.shape[0]):
+                for i in range(self._rows(ly)):
                     self.dsrc_map[(gi.from_dsrc[0], gi.from_dsrc[1] + i)] = 8 * q + i
                 self.reserved_slots.update(range(8 * q, 8 * q + 4))
                 q += 1
         for ly in self.layers:
-            ly.n_out = ly.weight.shape[0]
+            ws = list(ly.weight) if isinstance(ly.weight, (list, tuple)) else [ly.weight]
+            bs = list(ly.bias) if isinstance(ly.bias, (list, tuple)) else [ly.bias] * len(ws)
+            if len(ws) > 1 and any(w.shape[0] % 32 or w.shape[1] != ws[0].shape[1] for w in ws):
+                raise ValueError(f"{ly.name}: stacked matrices need equal in_features and rows in multiples of 32")
+            ly.in_features = ws[0].shape[1]
+            ly.n_out = sum(w.shape[0] for w in ws)
             nt_valid = (ly.n_out + 31) // 32
             ly.nt = pow2ceil(nt_valid)
             if ly.nt > 8:
                 raise NotImplementedError(f"{ly.name}: width {ly.n_out} > 256 is not supported by the MLP machine")
             if ly.out is not None and not ly.out.wide and ly.n_out > 4:
                 raise ValueError(f"{ly.name}: narrow OUT needs <= 4 outputs")
-            for prm in (ly.weight, ly.bias):
+            for prm in ws + bs:
                 if prm is not None and id(prm) not in pid:
                     pid[id(prm)] = len(self.params)
                     self.params.append(prm)
-            ly.w_id = pid[id(ly.weight)]
-            ly.b_id = pid[id(ly.bias)] if ly.bias is not None else -1
+            ly.parts, row0 = [], 0
+            for w_, b_ in zip(ws, bs):
+                ly.parts.append((pid[id(w_)], pid[id(b_)] if b_ is not None else -1, row0, w_.shape[0]))
+                row0 += w_.shape[0]
+            ly.w_id, ly.b_id = ly.parts[0][0], ly.parts[0][1]
             ly.bias_off = self.bias_len
             self.bias_len += 32 * ly.nt
             if ly.main is not None:
@@ -246,9 +263,14 @@ class Program:
                             self.dsrc_map[(ft.src, ft.comp)] = next(k for k in range(L.HN_DSRC_COMPS + 1) if k not in used)
             if ly.main is None and ly.aux is None:
                 raise ValueError(f"{ly.name}: layer without input")
-            total_in = (ly.main[1] if ly.main else 0) + (ly.aux.n if ly.aux else 0)
-            if total_in != ly.weight.shape[1]:
-                raise ValueError(f"{ly.name}: inputs {total_in} != in_features {ly.weight.shape[1]}")
+            main_in = 0
+            if ly.main is not None:     # a negative first column: only cur[-main[0]:] is read
+                main_in = ly.main[1] + min(0, ly.main[0])
+                if ly.main[0] < 0 or ly.main[0] + ly.main[1] > ly.in_features:
+                    main_in = min(ly.in_features - (ly.aux.n if ly.aux else 0), main_in)
+            total_in = main_in + (ly.aux.n if ly.aux else 0)
+            if total_in != ly.in_features:
+                raise ValueError(f"{ly.name}: inputs {total_in} != in_features {ly.in_features}")
             if ly.commit:
                 cur = ly
         if self.n_dsrc > L.HN_DSRC_COMPS:
@@ -266,6 +288,16 @@ class Program:
         last = self.layers[-1]
         if last.out is None:
             raise ValueError("the last layer of a program must produce an output")
+
+    @staticmethod
+    def _rows(ly: Layer) -> int:
+        w = ly.weight
+        return sum(x.shape[0] for x in w) if isinstance(w, (list, tuple)) else w.shape[0]
+
+    @staticmethod
+    def _main_end(ly: Layer) -> int:
+        """One past the last valid source column of the main block (a window layer's matrix is narrower than cur)."""
+        return min(ly.main[0] + ly.main[1], ly.in_features - (ly.aux.n if ly.aux is not None else 0))
 
     @property
     def n_dsrc(self):
@@ -405,19 +437,19 @@ class Program:
                 units[pos + u] = (w_id, ld, r0, c0, r_end, c_end, k0, transposed)
 
         for ly in self.layers:
-            ld = ly.weight.shape[1]
+            ld = ly.in_features
             for t in range(ly.nt):
+                w_id, _b, row0, rows = ly.part_of_row(32 * t)
                 if ly.main is not None:
                     k32 = ly.prev.nt
                     pos, ctr = self._take(ctr, k32 * u32)
                     for k in range(k32):
-                        put(pos + k * u32, ly.w_id, ld, 32 * t, ly.main[0] + 32 * k, ly.n_out,
-                            ly.main[0] + ly.main[1], 0)
+                        put(pos + k * u32, w_id, ld, 32 * t - row0, ly.main[0] + 32 * k, rows, self._main_end(ly), 0)
                 if ly.aux is not None:
                     for g in range(ly.aux.groups):
                         pos, ctr = self._take(ctr, 2 * u32)
                         for kk in range(2):
-                            put(pos + kk * u32, ly.w_id, ld, 32 * t, ly.aux_c0 + 64 * g + 32 * kk, ly.n_out,
+                            put(pos + kk * u32, w_id, ld, 32 * t - row0, ly.aux_c0 + 64 * g + 32 * kk, rows,
                                 ly.aux_c0 + ly.aux.n, 0)
         return units, ctr
 
@@ -427,9 +459,10 @@ class Program:
         ctr = 0
 
         def put(pos, ly: Layer, r0, c0, c_end):
+            w_id, _b, row0, rows = ly.part_of_row(r0)
             for u in range(u32):
                 k0 = 16 * u if mode == L.HN_MODE_BF16 else 4 * u
-                units[pos + u] = (ly.w_id, ly.weight.shape[1], r0, c0, ly.n_out, c_end, k0, 1)
+                units[pos + u] = (w_id, ly.in_features, r0 - row0, c0, rows, c_end, k0, 1)
 
         for step in self.bwd_plan:
             if step[0] == "layer":
@@ -437,11 +470,10 @@ class Program:
                 for t in range(P.nt):
                     pos, ctr = self._take(ctr, consumer.nt * u32)
                     for k in range(consumer.nt):
-                        put(pos + k * u32, consumer, 32 * k, consumer.main[0] + 32 * t,
-                            consumer.main[0] + consumer.main[1])
+                        put(pos + k * u32, consumer, 32 * k, consumer.main[0] + 32 * t, self._main_end(consumer))
                     if head is not None:
                         pos, ctr = self._take(ctr, u32)
-                        put(pos, head, 0, head.main[0] + 32 * t, head.main[0] + head.main[1])
+                        put(pos, head, 0, head.main[0] + 32 * t, self._main_end(head))
             elif step[0] == "aux":
                 _, ly, g, from2 = step
                 for tt in range(2):
@@ -492,9 +524,14 @@ class Program:
         bu, bc = self._stream_bwd(mode)
         fwd_units, fwd_chunks = self._units_array(fu, fc)
         bwd_units, bwd_chunks = self._units_array(bu, bc)
-        bias = np.zeros(len(self.layers), dtype=L.PACK_BIAS_DT)
-        for i, ly in enumerate(self.layers):
-            bias[i] = (ly.b_id, ly.n_out if ly.b_id >= 0 else 0, ly.bias_off, 32 * ly.nt)
+        rows = []
+        for ly in self.layers:
+            for j, (_w, b_id, row0, nrows) in enumerate(ly.parts):
+                last = j == len(ly.parts) - 1
+                rows.append((b_id, nrows if b_id >= 0 else 0, ly.bias_off + row0, (32 * ly.nt - row0) if last else nrows))
+        bias = np.zeros(len(rows), dtype=L.PACK_BIAS_DT)
+        for i, r_ in enumerate(rows):
+            bias[i] = r_
         feat = np.zeros(max(1, len(self.feat_table)), dtype=L.FEAT_DT)
         for i, f in enumerate(self.feat_table):
             slot = self.dsrc_map.get((f.src, f.comp), -1) + 1 if f.need_grad else 0
@@ -559,20 +596,21 @@ class Program:
             if ly.aux is not None:
                 segs.append((offs[ly.aux.slot][0], 2 * ly.aux.groups, ly.aux_c0, ly.aux.n))
             z_off = offs[ly.dz_slot][0]
-            n_tiles = (ly.n_out + 31) // 32
             first = True
             for (x_off, x_nt, c0, ncols) in segs:
                 k_tiles = (ncols + 31) // 32
-                for nt0 in range(0, n_tiles, tmax):
-                    n_nt = min(tmax, n_tiles - nt0)
-                    for kt0 in range(0, k_tiles, tmax):
-                        n_kt = min(tmax, k_tiles - kt0)
-                        with_bias = first and kt0 == 0 and ly.b_id >= 0
-                        rects.append((ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias))
+                for prt in ly.parts:                    # one rectangle set per stacked matrix
+                    p_t0, p_tiles = prt[2] // 32, (prt[3] + 31) // 32
+                    for nt0 in range(p_t0, p_t0 + p_tiles, tmax):
+                        n_nt = min(tmax, p_t0 + p_tiles - nt0)
+                        for kt0 in range(0, k_tiles, tmax):
+                            n_kt = min(tmax, k_tiles - kt0)
+                            with_bias = first and kt0 == 0 and prt[1] >= 0
+                            rects.append((ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias, prt))
                 first = False
         total_tiles = sum(r[8] + r[9] for r in rects)
         jobs = []
-        for (ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias) in rects:
+        for (ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias, prt) in rects:
             gn, gk = self._wave_grid(n_nt, n_kt)
             bps = max(1, stage_tiles // (n_nt + n_kt))
             nstage = -(-nblk // bps)
@@ -586,9 +624,10 @@ class Program:
             bounds[-1] = nblk
             for b0, b1 in zip(bounds[:-1], bounds[1:]):
                 if b1 > b0:
+                    c_end = min(c0 + ncols, ly.in_features)      # window layers: the matrix is narrower than cur
                     jobs.append((z_off, x_off, ly.nt, x_nt, nt0, kt0, n_nt, n_kt, b0, b1,
-                                 goffs[ly.w_id], ly.weight.shape[1], 32 * nt0, c0 + 32 * kt0, ly.n_out, c0 + ncols,
-                                 goffs[ly.b_id] if with_bias else -1, gn | gk << 8 | bps << 16))
+                                 goffs[prt[0]], ly.in_features, 32 * nt0 - prt[2], c0 + 32 * kt0, prt[3], c_end,
+                                 goffs[prt[1]] if with_bias else -1, gn | gk << 8 | bps << 16))
         # heaviest jobs first: the tail of the launch is then made of short jobs
         jobs.sort(key=lambda j: -(j[6] + j[7]) * (j[9] - j[8]))
         arr = np.zeros(len(jobs), dtype=L.DWJOB_DT)

@@ -64,16 +64,15 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         call = model.fused_call(emb_xyz, emb_dir, weights_only)
         (o,) = F.run_program(call, [pts.reshape(-1, 3), rays_d], s)
         if noise is None:
-            noise = torch.randn(n_rays, s, device=rays.device)
-        noise = noise * noise_std
+            noise = torch.randn(n_rays, s, device=rays.device)      # drawn on every call (rendering.py:152)
         if weights_only:
             dummy_rgb = torch.zeros(n_rays, s, 3, device=rays.device)
             res = F.composite(dummy_rgb, o.view(n_rays, s), noise, z, rays_d, None, variant=1, white_bg=False,
-                              sample_at_infinity=True, want_median=False)
+                              sample_at_infinity=True, want_median=False, noise_scale=float(noise_std))
             return None, None, res[3], res[2]
         o = o.view(n_rays, s, 4)
         res = F.composite(o[..., :3], o[..., 3], noise, z, rays_d, None, variant=1, white_bg=white_back,
-                          sample_at_infinity=True, want_median=False)
+                          sample_at_infinity=True, want_median=False, noise_scale=float(noise_std))
         return res[0], res[1], res[3], res[2]
 
     rgb_c, depth_c, w_c, op_c = inference(model_coarse, xyz, z_vals, rng.get('noise_coarse'), test_time)

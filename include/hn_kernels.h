@@ -270,7 +270,8 @@ typedef struct {
   float dust_threshold;
   const float* rgb;    /* (B,S,3) */
   const float* raw;    /* (B,S) raw density */
-  const float* noise;  /* (B,S) already scaled, or NULL */
+  const float* noise;  /* (B,S) standard-normal draws (or NULL); the kernel adds noise_scale * noise to the raw density
+                          (model_utils.noise_regularize, model_utils.py:300-317: randn * noise_std) */
   const float* z;      /* (B,S) */
   const float* dirs;   /* (B,3) row stride ray_ld */
   int64_t ray_ld;
@@ -289,6 +290,8 @@ typedef struct {
   float* d_rgb;           /* (B,S,3) */
   float* d_raw;           /* (B,S) */
   const float* keep;      /* (B,S) 0/1 density mask (filter_sigma's bounding box) or NULL; forward and backward */
+  float noise_scale;      /* noise_std; 1 for draws that arrive already scaled */
+  int32_t pad_;
 } HnCompositeArgs;
 int hn_composite_forward(const HnCompositeArgs* a, hnStream_t stream);
 int hn_composite_backward(const HnCompositeArgs* a, hnStream_t stream);
@@ -314,6 +317,14 @@ int hn_embed_gather(const float* table, const int64_t* idx, int n_rays, int dim,
                     float* out, hnStream_t stream);
 int hn_embed_backward(const float* d_points, int ld, int col0, const int64_t* idx, int n_rays,
                       int n_samples, int dim, int n_rows, float* d_table, hnStream_t stream);
+
+/* The reference's loss head (losses.py:4-14): loss = mean((coarse - gt)^2) [+ mean((fine - gt)^2)] over (B,3) pixels,
+ * one launch forward (one workgroup; the result is written, not accumulated) and one launch backward:
+ * d_coarse = d_fine-style 2 (pred - gt) / n * g_loss[0] (g_loss on the device; NULL = 1).  fine / d_fine may be NULL. */
+int hn_mse_loss_forward(const float* coarse, const float* fine, const float* gt, int64_t n, float* loss_out,
+                        hnStream_t stream);
+int hn_mse_loss_backward(const float* coarse, const float* fine, const float* gt, int64_t n, const float* g_loss,
+                         float* d_coarse, float* d_fine, hnStream_t stream);
 
 /* torch.optim.Adam (the reference's default optimizer, utils/__init__.py get_optimizer) over ONE flat fp32 buffer
  * (ParamArena): p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), m,v updated first, L2 weight decay added to the

@@ -449,14 +449,26 @@ def test_se3_field_warp_vs_oracle():
         pts = H.uniform(41, "se3pts", (6, 50, 3), -1.0, 1.0)
         g = H.normal(41, "se3go", (6, 50, 3))
         p = {"wf." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
-        ref = O.se3_field(p, "wf", pts)
+        pr = pts.clone().requires_grad_(True)
+        ref = O.se3_field(p, "wf", pr)
         (ref * g).sum().backward()
-        out = f.warp(pts.to(DEV), None, {"warp_alpha": None})
+        pg = pts.to(DEV).requires_grad_(True)
+        out = f.warp(pg, None, {"warp_alpha": None})
         assert out.shape == (6, 50, 3)
         (out * g.to(DEV)).sum().backward()
         assert_close(out, ref, 1e-4, "SE3Field.warp")
         for k, prm in f.named_parameters():
             assert_grad_close(prm.grad, p["wf." + k].grad, 1e-3, f"SE3Field d {k}")
+        # gradient w.r.t. the points: through R p + t (hn_se3_apply_backward) and through encoder + trunk + heads
+        assert_grad_close(pg.grad, pr.grad, 1e-3, "SE3Field d points")
+        # no library GEMM: the only launches of a forward are the machine and the exp-map kernel
+        from hypernerf_torch_amd import _lib as L
+        L.KERNEL_TIMES = {}
+        with torch.no_grad():
+            f.warp(pts.to(DEV), None, {"warp_alpha": None})
+        names = set(k.split("[")[0] for k in L.collect_kernel_times())
+        L.KERNEL_TIMES = None
+        assert names <= {"hn_mlp_forward", "hn_se3_apply_forward", "hn_pack_units"}, names
         assert set(f(pts.to(DEV), None, {"warp_alpha": None}).keys()) == {"warped_points"}
     finally:
         HN.set_precision("bf16")

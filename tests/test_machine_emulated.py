@@ -243,3 +243,47 @@ def test_fused_level_program_emulated(bf16):
     E.run_backward(prog, mode, tables, params, bsrcs, n, s, stash2)
     flat2 = E.run_wgrad(prog, mode, jobs, stash2, gtot)
     check_grads(prog, flat2, tp, dict(m.named_parameters()))
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+def test_se3_field_program_emulated(bf16):
+    """SE3Field as ONE program (warping.py:212-225): encoder -> trunk -> [w_net.linears.0 ; v_net.linears.0] as one
+    row-stacked 128 -> 256 layer -> two logit layers reading a window (one half) of that activation each.  Outputs
+    (w | v), every weight gradient (the stacked layer's go to two different parameters) and the gradient w.r.t. the
+    points, against the oracle's MLPs + autograd."""
+    torch.manual_seed(0)
+    f = warping.SE3Field(in_ch=3)
+    sd = load_hash(f, 13)
+    n = 40
+    pts = H.uniform(9, "pts", (n, 3), -1, 1).double()
+    call = f._field_call(True)
+    prog = call.program
+    assert [len(c) for c in prog.chains()] == [10]
+    mode = E.Mode(bf16)
+    tables = prog.host_tables(1 if bf16 else 0)
+    params = np_params(prog)
+    srcs = [(pts.numpy(), False), None, None, None]
+    outs, stash = E.run_forward(prog, mode, tables, params, srcs, n, 1, [6])
+    tp = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pt = pts.clone().requires_grad_(True)
+    # the encoder with the program's own (fp32) scale constants, evaluated in fp64 like the emulation
+    scales = (2.0 ** torch.linspace(0.0, 8.0, steps=8)).double()
+    xb = pt[..., None, :] * scales[:, None]
+    h = torch.sin(torch.stack((xb, xb + 0.5 * 3.1415926), dim=-2)).reshape(n, -1)
+    assert float((h - O.posenc_jax(pt, 0, 8, False)).abs().max()) < 1e-4       # = the oracle's encoder up to fp32 scales
+    t = O.mlp(tp, "trunk", h, depth=6)
+    w = O.mlp(tp, "w_net", t, depth=0)
+    v = O.mlp(tp, "v_net", t, depth=0)
+    np.testing.assert_allclose(outs[0][:, :3], w.detach().numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(outs[0][:, 3:], v.detach().numpy(), rtol=1e-9, atol=1e-12)
+    g = H.uniform(10, "g", (n, 6), -1, 1).double()
+    ((w * g[:, :3]).sum() + (v * g[:, 3:]).sum()).backward()
+    bsrcs = srcs + [(g.numpy(), False)]
+    dsrc = E.run_backward(prog, mode, tables, params, bsrcs, n, 1, stash)
+    cx = {c: sl for (si, c), sl in prog.dsrc_map.items() if si == 0}
+    got = np.stack([dsrc[:, cx[c]] for c in range(3)], axis=1)
+    np.testing.assert_allclose(got, pt.grad.numpy(), rtol=1e-7, atol=1e-10)
+    jobs = prog.wgrad_jobs(1 if bf16 else 0, n)
+    _, gtot = prog.grad_offsets()
+    flat = E.run_wgrad(prog, mode, jobs, stash, gtot)
+    check_grads(prog, flat, tp, dict(f.named_parameters()))

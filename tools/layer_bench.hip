@@ -64,7 +64,7 @@ DEV void wait_vmcnt(int n) {
 // SPREAD: the DMA pieces of a chunk are not issued in a burst behind the chunk barrier (where all 8 waves stop issuing
 //         MFMAs at the same time) but one at a time from `poll()` calls placed in the MFMA stream
 // WSRC:   0 ring, 1 static chunk (no DMA, no barrier), 2 registers, 3 barriers without DMA, 4 DMA without barriers
-template <int WAVES, int RING, bool CNT, int CHUNK, bool SPREAD, int WSRC>
+template <int WAVES, int RING, bool CNT, int CHUNK, bool SPREAD, int WSRC, int LOADERS = 0>
 struct Ring {
   const char* g;
   char* lds;
@@ -73,12 +73,13 @@ struct Ring {
   int ops;       // vector-memory instructions this wave has issued so far
   int pend, pend_chunk;
   unsigned long long hist;  // `ops` (16 bits each) right after the DMA of the most recently issued chunks, latest lowest
-  static constexpr int PIECES = CHUNK / WAVES;
+  static constexpr int PIECES = LOADERS ? CHUNK / LOADERS : CHUNK / WAVES;
   DEV void piece(int c, int i) {
     if (WSRC == 3) return;
+    if (LOADERS && wave < WAVES) return;          // compute waves issue no DMA
     const char* src = g + (size_t)c * (CHUNK * 1024);
     char* dst = lds + (c % RING) * (CHUNK * 1024);
-    const int unit = wave + i * WAVES;
+    const int unit = LOADERS ? (wave - WAVES) + i * LOADERS : wave + i * WAVES;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + unit * 1024 + lane * 16),
                                      (__attribute__((address_space(3))) void*)(dst + unit * 1024), 16, 0, 0);
   }
@@ -117,7 +118,8 @@ struct Ring {
       int younger = nchunks - 1 - c;            // chunks issued after chunk c
       if (younger > RING - 2) younger = RING - 2;
       const int mark = (int)((hist >> (16 * younger)) & 0xffff);
-      if (CNT) wait_vmcnt((ops - mark) & 0xffff);
+      if (LOADERS && wave < WAVES) { /* the loader waves wait for the DMA */ }
+      else if (CNT) wait_vmcnt((ops - mark) & 0xffff);
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (WSRC != 4) __builtin_amdgcn_s_barrier();
@@ -200,18 +202,23 @@ DEV void epi_share(int k, int tp, f32x16& a, u32x4* frag, unsigned& bits, const 
 //       from registers (no LDS reads at all)
 // EPI:  0 = acc -> fragments by plain packing, 1 = + ReLU, 2 = + mask words (stored), 3 = + transposes (not stored),
 //       4 = + stash stores (the full training epilogue)
-template <int NB, int WAVES, bool PIPE, int RING, bool CNT, int WSRC, int EPI, int CHUNK, bool SPREAD, int STORE>
-__global__ __launch_bounds__(WAVES * 64, NB == 2 ? 1 : 2) void layer_chain(const Args a) {
+template <int NB, int WAVES, bool PIPE, int RING, bool CNT, int WSRC, int EPI, int CHUNK, bool SPREAD, int STORE, int LOADERS>
+__global__ __launch_bounds__((WAVES + LOADERS) * 64, LOADERS ? 3 : (NB == 2 ? 1 : 2)) void layer_chain(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
-  Ring<WAVES, RING, CNT, CHUNK, SPREAD, WSRC> ws;
+  Ring<WAVES, RING, CNT, CHUNK, SPREAD, WSRC, LOADERS> ws;
   ws.g = a.wstream; ws.lds = smem; ws.nchunks = a.n_layers * 128 / CHUNK; ws.wave = wave; ws.lane = lane;
   float* bias_lds = reinterpret_cast<float*>(smem + RING * CHUNK * 1024);
   for (int i = threadIdx.x; i < a.n_layers * 256; i += blockDim.x) bias_lds[i] = a.bias[i];
   __syncthreads();
 
+  if (LOADERS && wave >= WAVES) {       // dedicated loader waves: all DMA, all vmcnt waits, no arithmetic
+    ws.start();
+    for (int c = 0; c < ws.nchunks; ++c) ws.take(CHUNK);
+    return;
+  }
   const int nblk_total = (a.n_points + 31) / 32;
   const int blk0 = (blockIdx.x * WAVES + wave) * NB;
   u32x4 cur[NB][16], nxt[NB][16];
@@ -370,9 +377,9 @@ static float bf16_to_f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float y; me
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int NB, int WAVES, bool PIPE, int RING, bool CNT, int WSRC, int EPI, int CHUNK = 32, bool SPREAD = false, int STORE = 0>
+template <int NB, int WAVES, bool PIPE, int RING, bool CNT, int WSRC, int EPI, int CHUNK = 32, bool SPREAD = false, int STORE = 0, int LOADERS = 0>
 static double run(const char* name, Args a, int reps, std::vector<uint16_t>* out_host) {
-  auto k = layer_chain<NB, WAVES, PIPE, RING, CNT, WSRC, EPI, CHUNK, SPREAD, STORE>;
+  auto k = layer_chain<NB, WAVES, PIPE, RING, CNT, WSRC, EPI, CHUNK, SPREAD, STORE, LOADERS>;
   a.train = EPI;
   const size_t lds = (size_t)RING * CHUNK * 1024 + a.n_layers * 256 * 4;
   CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -380,10 +387,10 @@ static double run(const char* name, Args a, int reps, std::vector<uint16_t>* out
   const int grid = (a.n_points + pts_wg - 1) / pts_wg;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(WAVES * 64), lds, 0, a);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3((WAVES + LOADERS) * 64), lds, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(WAVES * 64), lds, 0, a);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3((WAVES + LOADERS) * 64), lds, 0, a);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -461,22 +468,18 @@ int main(int argc, char** argv) {
   std::vector<uint16_t> o0, o1;
   auto same = [&](const char* nm) { size_t diff = 0; for (size_t i = 0; i < o0.size(); ++i) diff += o0[i] != o1[i]; printf("   %s vs base: %zu differing outputs\n", nm, diff); };
   run<1, 8, false, 2, false, 0, 4>("base  ring2 vmcnt0 full", a, reps, &o0); check(o0, "base");
-  for (int rep = 0; rep < 2; ++rep) {
-  run<1, 8, true, 3, true, 0, 4>("pipe ring3 burst store0", a, reps, &o1); same("burst");
-  run<1, 8, true, 3, true, 0, 4, 32, true, 0>("pipe ring3 SPREAD store0", a, reps, &o1); same("spread");
-  run<1, 8, true, 3, true, 0, 4, 32, true, 1>("pipe ring3 SPREAD store1(nt split)", a, reps, &o1); same("spread s1");
-  run<1, 8, true, 3, true, 0, 4, 32, true, 2>("pipe ring3 SPREAD store2(plain split)", a, reps, &o1); same("spread s2");
-  run<1, 8, true, 2, true, 0, 4, 64, true, 1>("pipe ring2x64K SPREAD store1", a, reps, &o1); same("64K");
-  run<1, 8, true, 4, true, 0, 4, 32, true, 1>("pipe ring4 SPREAD store1", a, reps, &o1); same("ring4");
-  run<1, 8, true, 3, true, 0, 1>("pipe ring3 burst epi1", a, reps, nullptr);
-  run<1, 8, true, 3, true, 0, 1, 32, true, 0>("pipe ring3 SPREAD epi1", a, reps, nullptr);
-  run<1, 8, true, 2, true, 0, 1, 64, true, 0>("pipe ring2x64K SPREAD epi1", a, reps, nullptr);
-  run<1, 8, true, 3, true, 3, 1>("pipe barriers only (no DMA) epi1", a, reps, nullptr);
-  run<1, 8, true, 3, true, 4, 1>("pipe DMA burst, no barriers epi1", a, reps, nullptr);
-  run<1, 8, true, 3, true, 4, 1, 32, true, 0>("pipe DMA spread, no barriers epi1", a, reps, nullptr);
-  run<1, 8, true, 3, true, 1, 1>("pipe static LDS epi1", a, reps, nullptr);
-  run<1, 8, true, 3, true, 1, 4, 32, false, 1>("pipe static LDS epi4 store1", a, reps, nullptr);
-  run<1, 8, true, 3, true, 1, 4, 32, false, 2>("pipe static LDS epi4 store2", a, reps, nullptr);
+  for (int rep = 0; rep < 3; ++rep) {
+  run<1, 8, false, 2, false, 0, 4>("base  ring2 vmcnt0 full", a, reps, &o1); same("base");
+  run<1, 8, false, 3, true, 0, 4>("base  ring3 counted full", a, reps, &o1); same("ring3c");
+  run<1, 8, true, 3, true, 0, 4>("pipe  ring3 counted full", a, reps, &o1); same("pipe");
+  run<1, 8, false, 3, true, 0, 4, 32, false, 0, 4>("base  ring3 + 4 LOADER waves", a, reps, &o1); same("loaders");
+  run<1, 8, false, 4, true, 0, 4, 32, false, 0, 4>("base  ring4 + 4 LOADER waves", a, reps, &o1); same("loaders r4");
+  run<1, 8, false, 2, true, 0, 4, 64, false, 0, 4>("base  ring2x64K + 4 LOADER waves", a, reps, &o1); same("loaders 64K");
+  run<1, 8, false, 3, true, 0, 4, 32, false, 0, 2>("base  ring3 + 2 LOADER waves", a, reps, &o1); same("loaders2");
+  run<1, 8, false, 3, true, 0, 1, 32, false, 0, 4>("base  ring3 + 4 LOADERS epi1", a, reps, nullptr);
+  run<1, 8, false, 3, true, 0, 1>("base  ring3 counted epi1", a, reps, nullptr);
+  run<1, 8, false, 3, true, 1, 1>("base  static LDS epi1", a, reps, nullptr);
+  run<1, 8, false, 3, true, 1, 4>("base  static LDS full", a, reps, nullptr);
   }
   return 0;
 }
