@@ -297,7 +297,13 @@ class Program:
     @staticmethod
     def _main_end(ly: Layer) -> int:
         """One past the last valid source column of the main block (a window layer's matrix is narrower than cur)."""
-        return min(ly.main[0] + ly.main[1], ly.in_features - (ly.aux.n if ly.aux is not None else 0))
+        end = ly.main[0] + ly.main[1]
+        if end > ly.in_features:            # window layer
+            if ly.aux is not None:
+                raise NotImplementedError(f"{ly.name}: a window on the running activation cannot be combined with "
+                                          "generated input features")
+            end = ly.in_features
+        return end
 
     @property
     def n_dsrc(self):

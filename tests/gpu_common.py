@@ -56,16 +56,23 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+FLOOR_FRAC = 0.05      # elements below 5 % of the tensor's scale are compared absolutely (at tol x that floor)
+
+
 def assert_close(a, b, tol, what):
-    """max |a-b| <= tol * max(1, max|b|): the north-star's '<=1e-4 rel' read against the tensor's scale."""
+    """The north-star's '<= 1e-4 rel', ELEMENT-wise: |a-b| <= tol * max(|b|, FLOOR_FRAC * scale) for every element,
+    scale = max(1, max|b|) — relative to the element itself wherever it is not near zero, and an absolute
+    tol * 0.05 * scale (5e-6 for tol 1e-4 on an O(1) tensor) for the elements that are.  The measured worst ratios
+    of a GPU run are written to HN_PARITY_REPORT (profiles/r02_parity_errors.json)."""
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     assert a.shape == b.shape, (what, a.shape, b.shape)
-    err = float((a - b).abs().max())
-    scale = max(1.0, float(b.abs().max()))
-    assert np.isfinite(err), what
-    _record(what, "tensor-scale", err / scale, tol)
-    assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:.1e} * {scale:.3g}"
+    assert torch.isfinite(a).all(), what
+    scale = max(1.0, float(b.abs().max())) if b.numel() else 1.0
+    denom = torch.clamp(b.abs(), min=FLOOR_FRAC * scale)
+    ratio = float(((a - b).abs() / denom).max()) if a.numel() else 0.0
+    _record(what, f"element-wise rel (floor {FLOOR_FRAC:g} x scale)", ratio, tol)
+    assert ratio <= tol, f"{what}: max |a-b| / max(|ref|, {FLOOR_FRAC:g} x {scale:.3g}) = {ratio:.3e} > {tol:.1e}"
 
 
 def assert_rel_close(a, b, tol, floor, what):

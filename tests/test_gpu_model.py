@@ -1,10 +1,14 @@
 """GPU parity tests (MI355X): the fused MLP machine and the full render path against the CPU oracle and the
 committed golden fixtures (outputs of the reference itself).
 
-Tolerances.  fp32 mode (v_mfma_f32_32x32x2_f32, exact fp32 products): the north-star's 1e-4, measured as
-max|a-b| <= 1e-4 * max(1, max|ref|) per tensor.  bf16 mode (bf16 operands, fp32 accumulate): 3e-2 on rgb-like
-outputs — bf16 has 8 significand bits and the template stacks 14 layers; its acceptance criterion is PSNR
-(bench.py reports the bf16-vs-fp32 PSNR gap), this test only guards against structural errors."""
+Tolerances (measured worst cases of a GPU run: profiles/r02_parity_errors.json, summarised in DESIGN.md §4).
+fp32 mode (v_mfma_f32_32x32x2_f32, exact fp32 products): the north-star's 1e-4, ELEMENT-wise relative with an absolute
+floor for near-zero elements (gpu_common.assert_close); every forward tensor of every fixture measures <= 2.5e-5 on
+that scale, so there are no per-tensor exceptions.  Gradients: max error <= 5e-3 of the tensor's largest entry
+(measured <= 3.1e-3; the worst are layers fed by sin(2^9 x) features, where two fp32 summation orders of the same sum
+differ).  bf16 mode (bf16 operands, fp32 accumulate): forward 1e-2 (measured <= 4.2e-3), gradients as relative L2 of
+the tensor <= 0.25 on these 40-1000-point batches (measured <= 0.18: a ReLU that flips under bf16 rounding moves one
+summand of a small-batch gradient by O(1)); the acceptance criterion of bf16 mode is PSNR (tools/psnr_parity.py)."""
 import glob
 import math
 import os
@@ -24,7 +28,7 @@ from oracle import hypernerf_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": 1e-4, "bf16": 3e-2}
+TOL = {"fp32": 1e-4, "bf16": 1e-2}
 GTOL = {"fp32": 2e-3, "bf16": 2.5e-1}
 
 
@@ -177,8 +181,7 @@ def test_golden_model_fp32(golden_dir, fixture):
     assert flips == 0, f"{flips} fine-sample indices differ from the reference (tie margin of the fixture is 1e-5)"
     for lvl in ("coarse", "fine"):
         for k in ("points", "warped_points", "rgb", "depth", "med_depth", "acc", "weights", "med_points"):
-            tol = 1e-4 if not (lvl == "fine" and k in ("warped_points",)) else 2e-4
-            assert_close(out[lvl][k], torch.from_numpy(g[f"{lvl}/{k}"]), tol, f"{fixture} {lvl}/{k}")
+            assert_close(out[lvl][k], torch.from_numpy(g[f"{lvl}/{k}"]), 1e-4, f"{fixture} {lvl}/{k}")
     gt = H.uniform(seed, "gt", (b, 3), 0.0, 1.0).to(DEV)
     loss = ((out["coarse"]["rgb"] - gt) ** 2).mean() + ((out["fine"]["rgb"] - gt) ** 2).mean()
     assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-4 * max(1.0, float(g["loss"]))
@@ -213,10 +216,10 @@ def test_model_vs_oracle_larger(case, precision):
         same = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).float().mean().item()
         assert same > 0.999, f"only {same:.4f} of fine-sample indices agree"
         for k in ("rgb", "depth", "acc", "weights"):
-            assert_close(out["fine"][k], ref["fine"][k], 5e-4, f"{case} fine/{k}")
+            assert_close(out["fine"][k], ref["fine"][k], 1e-4, f"{case} fine/{k}")
     loss = ((out["coarse"]["rgb"] - gt.to(DEV)) ** 2).mean() + ((out["fine"]["rgb"] - gt.to(DEV)) ** 2).mean()
     loss.backward()
-    # gradients.  fp32: every tensor to 1e-2 of its largest entry (the <=0.1 % of fine samples that land in a
+    # gradients.  fp32: every tensor to 5e-3 of its largest entry (the <=0.1 % of fine samples that land in a
     # neighbouring pdf bin and sin(2^9 x) features bound what two fp32 summation orders can agree on).
     # bf16: relative L2 error of the WHOLE gradient (<= 0.3: in bf16 mode the fine samples are drawn from bf16 coarse
     # weights, i.e. the fine level is evaluated at slightly different depths than the oracle), and per tensor where
@@ -224,16 +227,16 @@ def test_model_vs_oracle_larger(case, precision):
     named = dict(m.named_parameters())
     if precision == "fp32":
         for k, prm in named.items():
-            assert_grad_close(prm.grad, p[k].grad, 1e-2, f"{case} d {k}")
+            assert_grad_close(prm.grad, p[k].grad, 5e-3, f"{case} d {k}")
     else:
         ks = [k for k in named if p[k].grad is not None]
         ga = torch.cat([named[k].grad.detach().cpu().double().reshape(-1) for k in ks])
         ra = torch.cat([p[k].grad.double().reshape(-1) for k in ks])
         tot = float(ra.norm())
-        assert float((ga - ra).norm()) <= 0.3 * tot, f"{case}: whole-gradient rel L2 {float((ga - ra).norm()) / tot:.3f}"
+        assert float((ga - ra).norm()) <= 0.2 * tot, f"{case}: whole-gradient rel L2 {float((ga - ra).norm()) / tot:.3f}"
         for k in ks:
             if float(p[k].grad.norm()) >= 1e-2 * tot:
-                assert_grad_close(named[k].grad, p[k].grad, 0.5, f"{case} d {k}", frobenius=True)
+                assert_grad_close(named[k].grad, p[k].grad, 0.25, f"{case} d {k}", frobenius=True)
 
 
 LEGACY = {
@@ -278,7 +281,7 @@ def test_golden_legacy_render_rays(golden_dir, name):
     rng = {k: v.to(DEV) for k, v in legacy_rng(g, kw).items()}
     res = legacy_rendering.render_rays([coarse, fine], emb, rays, rng=rng, **kw)
     for k in [k for k in g.files if k.startswith("out/")]:
-        assert_close(res[k[4:]], torch.from_numpy(g[k]), 1e-4 if k.endswith("coarse") else 3e-4, f"{name} {k}")
+        assert_close(res[k[4:]], torch.from_numpy(g[k]), 1e-4, f"{name} {k}")
     if "loss" in g.files:
         b = rays.shape[0]
         gt = H.uniform(seed, "gt", (b, 3), 0.0, 1.0).to(DEV)
@@ -514,7 +517,7 @@ def test_config5_se3_warp_axis_aligned_model_vs_oracle(cond):
         loss = ((out["coarse"]["rgb"] - gt.to(DEV)) ** 2).mean() + ((out["fine"]["rgb"] - gt.to(DEV)) ** 2).mean()
         loss.backward()
         for k, prm in m.named_parameters():
-            assert_grad_close(prm.grad, p[k].grad, 1e-2, f"config5 d {k}")
+            assert_grad_close(prm.grad, p[k].grad, 5e-3, f"config5 d {k}")
     finally:
         HN.set_precision("bf16")
 
@@ -601,7 +604,7 @@ def test_config3_sample_counts_vs_oracle_and_edge_batches():
         same = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).float().mean().item()
         assert same > 0.999, f"only {same:.4f} of fine-sample indices agree"
         for k in ("rgb", "depth", "acc"):
-            assert_close(out["fine"][k], ref["fine"][k], 5e-4, f"config3 fine/{k}")
+            assert_close(out["fine"][k], ref["fine"][k], 1e-4, f"config3 fine/{k}")
         for nb in (2, 33):
             o2, d2, idx2 = rays_for(seed + nb, nb)
             r2 = {"origins": o2.to(DEV), "directions": d2.to(DEV), "viewdirs": None,
@@ -642,10 +645,10 @@ def test_render_opts_filter_sigma_vs_oracle():
         out = m(rays, {}, render_opts=ro, rng={k: v.to(DEV) for k, v in rng.items()})
         for k in ("rgb", "depth", "acc", "weights"):
             assert_close(out["coarse"][k], ref["coarse"][k], 1e-4, f"render_opts coarse/{k}")
-            assert_close(out["fine"][k], ref["fine"][k], 5e-4, f"render_opts fine/{k}")
+            assert_close(out["fine"][k], ref["fine"][k], 1e-4, f"render_opts fine/{k}")
         loss = ((out["coarse"]["rgb"] - gt.to(DEV)) ** 2).mean() + ((out["fine"]["rgb"] - gt.to(DEV)) ** 2).mean()
         loss.backward()
         for k, prm in m.named_parameters():
-            assert_grad_close(prm.grad, p[k].grad, 1e-2, f"render_opts d {k}")
+            assert_grad_close(prm.grad, p[k].grad, 5e-3, f"render_opts d {k}")
     finally:
         HN.set_precision("bf16")

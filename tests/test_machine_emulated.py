@@ -287,3 +287,34 @@ def test_se3_field_program_emulated(bf16):
     _, gtot = prog.grad_offsets()
     flat = E.run_wgrad(prog, mode, jobs, stash, gtot)
     check_grads(prog, flat, tp, dict(f.named_parameters()))
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+def test_legacy_nerf_aux_first_skip_emulated(bf16):
+    """The nerf_pl NeRF (models/nerf.py:83-124) concatenates [input_xyz, h] BEFORE its skip layer: the generated
+    features take the FIRST columns of that matrix and the running activation the ones after.  Small widths;
+    embedded inputs as raw features; forward and every weight gradient."""
+    from hypernerf_torch_amd.models import nerf as legacy_nerf
+    torch.manual_seed(0)
+    m = legacy_nerf.NeRF(D=4, W=64, in_channels_xyz=15, in_channels_dir=9, skips=[2])
+    sd = load_hash(m, 17)
+    n = 40
+    x = H.uniform(11, "x", (n, 24), -1, 1).double()
+    call = m._embedded_call(False)
+    prog = call.program
+    mode = E.Mode(bf16)
+    tables = prog.host_tables(1 if bf16 else 0)
+    params = np_params(prog)
+    srcs = [(x.numpy(), False), None, None, None]
+    outs, stash = E.run_forward(prog, mode, tables, params, srcs, n, 1, [4])
+    tp = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y = O.legacy_nerf(tp, x, d=4, w=64, in_xyz=15, in_dir=9, skips=(2,))
+    np.testing.assert_allclose(outs[0], y.detach().numpy(), rtol=1e-9, atol=1e-11)
+    g = H.uniform(12, "g", (n, 4), -1, 1).double()
+    (y * g).sum().backward()
+    bsrcs = srcs + [(g.numpy(), False), (outs[0], False)]
+    E.run_backward(prog, mode, tables, params, bsrcs, n, 1, stash)
+    jobs = prog.wgrad_jobs(1 if bf16 else 0, n)
+    _, gtot = prog.grad_offsets()
+    flat = E.run_wgrad(prog, mode, jobs, stash, gtot)
+    check_grads(prog, flat, tp, dict(m.named_parameters()))
