@@ -171,9 +171,9 @@ def test_persistent_loop_more_than_1024_tiles(precision):
     y = tf.warp(pts.to(DEV), eg, None)
     (y * gsel.to(DEV)).sum().backward()
     tol, gtol = (1e-4, 2e-3) if precision == "fp32" else (1e-2, 2.5e-1)     # bf16: the bound of test_gpu_model.GTOL
-    assert_close(y, y_ref, tol, f"warp forward, {b * s} points")
+    assert_close(y, y_ref, tol, f"warp forward, {b * s} points", elementwise=precision == "fp32")
     # the LAST tile (served by a workgroup's later iteration) specifically
-    assert_close(y[-64:], y_ref[-64:], tol, "warp forward, last rays")
+    assert_close(y[-64:], y_ref[-64:], tol, "warp forward, last rays", elementwise=precision == "fp32")
     from gpu_common import assert_grad_close
     assert_grad_close(eg.grad, er.grad, gtol, "d embed", frobenius=True)
     for k, prm in tf.named_parameters():

@@ -216,9 +216,9 @@ def test_arena_adam_matches_torch_adam(weight_decay):
         opt.step()
         assert float(arena.grad.abs().max()) == 0.0
         for a, b in zip(p1, p2):
-            assert_close(b, a, 1e-6, f"step {it} parameters")
+            assert_close(b, a, 5e-6, f"step {it} parameters")
     assert float(opt.step_count) == 6.0
     st = ref.state[p1[0]]
     o0, n0 = arena.offsets[0], p1[0].numel()
-    assert_close(opt.exp_avg[o0:o0 + n0].view_as(p1[0]), st["exp_avg"], 1e-6, "exp_avg")
-    assert_close(opt.exp_avg_sq[o0:o0 + n0].view_as(p1[0]), st["exp_avg_sq"], 1e-6, "exp_avg_sq")
+    assert_close(opt.exp_avg[o0:o0 + n0].view_as(p1[0]), st["exp_avg"], 5e-6, "exp_avg")
+    assert_close(opt.exp_avg_sq[o0:o0 + n0].view_as(p1[0]), st["exp_avg_sq"], 5e-6, "exp_avg_sq")
