@@ -108,9 +108,10 @@ def prepare_ray_dict(rays: torch.Tensor) -> dict:
     if len(rays.shape) > 2:
         rays = rays.view(-1, 8)
     b = rays.shape[0]
-    idx = torch.ones((b, 1), dtype=torch.long, device=rays.device)
     if use_meta:
         idx = rays[:, 8].type(torch.long)
+    else:
+        idx = torch.ones((b, 1), dtype=torch.long, device=rays.device)
     metadata = {k: idx for k in ('warp', 'camera', 'appearance', 'time')}     # read-only downstream: one tensor
     return {"origins": rays[:, :3], "directions": rays[:, 3:6], "viewdirs": None, "metadata": metadata}
 

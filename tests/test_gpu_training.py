@@ -253,3 +253,39 @@ def test_train_step_two_ranks_match_one_rank(use_graph):
     ref = ts.arena.grad.cpu()
     err = float((torch.from_numpy(got[0][0]) - ref).norm() / ref.norm())
     assert err <= 1e-5, f"mean of the two shard gradients vs the full-batch gradient: rel L2 {err:.2e}"
+
+
+def test_eval_image_loop_vs_oracle_deterministic(tmp_path):
+    """the per-image loop of eval.py:145-178 — rays generated on the device, the fine level rendered
+    in chunks with deterministic sampling (use_stratified_sampling=False: linspace depths and linspace u,
+    model_utils.py:36-38, 226-227), the 8-bit frame and the PSNR — against the CPU oracle rendering the same image."""
+    from hypernerf_torch_amd.inference import evaluate_images
+    h, w, focal = 6, 8, 7.5
+    m, sd = small_model(61, 16, 16, noise_std=None, precision="fp32")
+    m = m.eval()
+    m.use_stratified_sampling = False
+    c2w = torch.tensor([[1.0, 0.0, 0.0, 0.1], [0.0, 1.0, 0.0, -0.2], [0.0, 0.0, 1.0, 1.5]])
+    cfg = O.ModelCfg(n_samples_coarse=16, n_samples_fine=16, noise_std=None, **KW)
+    samples, refs = [], []
+    for img_id in (3, 7):
+        rays = F.generate_rays(h, w, focal, c2w.to(DEV), near=0.0, far=1.0, ndc=False, image_id=img_id)
+        ref_rays = O.image_rays(h, w, focal, c2w, 0.0, 1.0, False, image_id=img_id)
+        assert_close(rays, ref_rays, 2e-6, "generated rays")
+        o, d = ref_rays[:, 0:3], ref_rays[:, 3:6]
+        idx = torch.full((h * w,), img_id, dtype=torch.int64)
+        u = torch.linspace(0, 1, 16).expand(h * w, -1).contiguous()
+        ref = O.nerf_model_forward({k: v.clone() for k, v in sd.items()}, cfg, o, d, idx, {"t_rand": None, "u": u})
+        gt = (ref["fine"]["rgb"] + 0.02 * H.uniform(61 + img_id, "gt", (h * w, 3), -1, 1)).clamp(0, 1)
+        refs.append((ref["fine"]["rgb"], ref["fine"]["depth"], gt))
+        samples.append({"rays": rays, "rgbs": gt.to(DEV), "hw": (h, w)})
+    res = evaluate_images(m, samples, chunk=20, save_dir=str(tmp_path))
+    assert len(res["images"]) == 2 and res["images"][0].shape == (h, w, 3) and res["images"][0].dtype == torch.uint8
+    for i, (rgb, depth, gt) in enumerate(refs):
+        img8_ref = (rgb.view(h, w, 3) * 255).to(torch.uint8)
+        diff = (res["images"][i].int() - img8_ref.int()).abs()
+        assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 0.02      # truncation at a .0 boundary
+        assert_close(res["depths"][i], depth.view(h, w), 1e-4, f"image {i} depth")
+        psnr_ref = float(-10 * torch.log10(((gt - rgb) ** 2).mean()))
+        assert abs(res["psnrs"][i] - psnr_ref) <= 1e-3, (res["psnrs"][i], psnr_ref)
+        assert os.path.getsize(os.path.join(str(tmp_path), f"{i:03d}.ppm")) == len(f"P6 {w} {h} 255\n") + h * w * 3
+    assert abs(res["mean_psnr"] - sum(res["psnrs"]) / 2) < 1e-12

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hn_version() == 100
+    assert lib.hn_version() == 200
 
 
 def test_abi_struct_sizes_match_c():
