@@ -102,6 +102,59 @@ HN_DEV float hn_direct_source(const HnFeat e, const HnMlpArgs& a, int p, int ray
 HN_DEV float hn_sin_rev(float t) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t)); }
 #define HN_INV_2PI 0.15915494309189535f
 
+// Derived feature table of the bf16 kernels (built in LDS at kernel start from HnFeat): everything a feature needs
+// without decoding its kind — value = idmask ? x : sin_rev(scale * x + phase), x = *(srcv + off):
+//   SIN: scale = f/2pi, phase 0 ; COS / SINP: phase 1/4 ; ZERO: scale = phase = 0 (sin 0 = 0) ; ID: idmask = ~0.
+// d value / dx = idmask ? 1 : 2pi scale * sin_rev(scale * x + phase + 1/4).
+struct HnDFeat { unsigned off; float scale, phase; unsigned idmask; };
+HN_DEV HnDFeat hn_derive_feat(const HnFeat e) {
+  const int kind = (e.packed >> 12) & 15;
+  HnDFeat d;
+  d.off = (unsigned)(e.packed & 255) * 128u;
+  const bool trig = kind == HN_FEAT_SIN || kind == HN_FEAT_COS || kind == HN_FEAT_SINP;
+  d.scale = trig ? e.freq * 0.15915494309189535f : 0.0f;
+  d.phase = (kind == HN_FEAT_COS || kind == HN_FEAT_SINP) ? 0.25f : 0.0f;
+  d.idmask = (kind == HN_FEAT_ID || kind == HN_FEAT_ID_DIRECT) ? 0xffffffffu : 0u;
+  return d;
+}
+HN_DEV float hn_bfi(unsigned m, float a, float b) {     // m ? a : b, bit-wise (one v_bfi_b32)
+  return __uint_as_float((m & __float_as_uint(a)) | (~m & __float_as_uint(b)));
+}
+// values of 4 consecutive table entries for the lane's point: 4 x 16-byte table reads issued together, then the 4
+// source values (addresses from the entries) together, then 5 VALU per feature.  `srcv_r` = the wave's staged
+// components + 4 * point-in-block.
+HN_DEV void hn_features4(const HnDFeat* tp, const char* srcv_r, float* out) {
+  u32x4 t[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t[j] = reinterpret_cast<const u32x4*>(tp)[j];
+  __builtin_amdgcn_sched_barrier(0);
+  float x[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const float*>(srcv_r + t[j][0]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float sv = hn_sin_rev(__builtin_fmaf(__uint_as_float(t[j][1]), x[j], __uint_as_float(t[j][2])));
+    out[j] = hn_bfi(t[j][3], x[j], sv);
+  }
+}
+HN_DEV void hn_feature_grads4(const HnDFeat* tp, const char* srcv_r, float* out) {
+  u32x4 t[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t[j] = reinterpret_cast<const u32x4*>(tp)[j];
+  __builtin_amdgcn_sched_barrier(0);
+  float x[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const float*>(srcv_r + t[j][0]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float sc = __uint_as_float(t[j][1]);
+    const float g = (sc * 6.283185307179586f) * hn_sin_rev(__builtin_fmaf(sc, x[j], __uint_as_float(t[j][2]) + 0.25f));
+    out[j] = hn_bfi(t[j][3], 1.0f, g);
+  }
+}
+
 // bf16 mode evaluates every trigonometric kind with ONE transcendental and no branch:
 //   sin(f x) = sin_rev(f x / 2pi), cos(f x) = sin(f x + pi/2) = sin_rev(f x / 2pi + 1/4)
 // fp32 (parity) mode calls the precise sinf/cosf the reference's CPU path uses.
@@ -147,19 +200,34 @@ HN_DEV float hn_feature_grad(const HnFeat e, const float* srcv, int r) {
 
 // fragments of one group of 64 generated features
 template <bool DIRECT>
-HN_DEV void hn_make_group(bf16x8* out, const HnFeat* ft, const float* srcv, int lane, const HnMlpArgs& a, int p,
-                          int ray) {
+HN_DEV void hn_make_group(bf16x8* out, const HnFeat* ft, const HnDFeat* dft, const float* srcv, int lane,
+                          const HnMlpArgs& a, int p, int ray) {
   const int h = lane >> 5, r = lane & 31;
+  if constexpr (DIRECT) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      out[s][j] = (__bf16)hn_feature<true, DIRECT>(ft[16 * s + hn_pi16(h, j)], srcv, r, a, p, ray);
+      for (int j = 0; j < 8; ++j)
+        out[s][j] = (__bf16)hn_feature<true, true>(ft[16 * s + hn_pi16(h, j)], srcv, r, a, p, ray);
+    }
+  } else {
+    // Batched: the 8 entries of a fragment are two runs of 4 consecutive table entries (pi16); per run two LDS
+    // round trips (entries, then source values) instead of eight (left to itself the compiler waits for every
+    // read before it issues the next: 5.5k cycles per group in the in-kernel trace).
+    const char* srcv_r = reinterpret_cast<const char*>(srcv) + 4 * r;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float v[8];
+      hn_features4(dft + 16 * s + 4 * h, srcv_r, v);
+      hn_features4(dft + 16 * s + 8 + 4 * h, srcv_r, v + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) out[s][j] = (__bf16)v[j];
+    }
   }
 }
 template <bool DIRECT>
-HN_DEV void hn_make_group(float* out, const HnFeat* ft, const float* srcv, int lane, const HnMlpArgs& a, int p,
-                          int ray) {
+HN_DEV void hn_make_group(float* out, const HnFeat* ft, const HnDFeat*, const float* srcv, int lane, const HnMlpArgs& a,
+                          int p, int ray) {
   const int h = lane >> 5, r = lane & 31;
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
@@ -224,10 +292,15 @@ HN_DEV void hn_gemm_k(f32x16& acc, const typename ModeT<BF16>::Frag* in, int K32
 // address of tile 0 of a stash slot for one 32-point block (looked up once per op, outside the tile loops: the slot
 // table sits in the kernel arguments and a lookup is two dependent scalar loads)
 template <bool BF16>
-HN_DEV char* hn_slot_base(const HnMlpArgs& a, int slot, int blk) {
-  if (slot < 0) return nullptr;
-  const HnSlot sl = a.slots[slot];
-  return reinterpret_cast<char*>(a.stash) + sl.off + (size_t)blk * sl.nt * (ModeT<BF16>::TILE_UNITS * 1024);
+HN_DEV char* hn_slot_base(const HnMlpArgs& a, int off_kib, int nt, int blk) {
+  // `off_kib`: the slot's offset for block 0 in KiB, resolved by the host for this launch's point count (the op
+  // word itself: no table lookup — a kernel-argument lookup is two dependent scalar loads per slot and layer)
+  if (off_kib < 0) return nullptr;
+  return reinterpret_cast<char*>(a.stash) + (size_t)(unsigned)off_kib * 1024 + (size_t)blk * nt * (ModeT<BF16>::TILE_UNITS * 1024);
+}
+// mask words of a block: `off256` = the slot's byte offset / 256 (resolved by the host), nt words per lane and block
+HN_DEV uint32_t* hn_mask_base(const HnMlpArgs& a, int off256, int nt, int blk, int lane) {
+  return a.masks + (size_t)(unsigned)off256 * 64 + (size_t)blk * nt * 64 + lane;
 }
 // transpose one tile through the matrix core and store it as tile t of the slot
 template <bool BF16>
@@ -399,9 +472,15 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   // biases and the feature table live in LDS for the whole kernel: no global loads inside the MFMA loops
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * HN_CHUNK_UNITS * 1024);
   HnFeat* feat_lds = reinterpret_cast<HnFeat*>(bias_lds + ((a.n_bias + 3) & ~3));
-  float* srcv = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (a.n_comps * 32);
+  HnDFeat* dfeat_lds = reinterpret_cast<HnDFeat*>(feat_lds + ((a.n_feat + 1) & ~1));      // bf16 kernels only
+  float* srcv = reinterpret_cast<float*>(BF16 ? reinterpret_cast<char*>(dfeat_lds + a.n_feat)
+                                              : reinterpret_cast<char*>(dfeat_lds)) + wave * (a.n_comps * 32);
   for (int i = threadIdx.x; i < a.n_bias; i += blockDim.x) bias_lds[i] = a.bias[i];
-  for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
+  for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) {
+    const HnFeat e = a.feat[i];
+    feat_lds[i] = e;
+    if constexpr (BF16) dfeat_lds[i] = hn_derive_feat(e);
+  }
   __syncthreads();
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -426,13 +505,9 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const float* bias = bias_lds + w[2];
         const bool do_mask = a.training && w[4] >= 0 && wave_valid;
         const bool do_stash = a.training && w[5] >= 0 && wave_valid;
-        char* out_base = do_stash ? hn_slot_base<BF16>(a, w[5], blk) : nullptr;
-        char* aux_base = (a.training && wave_valid) ? hn_slot_base<BF16>(a, w[6], blk) : nullptr;
-        uint32_t* mask_base = nullptr;
-        if (do_mask) {
-          const HnSlot sl = a.slots[w[4]];
-          mask_base = a.masks + sl.off / 4 + (size_t)blk * sl.nt * 64 + lane;
-        }
+        char* out_base = do_stash ? hn_slot_base<BF16>(a, w[5], NT, blk) : nullptr;
+        char* aux_base = (a.training && wave_valid) ? hn_slot_base<BF16>(a, w[6], 2 * nG, blk) : nullptr;
+        uint32_t* mask_base = do_mask ? hn_mask_base(a, w[4], (NT + 1) >> 1, blk, lane) : nullptr;
         const bool has_out = w_next[0] == HN_OP_OUT;    // head layer: its <=4 outputs leave from the accumulator
         const HnOpWords out_w = w_next;
         Frag aux[AUXG * 2 * M::STEPS32];
@@ -440,9 +515,11 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         for (int g = 0; g < AUXG; ++g) {
           if (g < nG) {
             if (flags & HN_LAYER_DIRECT)
-              hn_make_group<true>(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, srcv, lane, a, p, ray);
+              hn_make_group<true>(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, dfeat_lds + w[3] + 64 * g, srcv,
+                                  lane, a, p, ray);
             else
-              hn_make_group<false>(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, srcv, lane, a, p, ray);
+              hn_make_group<false>(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, dfeat_lds + w[3] + 64 * g, srcv,
+                                   lane, a, p, ray);
             if (aux_base != nullptr) {
               hn_stash<BF16>(aux + g * 2 * M::STEPS32, aux_base, 2 * g, lane);
               hn_stash<BF16>(aux + (g * 2 + 1) * M::STEPS32, aux_base, 2 * g + 1, lane);
@@ -574,10 +651,10 @@ HN_DEV bool hn_prefetch_masks(const HnMlpArgs& a, const HnOpWords& wn, int blk, 
                               unsigned* out) {
   if (wn[0] != HN_BOP_LAYER || wn[4] < 0) return false;
   const int NT = (wn[1] >> 16) & 255;
-  const HnSlot sl = a.slots[wn[4]];
+  const uint32_t* mb = hn_mask_base(a, wn[4], (NT + 1) >> 1, blk, lane);
 #pragma unroll
   for (int dd = 0; dd < 4; ++dd)
-    out[dd] = (2 * dd < NT) ? (wave_valid ? a.masks[sl.off / 4 + ((size_t)blk * sl.nt + dd) * 64 + lane] : 0xffffffffu) : 0u;
+    out[dd] = (2 * dd < NT) ? (wave_valid ? mb[dd * 64] : 0xffffffffu) : 0u;
   return true;
 }
 
@@ -595,13 +672,19 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   constexpr int PTS = M::WAVES * 32;
   const int ntiles = (a.n_points + PTS - 1) / PTS;
   HnFeat* feat_lds = reinterpret_cast<HnFeat*>(smem + 2 * HN_CHUNK_UNITS * 1024);
-  float* srcv = reinterpret_cast<float*>(feat_lds + ((a.n_feat + 1) & ~1)) + wave * (a.n_comps * 32);
+  HnDFeat* dfeat_lds = reinterpret_cast<HnDFeat*>(feat_lds + ((a.n_feat + 1) & ~1));      // bf16 kernel only
+  float* srcv = reinterpret_cast<float*>(BF16 ? reinterpret_cast<char*>(dfeat_lds + a.n_feat)
+                                              : reinterpret_cast<char*>(dfeat_lds)) + wave * (a.n_comps * 32);
 #ifdef HN_PROF
   long long* prof_buf = reinterpret_cast<long long*>(a.prof);
   const bool prof_on = prof_buf != nullptr && blockIdx.x == 0 && wave == 0;
   int prof_n = 0;
 #endif
-  for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) feat_lds[i] = a.feat[i];
+  for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) {
+    const HnFeat e = a.feat[i];
+    feat_lds[i] = e;
+    if constexpr (BF16) dfeat_lds[i] = hn_derive_feat(e);
+  }
   __syncthreads();
 
   WStream<M::WAVES> ws;
@@ -678,7 +761,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
           for (int i = 0; i < 4; ++i) tmp[i] = d[i];             // step q, h==0 <-> feature q
         }
-        if (a.training && w[7] >= 0 && wave_valid) hn_stash<BF16>(tmp, hn_slot_base<BF16>(a, w[7], blk), 0, lane);
+        if (a.training && w[7] >= 0 && wave_valid) hn_stash<BF16>(tmp, hn_slot_base<BF16>(a, w[7], 1, blk), 0, lane);
 #pragma unroll
         for (int s = 0; s < M::STEPS32; ++s) {
           if (to2) cur2[s] = tmp[s];
@@ -688,13 +771,12 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const int n = w[3], NT = w[4];
         const HnSrc s = a.src[w[1]];
         unsigned nbits = 0xffffffffu;  // complement of the mask word: set = keep
-        char* dz_base = (a.training && wave_valid) ? hn_slot_base<BF16>(a, w[7], blk) : nullptr;
+        char* dz_base = (a.training && wave_valid) ? hn_slot_base<BF16>(a, w[7], NT, blk) : nullptr;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           if (t < NT) {
             if (w[5] >= 0 && !(t & 1)) {  // output activation was relu: dZ = dY * relu'
-              const HnSlot sl = a.slots[w[5]];
-              nbits = wave_valid ? ~a.masks[sl.off / 4 + ((size_t)blk * sl.nt + (t >> 1)) * 64 + lane] : 0u;
+              nbits = wave_valid ? ~hn_mask_base(a, w[5], (NT + 1) >> 1, blk, lane)[(t >> 1) * 64] : 0u;
             }
             f32x16 v;
 #pragma unroll
@@ -711,7 +793,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const int K32 = w[1] & 255, K32b = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
         const bool has_mask = w[4] >= 0;
         const bool do_stash = a.training && w[5] >= 0 && wave_valid;
-        char* dz_base = do_stash ? hn_slot_base<BF16>(a, w[5], blk) : nullptr;
+        char* dz_base = do_stash ? hn_slot_base<BF16>(a, w[5], NT, blk) : nullptr;
         unsigned nbits = 0xffffffffu;
         unsigned mbits[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // complemented words: set = keep
         if (has_mask) {
@@ -719,11 +801,11 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) mbits[dd] = ~mnext[dd];
           } else {             // all relu masks of the layer up front: one VMEM wait per layer, none per tile
-            const HnSlot sl = a.slots[w[4]];
+            const uint32_t* mb = hn_mask_base(a, w[4], (NT + 1) >> 1, blk, lane);
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd)
               if (2 * dd < NT)
-                mbits[dd] = wave_valid ? ~a.masks[sl.off / 4 + ((size_t)blk * sl.nt + dd) * 64 + lane] : 0u;
+                mbits[dd] = wave_valid ? ~mb[dd * 64] : 0u;
           }
         }
         mnext_ready = false;
@@ -767,8 +849,21 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
           // the host put in the weight stream right behind this tile's weights).  No LDS accumulators: an LDS
           // atomic after an LDS-DMA makes the compiler drain vmcnt, i.e. the weight prefetch.
           const HnFeat* ft = feat_lds + w[3] + 32 * tt;
+          if constexpr (BF16) {
+            // accumulator register i is feature rho(i, h): four runs of 4 consecutive table entries
+            const HnDFeat* dft = dfeat_lds + w[3] + 32 * tt + 4 * h;
+            const char* srcv_r = reinterpret_cast<const char*>(srcv) + 4 * r;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] *= hn_feature_grad<BF16>(ft[hn_rho(i, h)], srcv, r);
+            for (int q4 = 0; q4 < 4; ++q4) {
+              float g[4];
+              hn_feature_grads4(dft + 8 * q4, srcv_r, g);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[4 * q4 + e] *= g[e];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= hn_feature_grad<BF16>(ft[hn_rho(i, h)], srcv, r);
+          }
           Frag gfr[M::STEPS32];
           hn_acc_to_frags(acc, gfr);
           hn_gemm_blocks<BF16, 1>(dacc, gfr, ws);
@@ -1182,7 +1277,8 @@ extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
   hn_allow_big_lds();
   constexpr int WB = ModeT<true>::WAVES;
   const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + (size_t)((a->n_bias + 3) & ~3) * 4 +
-                     (size_t)((a->n_feat + 1) & ~1) * 8 + (size_t)8 * a->n_comps * 32 * 4;
+                     (size_t)((a->n_feat + 1) & ~1) * 8 + (a->mode == HN_MODE_BF16 ? (size_t)a->n_feat * 16 : 0) +
+                     (size_t)8 * a->n_comps * 32 * 4;
   if (lds > 150 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
     if (a->max_groups <= 2)
@@ -1207,7 +1303,7 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
   if (flds > 64 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
     constexpr int WB = ModeT<true>::WAVES;
-    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + (size_t)WB * a->n_comps * 32 * 4;
+    const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + (size_t)a->n_feat * 16 + (size_t)WB * a->n_comps * 32 * 4;
     hipLaunchKernelGGL(hn_mlp_bwd_kernel<true>, dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
                        (hipStream_t)stream, *a);
   } else {

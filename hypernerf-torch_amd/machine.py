@@ -570,6 +570,33 @@ class Program:
                 mask_b += nblk * s.nt * 64 * 4
         return offs, stash_b, mask_b
 
+    def resolved_ops(self, mode: int, n_points: int) -> Tuple[np.ndarray, np.ndarray]:
+        """(forward ops, backward ops) with every slot field replaced by the slot's offset for `n_points` points:
+        stash regions in KiB, mask regions in units of 256 B (include/hn_kernels.h).  The kernels then need no slot
+        table (a kernel-argument lookup costs two dependent scalar loads per slot and layer)."""
+        offs, _, _ = self.layout(mode, n_points)
+
+        def res(slot: int) -> int:
+            if slot < 0:
+                return -1
+            off = offs[slot][0]
+            unit = 1024 if self.slots[slot].kind == "stash" else 256
+            assert off % unit == 0 and off // unit < 2 ** 31
+            return off // unit
+        fwd = self.fwd_ops.copy()
+        for w in fwd:
+            if w[0] == L.HN_OP_LAYER:
+                w[4], w[5], w[6] = res(int(w[4])), res(int(w[5])), res(int(w[6]))
+        bwd = self.bwd_ops.copy()
+        for w in bwd:
+            if w[0] == L.HN_BOP_LOAD:
+                w[7] = res(int(w[7]))
+            elif w[0] == L.HN_BOP_LOAD_WIDE:
+                w[5], w[7] = res(int(w[5])), res(int(w[7]))
+            elif w[0] == L.HN_BOP_LAYER:
+                w[4], w[5] = res(int(w[4])), res(int(w[5]))
+        return fwd, bwd
+
     def grad_offsets(self) -> Tuple[List[int], int]:
         offs, tot = [], 0
         for p in self.params:
@@ -815,10 +842,17 @@ class MlpRunner:
                 continue
             L.require_gpu(t)
             a.dst[i].ptr, a.dst[i].ld = t.data_ptr(), t.stride(-2) if t.dim() > 1 else 1
-        offs, _, _ = self.prog.layout(mode, n_points)
-        for i, (off, nt) in enumerate(offs):
-            a.slots[i].off, a.slots[i].nt = off, nt
         return a
+
+    def _ops(self, device, mode, n_points):
+        """Device copies of the op lists resolved for `n_points` (cached: a model sees a handful of sizes)."""
+        key = ("ops", str(device), mode, n_points)
+        hit = self._jobs.get(key)
+        if hit is None:
+            fwd, bwd = self.prog.resolved_ops(mode, n_points)
+            hit = (L.to_device_bytes(fwd, device), L.to_device_bytes(bwd, device))
+            self._jobs[key] = hit
+        return hit
 
     def forward(self, mode, n_points, samples_per_ray, srcs, dsts, training: bool):
         """Launch the forward machine.  Returns (stash, masks) (None, None when not training)."""
@@ -829,8 +863,8 @@ class MlpRunner:
             _, sb, mb = self.prog.layout(mode, n_points)
             stash = torch.empty(max(sb, 16), dtype=torch.uint8, device=device)
             masks = torch.empty(max(mb, 16), dtype=torch.uint8, device=device)
-        a = self._args(d, mode, n_points, samples_per_ray, training, d.fwd_ops, len(self.prog.fwd_ops),
-                       d.wstream.data_ptr(), d.fwd_chunks, srcs, dsts, stash, masks, None)
+        a = self._args(d, mode, n_points, samples_per_ray, training, self._ops(device, mode, n_points)[0],
+                       len(self.prog.fwd_ops), d.wstream.data_ptr(), d.fwd_chunks, srcs, dsts, stash, masks, None)
         L.launch("hn_mlp_forward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         return stash, masks
 
@@ -853,8 +887,9 @@ class MlpRunner:
             dsrc = torch.empty(n_points, self.prog.n_dsrc, dtype=torch.float32, device=device)
         if embed is not None and samples_per_ray % 32 != 0:
             raise L.HnError("the in-kernel embedding gradient needs samples_per_ray % 32 == 0")
-        a = self._args(d, mode, n_points, samples_per_ray, True, d.bwd_ops, len(self.prog.bwd_ops),
-                       d.wstream.data_ptr() + d.n_fwd_units * 1024, d.bwd_chunks, srcs, [], stash, masks, dsrc, embed)
+        a = self._args(d, mode, n_points, samples_per_ray, True, self._ops(device, mode, n_points)[1],
+                       len(self.prog.bwd_ops), d.wstream.data_ptr() + d.n_fwd_units * 1024, d.bwd_chunks, srcs, [],
+                       stash, masks, dsrc, embed)
         L.launch("hn_mlp_backward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         goffs = tuple(grad_target[1]) if grad_target is not None else None
         deferred = defer and grad_target is not None

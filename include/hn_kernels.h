@@ -55,7 +55,9 @@ typedef void* hnStream_t; /* hipStream_t */
  * aux blocks (a "block" = 32 out x 32 in).  Training: relu bit mask -> mask_slot, transposed
  * activation -> stash_out (X of the next layer's dW), transposed generated features -> stash_aux. */
 #define HN_OP_LAYER 1    /* w1 = K32 | nG<<8 | NT<<16 | act<<24 | flags<<28 ; w2=bias_off w3=feat_off
-                            w4=mask_slot|-1 w5=stash_out|-1 w6=stash_aux|-1                          */
+                            w4=mask|-1 w5=stash_out|-1 w6=stash_aux|-1 — RESOLVED for the launch: the byte offset
+                            of block 0 of that stash region in KiB (masks: in units of 256 B); a region holds, per
+                            32-point block, NT tiles (out), 2*nG tiles (aux) or (NT+1)/2 mask words per lane     */
 #define HN_ACT_NONE 0
 #define HN_ACT_RELU 1
 #define HN_LAYER_NO_COMMIT 1 /* flags bit0: leave cur untouched (head layers read by an OUT op)      */
@@ -76,8 +78,8 @@ typedef void* hnStream_t; /* hipStream_t */
                               w3 bit 9 set: ADD the source-gradient accumulators of slots 8*((w3>>10)&3) + i — the
                               gradient that later ops of this program (earlier in forward order) left for the
                               components this head published (a NULL src then contributes nothing)         */
-#define HN_BOP_LOAD_WIDE 2 /* w1=src  w2=col  w3=n  w4=NT  w5=relu mask slot|-1  w7=stash_slot|-1      */
-#define HN_BOP_LAYER 3     /* w1 = K32 | K32b<<8 | NT<<16 ; w4=mask_slot|-1 w5=stash|-1            */
+#define HN_BOP_LOAD_WIDE 2 /* w1=src  w2=col  w3=n  w4=NT  w5=relu mask|-1  w7=dZ stash|-1 (resolved offsets)   */
+#define HN_BOP_LAYER 3     /* w1 = K32 | K32b<<8 | NT<<16 ; w4=mask|-1 w5=dZ stash|-1 (resolved offsets)   */
 /* gradient w.r.t. GENERATED input features: per 32-feature tile of nG*64 features,
  * tmp = W_aux^T . (cur | cur2), then the chain rule through the feature table into the per-point
  * source-gradient accumulators (LDS), written to `dsrc` at the end of the program.               */
@@ -149,7 +151,8 @@ typedef struct {
   float* dsrc;           /* backward: [P][n_dsrc] source gradients */
   HnSrc src[HN_MAX_SRC]; /* forward: feature sources ; backward: same + gradient inputs */
   HnDst dst[HN_MAX_DST];
-  HnSlot slots[HN_MAX_SLOTS];
+  HnSlot slots[HN_MAX_SLOTS]; /* unused by the kernels since ABI 200 (the op words carry resolved offsets); kept for
+                                 hosts that want to hand the layout along */
   uint64_t* prof;        /* diagnostic only (NULL in production): 8 shader-clock sums, see tools/ */
   const int32_t* comps;  /* device, n_comps entries: src << 16 | column */
   int32_t n_comps;

@@ -366,6 +366,133 @@ __global__ __launch_bounds__((WAVES + LOADERS) * 64, LOADERS ? 3 : (NB == 2 ? 1 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// WS: weights stationary in REGISTERS, activations through an LDS image (design 1).
+// 8 waves, 256 points per workgroup.  Wave w owns the 32-feature output slab w of the layer: its 16 B-operand
+// fragments (64 VGPRs) come straight from L2 (prefetched one layer ahead), the A operand (32 points x 16 features)
+// is read from the image [feature][point] with two ds_read_b64_tr_b16 per MFMA.  D = X . W^T has points on the
+// register axis and features on the lane axis, i.e. the layout of the transposed stash: no transposing MFMAs.
+// The slab's outputs stay packed in registers until every wave has finished reading the image (barrier), then
+// overwrite the image in place (4 ds_write_b64 per tile), barrier, next layer.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+DEV int img_off(int f, int pt) {       // two half images of [256 feature rows][128 points], 16-byte chunks XOR-swizzled
+  const int half = pt >> 7, q = pt & 127;
+  const int sw = ((f & 3) << 2) | ((f >> 2) & 3);
+  return half * 65536 + 256 * f + 16 * ((q >> 3) ^ sw) + 2 * (q & 7);
+}
+struct WsArgs {
+  const char* wstream;   // [L][8 slabs][16 k-steps][64 lanes][8 bf16]
+  const float* bias;
+  char* stash;
+  uint32_t* masks;
+  __bf16* out;
+  int n_points, n_layers;
+};
+template <bool TRAIN>
+__global__ __launch_bounds__(512, 2) void ws_chain(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  float* bias_lds = reinterpret_cast<float*>(smem + 131072);
+  for (int i = threadIdx.x; i < a.n_layers * 256; i += blockDim.x) bias_lds[i] = a.bias[i];
+  const int p_base = blockIdx.x * 256;
+  for (int idx = threadIdx.x; idx < 256 * 128; idx += 512) {      // image of the input: the same hash as the other variants
+    const int pl = idx >> 7, fp = idx & 127;
+    const unsigned p = p_base + pl, f = 2 * fp;
+    unsigned x = p * 2654435761u ^ (f * 40503u + 12345u);
+    x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+    x = (x & 0x807f807fu) | 0x3f003f00u;
+    *reinterpret_cast<unsigned short*>(smem + img_off(f, pl)) = (unsigned short)(x & 0xffff);
+    *reinterpret_cast<unsigned short*>(smem + img_off(f + 1, pl)) = (unsigned short)(x >> 16);
+  }
+  __syncthreads();
+  // per-lane byte offsets of the transposed reads: lane 4q+p of 16-lane group gi -> row (feature) f0+q, points 4p..4p+3
+  const int gi = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int r0 = 16 * (gi & 1), hh = gi >> 1;
+  const int nblk_total = (a.n_points + 31) / 32;
+  u32x4 Wa[16];
+  auto load_w = [&](u32x4* W, int l) {
+    const char* src = a.wstream + (((size_t)l * 8 + wave) * 16) * 1024 + lane * 16;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) W[u] = *reinterpret_cast<const u32x4*>(src + u * 1024);
+  };
+  load_w(Wa, 0);
+  // transposed-read addresses: lane-dependent part per (feature sub-block, row tile & 3); k-step and half image are
+  // immediates / scalar adds
+  int abase[2][4];
+#pragma unroll
+  for (int part = 0; part < 2; ++part)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) abase[part][r4] = img_off(8 * hh + 4 * part + qq, r4 * 32 + r0 + 4 * pp);
+  auto layer = [&](int l, u32x4* W) __attribute__((always_inline)) {
+    const float bias = bias_lds[l * 256 + 32 * wave + c];
+    unsigned out[8][8];
+    unsigned bits = 0;
+    static_for<8>([&](auto RT) __attribute__((always_inline)) {
+      constexpr int rt = decltype(RT)::value;
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = bias;
+      auto read_a = [&](int u) {
+        // features 16u + 8hh + 4*part + qq ; points rt*32 + r0 + 4pp
+        // img_off(16u + f', pt) = img_off(f', pt & 127) + 4096 u + 65536 (pt >> 7): the swizzle only sees f' & 15
+        const int cst = 4096 * u + 65536 * (rt >> 2);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(smem + abase[0][rt & 3] + cst));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(smem + abase[1][rt & 3] + cst));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+      };
+      bf16x8 q[2];
+      q[0] = read_a(0); q[1] = read_a(1);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        acc = mfma(q[u & 1], as_frag(W[u]), acc);
+        if (u + 2 < 16) q[u & 1] = read_a(u + 2);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        if (TRAIN) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(acc[i]), 31);
+        if (TRAIN) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(acc[i + 1]), 31);
+        out[rt][i >> 1] = pack2(__int_as_float(max(__float_as_int(acc[i]), 0)), __int_as_float(max(__float_as_int(acc[i + 1]), 0)));
+      }
+      if (TRAIN) {
+        const int blk = blockIdx.x * 8 + rt;
+        char* dst = a.stash + (((size_t)l * nblk_total + blk) * 8 + wave) * 2048 + lane * 16;
+        __builtin_nontemporal_store((u32x4){out[rt][0], out[rt][1], out[rt][2], out[rt][3]}, reinterpret_cast<u32x4*>(dst));
+        __builtin_nontemporal_store((u32x4){out[rt][4], out[rt][5], out[rt][6], out[rt][7]}, reinterpret_cast<u32x4*>(dst + 1024));
+        if (rt & 1) {
+          a.masks[(((size_t)l * (nblk_total / 2) + blockIdx.x * 4 + (rt >> 1)) * 8 + wave) * 64 + lane] = bits;
+          bits = 0;
+        }
+      }
+    });
+    if (l + 1 < a.n_layers) load_w(W, l + 1);      // lands behind the barriers and the image writes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // every wave has read what it needs of the image
+    static_for<8>([&](auto RT) __attribute__((always_inline)) {
+      constexpr int rt = decltype(RT)::value;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        *reinterpret_cast<u32x2*>(smem + img_off(32 * wave + c, rt * 32 + 8 * g + 4 * h)) = (u32x2){out[rt][2 * g], out[rt][2 * g + 1]};
+      }
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // the next layer's image is complete
+  };
+  for (int l = 0; l < a.n_layers; ++l) layer(l, Wa);
+  for (int idx = threadIdx.x; idx < 256 * 256; idx += 512) {
+    const int pl = idx >> 8, f = idx & 255;
+    if (p_base + pl < a.n_points)
+      a.out[(size_t)(p_base + pl) * 256 + f] = __builtin_bit_cast(__bf16, *reinterpret_cast<unsigned short*>(smem + img_off(f, pl)));
+  }
+}
 // ---------------------------------------------------------------------------------------------------------------
 static float bf16_round(float x) {
   uint32_t u; memcpy(&u, &x, 4);
@@ -426,6 +553,16 @@ int main(int argc, char** argv) {
             const int k = 16 * u + 8 * (j >> 2) + 4 * h + (j & 3);
             packed[((((size_t)l * 8 + t) * 16 + u) * 64 + lane) * 8 + j] = bf16_bits(W[((size_t)l * 256 + 32 * t + r) * 256 + k]);
           }
+  std::vector<uint16_t> packed_ws((size_t)L * 8 * 16 * 512);
+  for (int l = 0; l < L; ++l)
+    for (int sl = 0; sl < 8; ++sl)
+      for (int u = 0; u < 16; ++u)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j)
+            packed_ws[((((size_t)l * 8 + sl) * 16 + u) * 64 + lane) * 8 + j] =
+                bf16_bits(W[((size_t)l * 256 + 32 * sl + (lane & 31)) * 256 + 16 * u + 8 * (lane >> 5) + j]);
+  char* d_wws;
+  CK(hipMalloc(&d_wws, packed_ws.size() * 2)); CK(hipMemcpy(d_wws, packed_ws.data(), packed_ws.size() * 2, hipMemcpyHostToDevice));
   Args a{};
   const int nblk = (P + 31) / 32;
   char* d_w; float* d_b; char* d_s; uint32_t* d_m; __bf16* d_o;
@@ -465,21 +602,36 @@ int main(int argc, char** argv) {
     }
     printf("   check %-28s max|err| = %.4g (max|ref| = %.4g) %s\n", nm, maxerr, maxref, maxerr <= 0.03 * maxref ? "ok" : "MISMATCH");
   };
+  auto run_ws = [&](bool train, std::vector<uint16_t>* oh) {
+    WsArgs w{d_wws, d_b, d_s, d_m, d_o, P, L};
+    auto k = train ? ws_chain<true> : ws_chain<false>;
+    const size_t lds = 131072 + (size_t)L * 256 * 4;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int grid = (P + 255) / 256;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, w);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, w);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    const double flops = 2.0 * P * 256.0 * 256.0 * L;
+    printf("%-34s train=%d  %8.3f ms  %7.1f TFLOP/s  (%.1f %% of 2.5 PF)\n", "WS weights-in-registers", (int)train, ms,
+           flops / ms * 1e-9, flops / ms * 1e-9 / 2500.0 * 100.0);
+    if (oh) { oh->resize((size_t)P * 256); CK(hipMemcpy(oh->data(), d_o, oh->size() * 2, hipMemcpyDeviceToHost)); }
+  };
   std::vector<uint16_t> o0, o1;
   auto same = [&](const char* nm) { size_t diff = 0; for (size_t i = 0; i < o0.size(); ++i) diff += o0[i] != o1[i]; printf("   %s vs base: %zu differing outputs\n", nm, diff); };
   run<1, 8, false, 2, false, 0, 4>("base  ring2 vmcnt0 full", a, reps, &o0); check(o0, "base");
-  for (int rep = 0; rep < 3; ++rep) {
-  run<1, 8, false, 2, false, 0, 4>("base  ring2 vmcnt0 full", a, reps, &o1); same("base");
-  run<1, 8, false, 3, true, 0, 4>("base  ring3 counted full", a, reps, &o1); same("ring3c");
-  run<1, 8, true, 3, true, 0, 4>("pipe  ring3 counted full", a, reps, &o1); same("pipe");
-  run<1, 8, false, 3, true, 0, 4, 32, false, 0, 4>("base  ring3 + 4 LOADER waves", a, reps, &o1); same("loaders");
-  run<1, 8, false, 4, true, 0, 4, 32, false, 0, 4>("base  ring4 + 4 LOADER waves", a, reps, &o1); same("loaders r4");
-  run<1, 8, false, 2, true, 0, 4, 64, false, 0, 4>("base  ring2x64K + 4 LOADER waves", a, reps, &o1); same("loaders 64K");
-  run<1, 8, false, 3, true, 0, 4, 32, false, 0, 2>("base  ring3 + 2 LOADER waves", a, reps, &o1); same("loaders2");
-  run<1, 8, false, 3, true, 0, 1, 32, false, 0, 4>("base  ring3 + 4 LOADERS epi1", a, reps, nullptr);
-  run<1, 8, false, 3, true, 0, 1>("base  ring3 counted epi1", a, reps, nullptr);
-  run<1, 8, false, 3, true, 1, 1>("base  static LDS epi1", a, reps, nullptr);
-  run<1, 8, false, 3, true, 1, 4>("base  static LDS full", a, reps, nullptr);
+  run_ws(true, &o1); check(o1, "WS");
+  { double md = 0; for (size_t i = 0; i < o0.size(); ++i) md = fmax(md, fabs(bf16_to_f(o0[i]) - bf16_to_f(o1[i]))); printf("   WS vs base: max |diff| over all outputs = %.4g\n", md); }
+  for (int rep = 0; rep < 4; ++rep) {
+    run<1, 8, false, 2, false, 0, 4>("base  ring2 vmcnt0 full", a, reps, nullptr);
+    run<1, 8, true, 3, true, 0, 4>("pipe  ring3 counted full", a, reps, nullptr);
+    run_ws(true, nullptr);
+    run<1, 8, false, 2, false, 0, 1>("base  ring2 vmcnt0 epi1", a, reps, nullptr);
+    run<1, 8, true, 3, true, 0, 1>("pipe  ring3 counted epi1", a, reps, nullptr);
+    run_ws(false, nullptr);
   }
   return 0;
 }
