@@ -66,7 +66,6 @@ class NerfModel(nn.Module):
         self.alpha_channels: int = 1
         self.rgb_channels: int = 3
         self.activation = nn.ReLU()
-        self.norm_type: Optional[str] = None
         self.sigma_activation = nn.Softplus()
         self.rgb_activation = nn.Sigmoid()
         if not share_GLO:
@@ -85,13 +84,11 @@ class NerfModel(nn.Module):
         self.hyper_embed_key: str = 'time'
         self.hyper_use_warp_embed: bool = hyper_use_warp_embed
         self.hyper_sheet_mlp_cls: Callable[..., nn.Module] = modules.HyperSheetMLP
-        self.hyper_sheet_use_input_points: bool = True
         self.hyper_sheet_out_dim: int = hyper_slice_out_dim
         self.use_warp: bool = use_warp
         self.warp_field_cls: Callable[..., nn.Module] = warping.TranslationField
         self.warp_embed_cls: Callable[..., nn.Module] = functools.partial(modules.GLOEmbed, embedding_dim=GLO_dim)
         self.warp_embed_key: str = 'time'
-        self.use_original_embed: bool = True
         self.xyz_freq, self.dir_freq, self.hyper_freq = xyz_fourier_dim, view_fourier_dim, hyper_fourier_dim
         self.GLO_dim = GLO_dim
 
