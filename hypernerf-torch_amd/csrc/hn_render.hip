@@ -383,17 +383,43 @@ __global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const float* __restr
   for (int i = lane; i < nb; i += 64) srt[i] = wr[i] + 1e-5f;
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {
-    // fp64 sequential normaliser rounded once; fp64 sequential prefix sum rounded per entry
-    double tot = 0.0;
-    for (int i = 0; i < nb; ++i) tot += (double)srt[i];
+  {
+    // Normaliser = fp64 sum rounded once, cdf = fp64 prefix sums rounded per entry (what the oracle defines; ATen's
+    // fp32 cascade is ISA dependent).  Both run over the whole wave: every term is an fp32 value, and fp64 sums of
+    // <= 255 fp32 values whose magnitudes lie within a factor 2^21 of each other are EXACT (24 + 8 + 21 = 53 bits),
+    // i.e. independent of the summation order — weights + 1e-5 span [1e-5, ~1], a factor 2^17.  (Beyond that range
+    // the result can differ from the sequential sum by one fp64 ulp before the rounding to fp32.)
+    const int per = (nb + 63) >> 6;                 // consecutive entries per lane (<= 4)
+    const int i0 = lane * per;
+    double loc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < per && i0 + k < nb) loc += (double)srt[i0 + k];
+    double tot = loc;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) tot += __shfl_xor(tot, m, 64);
     const float norm = (float)tot;
+    float pdf[4];
     double run = 0.0;
-    cdf[0] = 0.0f;
-    for (int i = 0; i < nb; ++i) {
-      const float pdf = __fdiv_rn(srt[i], norm);
-      run += (double)pdf;
-      cdf[i + 1] = (float)run;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pdf[k] = (k < per && i0 + k < nb) ? __fdiv_rn(srt[i0 + k], norm) : 0.0f;
+      run += (double)pdf[k];
+    }
+    double incl = run;                               // inclusive scan of the lanes' sums
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    double base = incl - run;                        // sum of all earlier lanes' entries (exact, see above)
+    if (lane == 0) cdf[0] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < per && i0 + k < nb) {
+        base += (double)pdf[k];
+        cdf[i0 + k + 1] = (float)base;
+      }
     }
   }
   __builtin_amdgcn_s_waitcnt(0);
@@ -583,13 +609,15 @@ extern "C" int hn_generate_rays(int H, int W, float focal, const float* c2w, int
 // captured in a HIP graph, and the gradient is zeroed on the way out (saves the separate fill of the next step).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hn_adam_kernel(float* p, float* g, float* m, float* v, long long n,
-                                                       const float* __restrict__ hyper, const float* step,
+                                                       const float* __restrict__ hyper, float* step,
                                                        int zero_grad) {
   // hyper-parameters are read from device memory: a captured launch (HIP graph) follows later changes of lr etc.
   const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], weight_decay = hyper[4];
   const float gscale = hyper[5];      // 1 / world size after a SUM all-reduce (1 otherwise)
-  // `step` already holds the number of THIS update (hn_adam_tick runs first on the same stream)
-  const float t = step[0];
+  // step[0] = number of updates done so far; this launch is update t = step[0] + 1.  Every block reads step[0]
+  // before it does anything else; the block that finishes LAST (ticket counter in step[1]) stores t and re-arms the
+  // ticket — by then every block has read the old value, so no second launch is needed to advance the counter.
+  const float t = step[0] + 1.0f;
   const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
   const long long stride = (long long)gridDim.x * blockDim.x * 4;
@@ -618,8 +646,15 @@ __global__ __launch_bounds__(256) void hn_adam_kernel(float* p, float* g, float*
       }
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* ticket = reinterpret_cast<unsigned*>(step) + 1;
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      step[0] = t;
+      *ticket = 0u;
+    }
+  }
 }
-__global__ void hn_adam_tick_kernel(float* step) { step[0] += 1.0f; }
 
 extern "C" int hn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                             const float* hyper_dev, float* step_dev, int zero_grad, hnStream_t stream) {
@@ -628,7 +663,6 @@ extern "C" int hn_adam_step(float* params, float* grads, float* exp_avg, float* 
       hyper_dev == nullptr)
     return -3;
   if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return -4;
-  hipLaunchKernelGGL(hn_adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
   long long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;

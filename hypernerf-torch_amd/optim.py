@@ -31,7 +31,8 @@ class ArenaAdam:
         dev = arena.data.device
         self.exp_avg = torch.zeros_like(arena.data)
         self.exp_avg_sq = torch.zeros_like(arena.data)
-        self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._step_words = torch.zeros(2, dtype=torch.float32, device=dev)      # [updates done, ticket counter]
+        self.step_count = self._step_words[:1]
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self._uploaded = None
         self.sync_hyper()

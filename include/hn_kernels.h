@@ -333,8 +333,9 @@ int hn_mse_loss_backward(const float* coarse, const float* fine, const float* gt
  * (ParamArena): p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), m,v updated first, L2 weight decay added to the
  * gradient.  `hyper_dev`: 8 floats ON THE DEVICE, [lr, beta1, beta2, eps, weight_decay, grad_scale, 0, 0] — read by the
  * kernel, so a launch captured in a HIP graph follows a learning-rate schedule (utils/__init__.py:43-46) without
- * re-capture; grad_scale multiplies the gradient first (1/world after a SUM all-reduce).  `step_dev`: one float on
- * the device holding the number of updates done so far; it is incremented on the stream before the update.
+ * re-capture; grad_scale multiplies the gradient first (1/world after a SUM all-reduce).  `step_dev`: TWO 4-byte words
+ * on the device, [0] = number of updates done so far as a float (advanced by the launch itself: the last block to
+ * finish stores it), [1] = a ticket counter the launch leaves at zero.
  * zero_grad != 0 clears `grads` in the same pass.  Buffers 16-byte aligned. */
 int hn_adam_step(float* params_dev, float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, long long n,
                  const float* hyper_dev, float* step_dev, int zero_grad, hnStream_t stream);

@@ -323,6 +323,50 @@ def test_config2_full_size_properties():
         assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
 
 
+def test_config2_full_size_fp32_vs_oracle():
+    """BASELINE config 2 at its FULL size (1024 rays x (64+64) = 196,608 evaluated points, the fused level programs,
+    the in-kernel embedding gradient path with 32-point blocks inside one ray) in fp32 mode against the CPU oracle:
+    forward tensors element-wise to 1e-4, loss, and the gradient of the GLO table (every point of the batch
+    contributes to it through all three networks)."""
+    HN.set_precision("fp32")
+    try:
+        kw = CASES["bendy_cond"]
+        b, nc, nf, seed = 1024, 64, 64, 83
+        m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=1.0, view_fourier_dim=6, **kw)
+        sd = load_hash(m, seed)
+        m = m.to(DEV)
+        o, d, idx = rays_for(seed, b)
+        rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1),
+               "noise_coarse": H.normal(seed, "n1", (b, nc, 1)), "noise_fine": H.normal(seed, "n2", (b, nc + nf, 1))}
+        cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=1.0, view_fourier_dim=6, **kw)
+        torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+        p = {k: v.clone().requires_grad_(k == "warp_embed.embed.weight") for k, v in sd.items()}
+        ref = O.nerf_model_forward(p, cfg, o, d, idx, rng)
+        gt = H.uniform(seed, "gt", (b, 3), 0, 1)
+        ref_loss = O.mse_loss(ref, gt)
+        ref_loss.backward()
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        out = m(rays, {}, rng={k: v.to(DEV) for k, v in rng.items()})
+        for k in ("rgb", "depth", "acc", "weights", "warped_points"):
+            assert_close(out["coarse"][k], ref["coarse"][k], 1e-4, f"config2 full size coarse/{k}")
+        same = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).float().mean().item()
+        assert same > 0.9995, f"only {same:.5f} of the 65,536 fine-sample indices agree"
+        # a fine sample that lands in the neighbouring pdf bin changes that ray's fine render: compare the rays whose
+        # indices all agree (> 97 % of them)
+        ok = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).all(dim=1)
+        assert float(ok.float().mean()) > 0.97
+        for k in ("rgb", "depth", "acc"):
+            assert_close(out["fine"][k][ok.to(DEV)], ref["fine"][k][ok], 1e-4, f"config2 full size fine/{k}")
+        from hypernerf_torch_amd import losses
+        loss = losses.MSELoss()(out, gt.to(DEV))
+        assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-5 * max(1.0, float(ref_loss.detach()))
+        loss.backward()
+        assert_grad_close(m.warp_embed.embed.weight.grad, p["warp_embed.embed.weight"].grad, 5e-3, "config2 d GLO table")
+    finally:
+        HN.set_precision("bf16")
+
+
 @pytest.mark.gpu
 def test_param_arena_gradients_match_autograd_path():
     """The same step with parameters attached to a ParamArena (dW accumulated straight into the flat gradient
