@@ -13,6 +13,7 @@ The K timed steps are repeated `--repeats` times back to back (each repeat brack
 `value` comes from the MEDIAN repeat, `ms_per_step_repeats` lists all of them.  Prints ONE JSON line (rank 0).
 """
 import argparse
+import ctypes
 import json
 import os
 import statistics
@@ -52,6 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel code path (process group + all-reduce between two graphs) even with one rank")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     for k in ("rays", "nc", "nf", "precision"):
@@ -135,8 +138,12 @@ def main():
     # aid only: it runs the N>1 code path (graph capture, gradient all-reduce, Adam) on a single-GPU box.
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    if world > 1:
+    # --force-dp: take the N>1 code path (process group, two graphs around the gradient all-reduce) with ONE rank: a
+    # 1-GPU box can then exercise RCCL initialisation next to HIP graphs and price the split of the step graph
+    dp = world > 1 or a.force_dp
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(os.environ.get("HN_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local)
 
@@ -150,7 +157,7 @@ def main():
     # parameters and gradients live in one flat arena each: the kernels accumulate dW straight into it, Adam steps
     # one tensor, and data parallelism SUM-all-reduces the gradient buffer in place (the 1/N sits in the Adam kernel).
     arena = HN.ParamArena(params)
-    if world > 1:
+    if dp:
         dist.broadcast(arena.data, src=0)
     opt = HN.ArenaAdam(arena, lr=5e-4, eps=1e-8, zero_grad=True, grad_scale=1.0 / world)
 
@@ -161,7 +168,7 @@ def main():
 
     if use_graph:
         from hypernerf_torch_amd.graphs import GraphedStep
-        if world == 1:
+        if not dp:
             step = GraphedStep(whole_step, warmup=3)
         else:
             # two graphs around the one collective: forward+backward | all-reduce of the gradient buffer | Adam
@@ -177,13 +184,13 @@ def main():
     else:
         def step():
             out, loss = fwd_bwd()
-            if world > 1:
+            if dp:
                 arena.all_reduce_sum()
             opt.step()
             return out, loss
 
     def barrier():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,13 +204,13 @@ def main():
             out, loss = step()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dp:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         reps.append(dt)
     ranks_seen = world
-    if world > 1:
+    if dp:
         all_gather_pixels(out['fine']['rgb'].detach())     # eval-style pixel assembly works on this topology
         cnt = torch.ones(1, device=dev)
         dist.all_reduce(cnt)
@@ -219,7 +226,7 @@ def main():
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.precision, "data": "synthetic",
         "config": {"workload": workload, "baseline_config": a.config, "rays_per_gpu": b, "n_samples": a.nc,
-                   "n_importance": a.nf, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                   "n_importance": a.nf, "parallelism": f"dp{world}", "hip_graph": use_graph, "dp_code_path": dp,
                    "ranks_seen_by_collective": ranks_seen},
         "per_gpu": value / world, "final_loss": float(loss.detach()),
         "repeats": len(reps), "ms_per_step_repeats": [1e3 * r / a.steps for r in reps],
@@ -230,10 +237,14 @@ def main():
         res.update(roofline(a, L, fwd_bwd, opt, programs(), dt / a.steps, b))
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.kind == "hypernerf":
         res["cpu_baseline"] = cpu_baseline(a)
-    if rank == 0:
-        print(json.dumps(res))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: RCCL writes a "Librccl path" banner through C stdio, which would
+    # otherwise be flushed at exit, after the line
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
 
 
 def roofline(a, L, fwd_bwd, opt, progs, step_s, b):

@@ -92,7 +92,7 @@ DWJOB_DT = np.dtype([("z_off", "<u8"), ("x_off", "<u8"), ("z_nt", "<i4"), ("x_nt
                      ("c_end", "<i4"), ("b_off", "<i4"), ("pad", "<i4")])
 
 EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
-           "hn_mlp_wgrad_batched",
+           "hn_mlp_wgrad_batched", "hn_mlp_workspace_bytes",
            "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf",
            "hn_embed_gather", "hn_embed_backward", "hn_se3_apply_forward", "hn_se3_apply_backward", "hn_generate_rays", "hn_adam_step",
            "hn_mse_loss_forward", "hn_mse_loss_backward",

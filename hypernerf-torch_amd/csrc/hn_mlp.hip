@@ -1,6 +1,7 @@
 // MLP machine for gfx950: weight packing, fused forward, fused backward-data, weight gradient.
 // See include/hn_kernels.h for the program format and hn_common.h for the register layouts.
 #include "hn_common.h"
+#include <algorithm>
 
 // Diagnostic build only (-DHN_PROF): wave 0 of workgroup 0 logs (code, shader clock) pairs into HnMlpArgs.prof.
 #ifdef HN_PROF
@@ -1268,6 +1269,53 @@ static int hn_check_args(const HnMlpArgs* a) {
   if (a->n_bias < 0 || a->n_feat < 0 || a->n_comps < 0 || a->n_comps > HN_MAX_COMPS) return -5;
   if (a->max_groups < 0 || a->max_groups > 3) return -5;
   if (a->n_comps > 0 && a->comps == nullptr) return -3;
+  return 0;
+}
+
+// Host-only: the extent of `stash` and `masks` an op program touches for n_points points (the kernels do no
+// bounds checks of their own; a host that did not compile the program itself sizes its buffers with this).
+extern "C" int hn_mlp_workspace_bytes(const int32_t* ops_host, int n_ops, int backward, int mode, int64_t n_points,
+                                      int64_t* stash_bytes, int64_t* mask_bytes) {
+  if (ops_host == nullptr || stash_bytes == nullptr || mask_bytes == nullptr) return -1;
+  if (n_ops <= 0 || n_points <= 0) return -2;
+  if (mode != HN_MODE_BF16 && mode != HN_MODE_F32) return -4;
+  const int64_t nblk = (n_points + 31) / 32;
+  const int64_t tile = (mode == HN_MODE_BF16 ? ModeT<true>::TILE_UNITS : ModeT<false>::TILE_UNITS) * 1024;
+  int64_t sb = 0, mb = 0;
+  auto stash = [&](int off_kib, int nt) {
+    if (off_kib >= 0) sb = std::max<int64_t>(sb, (int64_t)(unsigned)off_kib * 1024 + nblk * nt * tile);
+  };
+  auto mask = [&](int off256, int nt_tiles) {
+    if (off256 >= 0) mb = std::max<int64_t>(mb, (int64_t)(unsigned)off256 * 256 + nblk * ((nt_tiles + 1) >> 1) * 256);
+  };
+  for (int i = 0; i < n_ops; ++i) {
+    const int32_t* w = ops_host + (size_t)i * HN_OP_WORDS;
+    if (!backward) {
+      if (w[0] == HN_OP_LAYER) {
+        const int nG = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
+        mask(w[4], NT);
+        stash(w[5], NT);
+        stash(w[6], 2 * nG);
+      } else if (w[0] != HN_OP_OUT && w[0] != HN_OP_OUT_WIDE) {
+        return -7;
+      }
+    } else {
+      if (w[0] == HN_BOP_LOAD) {
+        stash(w[7], 1);
+      } else if (w[0] == HN_BOP_LOAD_WIDE) {
+        mask(w[5], w[4]);
+        stash(w[7], w[4]);
+      } else if (w[0] == HN_BOP_LAYER) {
+        const int NT = (w[1] >> 16) & 255;
+        mask(w[4], NT);
+        stash(w[5], NT);
+      } else if (w[0] != HN_BOP_AUX) {
+        return -7;
+      }
+    }
+  }
+  *stash_bytes = sb;
+  *mask_bytes = mb;
   return 0;
 }
 

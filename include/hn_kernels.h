@@ -216,6 +216,13 @@ int hn_pack_units(int mode, const HnPackUnit* units_dev, int n_units, const floa
 
 int hn_mlp_forward(const HnMlpArgs* args, hnStream_t stream);
 int hn_mlp_backward(const HnMlpArgs* args, hnStream_t stream);
+/* Workspace query (host arithmetic only, no GPU needed): bytes of `stash` and of `masks` that the forward
+ * (backward = 0) or backward (= 1) op program `ops_host` (HOST copy of HnMlpArgs.ops) touches for n_points
+ * points in a training launch.  A stash is shared by a program's forward, backward and weight-gradient launches:
+ * allocate the maximum of the two queries.  In the reference this is torch's autograd saving activations
+ * (every nn.Linear / ReLU of hypernerf/modules.py:116-127). */
+int hn_mlp_workspace_bytes(const int32_t* ops_host, int n_ops, int backward, int mode, int64_t n_points,
+                           int64_t* stash_bytes, int64_t* mask_bytes);
 
 /* dW/db for every Linear of a program: grads (fp32) are ACCUMULATED with float atomics. */
 int hn_mlp_wgrad(int mode, const HnDwJob* jobs_dev, int n_jobs, const void* stash_dev,

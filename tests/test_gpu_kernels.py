@@ -141,6 +141,29 @@ def test_golden_g10(golden_dir):
     np.testing.assert_allclose(pts.cpu().numpy(), g["pts"], rtol=1e-6, atol=1e-6)
 
 
+def test_legacy_sample_pdf_wrapper(golden_dir):
+    """`models.rendering.sample_pdf(bins, weights, N_importance, det, eps)` — the nerf_pl wrapper itself
+    (models/rendering.py:14-55): explicit `u` against the reference's samples of g10, the deterministic branch
+    (u = linspace(0, 1, N)) against the fixture's `z_samples_det` and the oracle, the random branch by its range and
+    sortedness per bin, and the unsupported `eps`."""
+    from hypernerf_torch_amd.models import rendering as R
+    g = np.load(os.path.join(golden_dir, "g10_pdf.npz"))
+    T = lambda k: torch.from_numpy(g[k]).to(DEV)
+    zs = R.sample_pdf(T("bins"), T("w"), 16, u=T("u"))
+    np.testing.assert_allclose(zs.cpu().numpy(), g["z_samples"], rtol=1e-6, atol=1e-6)
+    zd = R.sample_pdf(T("bins"), T("w"), 16, det=True)
+    np.testing.assert_allclose(zd.cpu().numpy(), g["z_samples_det"], rtol=1e-6, atol=1e-6)
+    u_det = torch.linspace(0, 1, 16).expand(8, 16).contiguous()
+    zo, _ = O.piecewise_constant_pdf(torch.from_numpy(g["bins"]), torch.from_numpy(g["w"]), u_det)
+    assert torch.equal(zd.cpu(), zo)
+    torch.manual_seed(5)
+    zr = R.sample_pdf(T("bins"), T("w"), 64)
+    assert zr.shape == (8, 64)
+    assert bool((zr >= T("bins")[:, :1]).all()) and bool((zr <= T("bins")[:, -1:]).all())
+    with pytest.raises(NotImplementedError):
+        R.sample_pdf(T("bins"), T("w"), 16, eps=1e-3)
+
+
 def test_embed_and_posenc():
     tab = H.uniform(9, "tab", (100, 8), -1, 1)
     idx = torch.from_numpy((H.uniform01(9, "i", 57) * 100).astype(np.int64))

@@ -53,6 +53,37 @@ def test_argument_errors_are_reported_not_crashes():
     assert lib.hn_sample_pdf(None, 0, None, 0, None, 0, None, None, None, 0, 0, 0, None, None, None, None, None) < 0
 
 
+def test_workspace_query_matches_the_host_compiler():
+    """hn_mlp_workspace_bytes (host arithmetic in the C library) against the layout the Python program compiler
+    allocates: every slot is written by the forward or the backward program, so the larger of the two queries is
+    exactly the allocation, in both modes and for ragged point counts."""
+    lib = L.load()
+    m = models.NerfModel(EMB, n_samples_coarse=8, n_samples_fine=8, hyper_slice_method="bendy_sheet",
+                         use_nerf_embed=True, use_alpha_cond=True)
+    progs = [m._level_call("fine").program, warping.SE3Field(in_ch=3)._field_call(True).program,
+             legacy_nerf.NeRF().fused_call(legacy_nerf.Embedding(3, 10), legacy_nerf.Embedding(3, 4), False).program]
+    for prog in progs:
+        for mode in (L.HN_MODE_BF16, L.HN_MODE_F32):
+            for n in (1, 32, 1000, 196608):
+                fwd, bwd = prog.resolved_ops(mode, n)
+                _, sb, mb = prog.layout(mode, n)
+                got = []
+                for back, ops in ((0, fwd), (1, bwd)):
+                    ops = np.ascontiguousarray(ops, dtype=np.int32)
+                    s_out, m_out = ctypes.c_int64(-1), ctypes.c_int64(-1)
+                    rc = lib.hn_mlp_workspace_bytes(ops.ctypes.data_as(ctypes.c_void_p), len(ops), back, mode,
+                                                    ctypes.c_int64(n), ctypes.byref(s_out), ctypes.byref(m_out))
+                    assert rc == 0
+                    assert 0 <= s_out.value <= sb and 0 <= m_out.value <= mb
+                    got.append((s_out.value, m_out.value))
+                assert max(g[0] for g in got) == sb and max(g[1] for g in got) == mb, (prog.name, mode, n, got, sb, mb)
+    bad = np.zeros((1, 8), dtype=np.int32); bad[0, 0] = 99
+    s_out, m_out = ctypes.c_int64(), ctypes.c_int64()
+    assert lib.hn_mlp_workspace_bytes(bad.ctypes.data_as(ctypes.c_void_p), 1, 0, L.HN_MODE_BF16, ctypes.c_int64(32),
+                                      ctypes.byref(s_out), ctypes.byref(m_out)) == -7
+    assert lib.hn_mlp_workspace_bytes(None, 1, 0, L.HN_MODE_BF16, ctypes.c_int64(32), None, None) == -1
+
+
 CASES = {
     "bendy": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=False, use_alpha_cond=False),
     "bendy_cond": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True),
