@@ -42,12 +42,16 @@ class ProgramCall:
 
     def __init__(self, program: Program, src_per_ray: Sequence[bool], dst_widths: Sequence[int],
                  grad_srcs: Sequence[Tuple[str, int]], gather_src: Optional[int] = None,
-                 bwd_src_from_out: Optional[Dict[int, int]] = None):
+                 bwd_src_from_out: Optional[Dict[int, int]] = None,
+                 fill_from_gather: Optional[Tuple[int, int]] = None):
         # grad_srcs[i] describes backward source 4+i: ('g', k) = gradient of output k (zeros if autograd has none),
         # ('go', k) = the same but simply absent when autograd has none, ('y', k) = output k
         # gather_src: index of a per-ray source given as (table, ray indices): the kernels read table[idx[ray]]
         # bwd_src_from_out: {source index: output index} — sources the forward publishes itself (no pointer) and
         # the backward reads back from the forward's output tensor (fused level programs)
+        # fill_from_gather: (output index, first column) — after the launch the gathered rows table[idx[ray]] are
+        # copied into those columns of every point of the ray (axis-aligned hyper coordinates as part of
+        # `warped_points`, models.py:533-534; a pure copy, no gradient flows back through these columns)
         self.program = program
         self.runner = MlpRunner(program)
         self.src_per_ray = list(src_per_ray)
@@ -55,6 +59,7 @@ class ProgramCall:
         self.grad_srcs = list(grad_srcs)
         self.gather_src = gather_src
         self.bwd_src_from_out = dict(bwd_src_from_out or {})
+        self.fill_from_gather = fill_from_gather
         self.cache = {}
 
 
@@ -89,6 +94,11 @@ class _ProgramFn(torch.autograd.Function):
             raise L.HnError("a program needs at least one per-point source")
         outs = [torch.empty(n_points, w, dtype=torch.float32, device=device) for w in call.dst_widths]
         stash, masks = call.runner.forward(mode, n_points, samples_per_ray, flat_srcs, outs, training)
+        if call.fill_from_gather is not None:
+            k, c0 = call.fill_from_gather
+            table, _, gidx = flat_srcs[call.gather_src]
+            rows = table.index_select(0, gidx.clamp(0, table.shape[0] - 1))
+            outs[k].view(-1, samples_per_ray, outs[k].shape[1])[:, :, c0:c0 + table.shape[1]] = rows[:, None, :]
         ctx.call, ctx.mode, ctx.spr, ctx.n_src, ctx.n_points = call, mode, samples_per_ray, n_src, n_points
         ctx.flat_srcs = flat_srcs
         ctx.tables = {call.gather_src: srcs[call.gather_src]} if call.gather_src is not None else {}

@@ -223,6 +223,52 @@ class NerfModel(nn.Module):
             self._template_calls[key] = call
         return call
 
+    def _gather_table(self, use_warp: bool):
+        """(GLOEmbed module, metadata key) when every embedding the TEMPLATE stage of a level consumes — the alpha /
+        rgb conditions (models.py:425-436) and axis-aligned hyper coordinates (models.py:533-534) — is a row of ONE
+        table looked up with ONE index; None otherwise (or when the stage consumes no embedding at all)."""
+        need = []
+        if self.use_nerf_embed:
+            need.append((self.warp_embed, self.warp_embed_key) if self.hyper_use_warp_embed
+                        else (self.nerf_embed, self.nerf_embed_key))
+        if use_warp and self.hyper_slice_method == 'axis_aligned_plane':
+            need.append((self.warp_embed, self.warp_embed_key) if self.hyper_use_warp_embed
+                        else (self.hyper_embed, self.hyper_embed_key))
+        if not need or any(n[0] is not need[0][0] or n[1] != need[0][1] for n in need):
+            return None
+        return need[0]
+
+    def _template_gather_call(self, level: str, hyper_from_table: bool, xyz_grad: bool) -> F.ProgramCall:
+        """query_template (models.py:447-493) for levels whose warp runs outside the program (SE3Field, or no warp at
+        all): sources 0 = spatial points (P,3), 1 = viewdirs (B,3), 2 = the GLO table, gathered with the ray's index
+        by the kernels — conditions and, for the axis-aligned slice, the hyper coordinates are read from the row, and
+        the row's gradient is reduced and scattered by the backward machine."""
+        key = ("tgather", level, hyper_from_table, xyz_grad)
+        call = self._template_calls.get(key)
+        if call is None:
+            m = self.nerf_mlps_fine if level == 'fine' else self.nerf_mlps_coarse
+            G = self.GLO_dim
+            feats = posenc_features(0, range(3), self.xyz_freq, xyz_grad)
+            if hyper_from_table:
+                feats += posenc_features(2, range(G), self.hyper_freq, True)
+            if len(feats) != m.in_ch:
+                raise RuntimeError(f"template input has {len(feats)} channels, the MLP expects {m.in_ch} "
+                                   "(the reference shape-errors the same way, e.g. axis_aligned_plane needs "
+                                   "hyper_slice_out_dim == GLO_dim)")
+            rgb_feats = posenc_features(1, range(3), self.dir_freq, False) if self.use_viewdirs else []
+            alpha_aux = None
+            if self.use_nerf_embed:
+                if self.use_alpha_condition:
+                    alpha_aux = AuxSpec(copy_features(2, range(G), True))
+                if self.use_rgb_condition:
+                    rgb_feats += copy_features(2, range(G), True)
+            layers = modules.nerf_mlp_layers(m, f"nerf_mlps_{level}", AuxSpec(feats), alpha_aux,
+                                             AuxSpec(rgb_feats) if rgb_feats else None)
+            call = F.ProgramCall(Program(layers, name=f"template_{level}"), [False, True, True], [3, 1],
+                                 [("g", 0), ("g", 1), ("y", 0)], gather_src=2)
+            self._template_calls[key] = call
+        return call
+
     # ---- fused level program -------------------------------------------------------------------
     FUSE_LEVELS = True      # warp field -> hyper sheet -> template as ONE launch per level where the model allows it
 
@@ -234,15 +280,15 @@ class NerfModel(nn.Module):
             return False
         if not isinstance(self.warp_field, warping.TranslationField):
             return False
-        if self.hyper_slice_method not in ('bendy_sheet', 'none'):
+        if self.hyper_slice_method not in ('bendy_sheet', 'none', 'axis_aligned_plane'):
             return False
-        if self.hyper_slice_method == 'bendy_sheet' and not self.hyper_use_warp_embed:
+        if self.hyper_slice_method != 'none' and not self.hyper_use_warp_embed:
             return False
         if self.use_nerf_embed and not self.hyper_use_warp_embed:
             return False
         if metadata.get('hyper_point') is not None:
             return False
-        return self.hyper_sheet_out_dim <= 4 or self.hyper_slice_method == 'none'
+        return self.hyper_sheet_out_dim <= 4 or self.hyper_slice_method != 'bendy_sheet'
 
     def _level_call(self, level: str) -> F.ProgramCall:
         """The whole level as one program of the MLP machine (reference: map_points models.py:545-581 followed by
@@ -266,10 +312,19 @@ class NerfModel(nn.Module):
                 layers += modules.mlp_layers(hs.mlp, "hyper_sheet_mlp.mlp", hs.input_aux(0, 2, False, True), None,
                                              OutSpec(0, 3, "none", publish=(3, 3)), GradIn(7, 3, from_dsrc=(3, 3)))
             feats = posenc_features(3, range(3), self.xyz_freq, True)
+            fill = None
             if h:
                 feats += posenc_features(3, range(3, 3 + h), self.hyper_freq, True)
+            elif self.hyper_slice_method == 'axis_aligned_plane':
+                # hyper coordinates = the ray's GLO row itself (models.py:533-534): encoded from the gathered source;
+                # the kernel does not copy them into `warped_points`, run_program fills those columns
+                h = G
+                feats += posenc_features(2, range(G), self.hyper_freq, True)
+                fill = (0, 3)
             if len(feats) != m.in_ch:
-                raise RuntimeError(f"template input has {len(feats)} channels, the MLP expects {m.in_ch}")
+                raise RuntimeError(f"template input has {len(feats)} channels, the MLP expects {m.in_ch} (the "
+                                   "reference shape-errors the same way, e.g. axis_aligned_plane needs "
+                                   "hyper_slice_out_dim == GLO_dim)")
             rgb_feats = posenc_features(1, range(3), self.dir_freq, False) if self.use_viewdirs else []
             alpha_aux = None
             if self.use_nerf_embed:
@@ -280,7 +335,8 @@ class NerfModel(nn.Module):
             layers += modules.nerf_mlp_layers(m, f"nerf_mlps_{level}", AuxSpec(feats), alpha_aux,
                                               AuxSpec(rgb_feats) if rgb_feats else None, dst_rgb=1, dst_alpha=2)
             call = F.ProgramCall(Program(layers, name=f"level_{level}"), [False, True, True, False], [3 + h, 3, 1],
-                                 [("g", 1), ("g", 2), ("y", 1), ("go", 0)], gather_src=2, bwd_src_from_out={3: 0})
+                                 [("g", 1), ("g", 2), ("y", 1), ("go", 0)], gather_src=2, bwd_src_from_out={3: 0},
+                                 fill_from_gather=fill)
             self._template_calls[key] = call
         return call
 
@@ -295,7 +351,8 @@ class NerfModel(nn.Module):
                 out.append((f"level_{key[1]}", call.program, n_rays * (nc if key[1] == 'coarse' else nc + nf)))
                 fused = True
             else:
-                out.append((f"template_{key[0]}", call.program, n_rays * (nc if key[0] == 'coarse' else nc + nf)))
+                lvl = key[1] if key[0] == "tgather" else key[0]
+                out.append((f"template_{lvl}", call.program, n_rays * (nc if lvl == 'coarse' else nc + nf)))
         if fused:
             return [o for o in out if o[0].startswith("level_")]
         both = n_rays * (2 * nc + nf)
@@ -362,6 +419,37 @@ class NerfModel(nn.Module):
                                                       self.warp_embed.embed.weight, None], s, self.precision,
                                                gather_idx=idx)
             warped = warped.view(b, s, -1)
+            return self._composite_level(out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity,
+                                         dust, keep, b, s, points.device)
+        tab = None
+        if (self.FUSE_LEVELS and not metadata_encoded and metadata.get('hyper_point') is None
+                and not return_warp_jacobian and not (use_warp and self.hyper_slice_method == 'bendy_sheet')):
+            tab = self._gather_table(use_warp)
+        if tab is not None:
+            # the warp (if any) runs as its own program; the template reads conditions / axis-aligned hyper
+            # coordinates straight from the GLO table (no gather kernel, no (B,S,H) expand + cat in front of it, the
+            # row gradient reduced in the backward machine)
+            emb_mod, key = tab
+            idx = metadata[key]
+            if idx.shape[-1] == 1 and idx.dim() > 1:
+                idx = idx.squeeze(-1)
+            if use_warp:
+                needs_rows = isinstance(self.warp_field, warping.TranslationField)
+                xyz = self.warp_field.warp(points, self.warp_embed(metadata[self.warp_embed_key]) if needs_rows else None,
+                                           extra_params)
+            else:
+                xyz = points
+            from_table = use_warp and self.hyper_slice_method == 'axis_aligned_plane'
+            ge = torch.is_grad_enabled() and xyz.requires_grad
+            call = self._template_gather_call(level, from_table, ge)
+            rgb, alpha = F.run_program(call, [xyz.reshape(b * s, 3), viewdirs if self.use_viewdirs else None,
+                                              emb_mod.embed.weight], s, self.precision, gather_idx=idx)
+            if from_table:
+                with torch.no_grad():
+                    rows = emb_mod.embed.weight.index_select(0, idx.reshape(-1).clamp(0, emb_mod.embed.weight.shape[0] - 1))
+                warped = torch.cat([xyz, rows[:, None, :].expand(b, s, rows.shape[-1])], dim=-1)
+            else:
+                warped = xyz
             return self._composite_level(out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity,
                                          dust, keep, b, s, points.device)
         if use_warp:

@@ -294,6 +294,75 @@ def test_bf16_mode_vs_bf16_operand_oracle(case):
         HN.set_precision("bf16")
 
 
+OPTION_CASES = {
+    # call-time use_warp=False on a model built WITH a warp field (models.py:695, 723: `self.use_warp and use_warp`)
+    "call_nowarp": (dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True), dict(use_warp=False)),
+    # view directions given separately from the ray directions (models.py:717-720)
+    "viewdirs": (dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True), dict(viewdirs=True)),
+    # every size argument of the constructor off its default
+    "dims": (dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True, use_rgb_cond=True,
+                  GLO_dim=4, xyz_fourier_dim=6, hyper_fourier_dim=3, view_fourier_dim=2, hyper_slice_out_dim=2), {}),
+    # near / far overridden per call (models.py:690-693)
+    "near_far": (dict(hyper_slice_method=None, use_nerf_embed=False, use_alpha_cond=False), dict(near=0.15, far=0.85)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(OPTION_CASES))
+def test_model_option_matrix_vs_oracle(case):
+    """Constructor sizes and forward() keyword arguments the fixtures do not vary, fp32 against the oracle (1e-4
+    element-wise on every returned per-ray tensor of both levels, gradients 5e-3), plus — for the default model —
+    `metadata_encoded=True` fed with the gathered rows (per-network launches) against the index path (one fused
+    launch per level): the same arithmetic per point, 1e-5."""
+    HN.set_precision("fp32")
+    try:
+        kw, call = OPTION_CASES[case]
+        nc, nf, b, seed = 16, 16, 40, 91
+        m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.3, **kw)
+        sd = load_hash(m, seed)
+        m = m.to(DEV)
+        o, d, idx = rays_for(seed, b)
+        vd = None
+        if call.get("viewdirs"):
+            vd = H.uniform(seed, "vd", (b, 3), -1, 1)
+            vd = vd / vd.norm(dim=-1, keepdim=True)
+        rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1),
+               "noise_coarse": H.normal(seed, "n1", (b, nc, 1)) * 0.3, "noise_fine": H.normal(seed, "n2", (b, nc + nf, 1)) * 0.3}
+        cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.3, near=call.get("near", 0.0),
+                         far=call.get("far", 1.0), **kw)
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = O.nerf_model_forward(p, cfg, o, d, idx, rng, viewdirs=vd, use_warp=call.get("use_warp", True))
+        gt = H.uniform(seed, "gt", (b, 3), 0, 1)
+        O.mse_loss(ref, gt).backward()
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None if vd is None else vd.to(DEV),
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        fkw = {k: call[k] for k in ("use_warp", "near", "far") if k in call}
+        drng = {k: v.to(DEV) for k, v in rng.items()}
+        out = m(rays, {}, rng=drng, **fkw)
+        same = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).float().mean().item()
+        assert same > 0.995, f"only {same:.4f} of fine-sample indices agree"
+        for lvl in ("coarse", "fine"):
+            for k in ("rgb", "depth", "acc", "weights", "warped_points"):
+                assert out[lvl][k].shape == ref[lvl][k].shape, (lvl, k)
+                if lvl == "coarse" or same == 1.0:
+                    assert_close(out[lvl][k], ref[lvl][k], 1e-4, f"options {case} {lvl}/{k}")
+        loss = ((out["coarse"]["rgb"] - gt.to(DEV)) ** 2).mean() + ((out["fine"]["rgb"] - gt.to(DEV)) ** 2).mean()
+        loss.backward()
+        for k, prm in m.named_parameters():
+            assert_grad_close(prm.grad, p[k].grad, 5e-3 if same == 1.0 else 2e-2, f"options {case} d {k}")
+        if case == "viewdirs":
+            # the same forward with the embeddings looked up by the caller (metadata_encoded, models.py:609-622, 425-436)
+            with torch.no_grad():
+                row = m.warp_embed(idx.to(DEV))
+                enc = dict(rays, metadata={"encoded_warp": row, "encoded_hyper": row, "encoded_nerf": row})
+                out2 = m(enc, {}, rng=drng, metadata_encoded=True)
+                out1 = m(rays, {}, rng=drng)
+            for lvl in ("coarse", "fine"):
+                for k in ("rgb", "depth", "acc"):
+                    assert_close(out2[lvl][k], out1[lvl][k], 1e-5, f"metadata_encoded {lvl}/{k}")
+    finally:
+        HN.set_precision("bf16")
+
+
 LEGACY = {
     "c_only": dict(N_samples=16, N_importance=0, perturb=0, noise_std=0),
     "c_only_pert_noise": dict(N_samples=16, N_importance=0, perturb=1, noise_std=1),

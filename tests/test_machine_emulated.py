@@ -246,6 +246,99 @@ def test_fused_level_program_emulated(bf16):
 
 
 @pytest.mark.parametrize("bf16", [True, False])
+def test_axis_aligned_level_and_gathered_template_emulated(bf16):
+    """axis_aligned_plane (models.py:533-534): the hyper coordinates are the ray's GLO row.  (a) the fused level
+    [warp | template] encodes them from the gathered source, (b) the stand-alone template program with the table
+    gathered in-kernel (levels whose warp runs outside the program: SE3Field).  Outputs, weight gradients and the
+    table gradient (conditions + hyper coordinates + warp input, one row per ray) against the oracle."""
+    from hypernerf_torch_amd.hypernerf import models
+    torch.manual_seed(0)
+    emb = {"warp": list(range(12)), "camera": [0], "appearance": list(range(12)), "time": list(range(12))}
+    m = models.NerfModel(emb, n_samples_coarse=8, n_samples_fine=8, hyper_slice_method="axis_aligned_plane",
+                         hyper_slice_out_dim=8, use_nerf_embed=True, use_alpha_cond=True, xyz_fourier_dim=2,
+                         hyper_fourier_dim=1, view_fourier_dim=1)
+    m.warp_field = warping.TranslationField(in_ch=3, in_ch_embed=8, depth=6, hidden_channels=32)
+    m.nerf_mlps_coarse = modules.NerfMLP(in_ch=15 + 24, trunk_depth=4, trunk_width=64, rgb_branch_depth=2,
+                                         rgb_branch_width=32, hidden_activation=torch.nn.ReLU(), skips=[2],
+                                         rgb_activation=torch.nn.Sigmoid(), alpha_condition_dim=8, rgb_condition_dim=9,
+                                         alpha_brach_width=32)
+    sd = load_hash(m, 23)
+    b, s = 5, 8
+    n = b * s
+    pts = H.uniform(7, "pts", (b, s, 3), -1, 1).double()
+    dirs = H.uniform(7, "dirs", (b, 3), -1, 1).double()
+    idx = torch.tensor([3, 11, 0, 3, 7])
+    mode = E.Mode(bf16)
+    table = sd["warp_embed.embed.weight"]
+    g_rgb = H.uniform(8, "g_rgb", (n, 3), -1, 1).double()
+    g_a = H.uniform(8, "g_a", (n, 1), -1, 1).double()
+
+    def reference(tp, with_warp):
+        e = O.glo_embed(tp["warp_embed.embed.weight"], idx)
+        ee = e[:, None, :].expand(b, s, 8)
+        xyz = O.translation_field(tp, "warp_field", pts, ee) if with_warp else pts
+        feat = torch.cat([O.posenc_orig(xyz, 2), O.posenc_orig(ee, 1)], -1)
+        rgb, alpha = O.nerf_mlp(tp, "nerf_mlps_coarse", feat, e, O.posenc_orig(dirs, 1), trunk_depth=4, rgb_depth=2,
+                                skips=(2,))
+        return xyz, rgb, alpha
+
+    def table_grad(prog, dsrc):
+        cols = {c: sl for (si, c), sl in prog.dsrc_map.items() if si == 2}
+        assert sorted(cols) == list(range(8))
+        rows = np.stack([dsrc[:, cols[c]].reshape(b, s).sum(1) for c in range(8)], axis=1)
+        d_table = np.zeros(table.shape)
+        np.add.at(d_table, idx.numpy(), rows)
+        return d_table
+
+    # (a) fused level
+    assert m._can_fuse_level(True, False, {})
+    call = m._level_call("coarse")
+    assert call.fill_from_gather == (0, 3) and call.dst_widths == [11, 3, 1]
+    prog = call.program
+    tables = prog.host_tables(1 if bf16 else 0)
+    params = np_params(prog)
+    srcs = [(pts.reshape(n, 3).numpy(), False), (dirs.numpy(), True), (table.numpy(), True, idx.numpy()), None]
+    outs, stash = E.run_forward(prog, mode, tables, params, srcs, n, s, [11, 3, 1])
+    tp = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xyz, rgb, alpha = reference(tp, True)
+    np.testing.assert_allclose(outs[0].reshape(b, s, 11)[..., :3], xyz.detach().numpy(), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(outs[1].reshape(b, s, 3), rgb.detach().numpy(), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(outs[2].reshape(b, s, 1), alpha.detach().numpy(), rtol=1e-9, atol=1e-11)
+    ((rgb.reshape(n, 3) * g_rgb).sum() + (alpha.reshape(n, 1) * g_a).sum()).backward()
+    bsrcs = srcs[:3] + [(outs[0], False), (g_rgb.numpy(), False), (g_a.numpy(), False), (outs[1], False), None]
+    dsrc = E.run_backward(prog, mode, tables, params, bsrcs, n, s, stash)
+    np.testing.assert_allclose(table_grad(prog, dsrc), tp["warp_embed.embed.weight"].grad.numpy(), rtol=1e-8, atol=1e-10)
+    _, gtot = prog.grad_offsets()
+    check_grads(prog, E.run_wgrad(prog, mode, prog.wgrad_jobs(1 if bf16 else 0, n), stash, gtot), tp,
+                dict(m.named_parameters()))
+
+    # (b) template alone, table gathered in-kernel, gradient w.r.t. the spatial points returned
+    call = m._template_gather_call("coarse", True, True)
+    prog = call.program
+    tables = prog.host_tables(1 if bf16 else 0)
+    params = np_params(prog)
+    srcs = [(pts.reshape(n, 3).numpy(), False), (dirs.numpy(), True), (table.numpy(), True, idx.numpy())]
+    outs, stash = E.run_forward(prog, mode, tables, params, srcs, n, s, [3, 1])
+    tp = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pts_g = pts.clone().requires_grad_(True)
+    e = O.glo_embed(tp["warp_embed.embed.weight"], idx)
+    feat = torch.cat([O.posenc_orig(pts_g, 2), O.posenc_orig(e[:, None, :].expand(b, s, 8), 1)], -1)
+    rgb, alpha = O.nerf_mlp(tp, "nerf_mlps_coarse", feat, e, O.posenc_orig(dirs, 1), trunk_depth=4, rgb_depth=2, skips=(2,))
+    np.testing.assert_allclose(outs[0].reshape(b, s, 3), rgb.detach().numpy(), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(outs[1].reshape(b, s, 1), alpha.detach().numpy(), rtol=1e-9, atol=1e-11)
+    ((rgb.reshape(n, 3) * g_rgb).sum() + (alpha.reshape(n, 1) * g_a).sum()).backward()
+    bsrcs = srcs + [None, (g_rgb.numpy(), False), (g_a.numpy(), False), (outs[0], False)]
+    dsrc = E.run_backward(prog, mode, tables, params, bsrcs, n, s, stash)
+    np.testing.assert_allclose(table_grad(prog, dsrc), tp["warp_embed.embed.weight"].grad.numpy(), rtol=1e-8, atol=1e-10)
+    pcols = [prog.dsrc_map[(0, c)] for c in range(3)]
+    np.testing.assert_allclose(dsrc[:, pcols].reshape(b, s, 3), pts_g.grad.numpy(), rtol=1e-8, atol=1e-10)
+    _, gtot = prog.grad_offsets()
+    flat = E.run_wgrad(prog, mode, prog.wgrad_jobs(1 if bf16 else 0, n), stash, gtot)
+    check_grads(prog, flat, {k: v for k, v in tp.items() if k.startswith("nerf_mlps_coarse")},
+                {k: v for k, v in m.named_parameters() if k.startswith("nerf_mlps_coarse")})
+
+
+@pytest.mark.parametrize("bf16", [True, False])
 def test_se3_field_program_emulated(bf16):
     """SE3Field as ONE program (warping.py:212-225): encoder -> trunk -> [w_net.linears.0 ; v_net.linears.0] as one
     row-stacked 128 -> 256 layer -> two logit layers reading a window (one half) of that activation each.  Outputs
