@@ -363,6 +363,53 @@ def test_model_option_matrix_vs_oracle(case):
         HN.set_precision("bf16")
 
 
+@pytest.mark.parametrize("case", ["bendy_cond", "axis", "nowarp_cond"])
+def test_per_network_launch_path_matches_fused_level(case):
+    """NerfModel.FUSE_LEVELS=False keeps the round-1 structure (one launch per network, torch glue in between; still
+    used for pre-encoded metadata and hyper_point overrides).  Same model, same draws, fp32: outputs to 1e-5
+    element-wise and every gradient to 1e-4 of the fused path's (same arithmetic per point; only the order in which
+    float atomics land in the weight gradients differs)."""
+    HN.set_precision("fp32")
+    try:
+        kw = CASES[case]
+        nc, nf, b, seed = 32, 32, 24, 93
+        rays_cpu = rays_for(seed, b)
+        rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1),
+               "noise_coarse": H.normal(seed, "n1", (b, nc, 1)) * 0.5, "noise_fine": H.normal(seed, "n2", (b, nc + nf, 1)) * 0.5}
+        gt = H.uniform(seed, "gt", (b, 3), 0, 1).to(DEV)
+        res = {}
+        for fuse in (True, False):
+            m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, **kw)
+            load_hash(m, seed)
+            m = m.to(DEV)
+            m.FUSE_LEVELS = fuse
+            o, d, idx = rays_cpu
+            rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                    "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+            L.KERNEL_TIMES = {}
+            try:
+                out = m(rays, {}, rng={k: v.to(DEV) for k, v in rng.items()})
+                loss = ((out["coarse"]["rgb"] - gt) ** 2).mean() + ((out["fine"]["rgb"] - gt) ** 2).mean()
+                loss.backward()
+                torch.cuda.synchronize()
+                L.collect_kernel_times()
+                launches = sorted(k for k in L.KERNEL_TIMES if k.startswith("hn_mlp_forward"))
+            finally:
+                L.KERNEL_TIMES = None
+            res[fuse] = (out, {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, launches)
+        assert len(res[True][2]) <= 2 and all("level" in k or "template" in k for k in res[True][2]), res[True][2]
+        if case != "nowarp_cond":
+            assert len(res[False][2]) > len(res[True][2]), (res[True][2], res[False][2])
+        for lvl in ("coarse", "fine"):
+            for k in ("rgb", "depth", "acc", "weights", "warped_points"):
+                assert_close(res[False][0][lvl][k], res[True][0][lvl][k].cpu(), 1e-5, f"unfused {case} {lvl}/{k}")
+        assert res[False][1].keys() == res[True][1].keys()
+        for k, g in res[True][1].items():
+            assert_grad_close(res[False][1][k], g, 1e-4, f"unfused {case} d {k}")
+    finally:
+        HN.set_precision("bf16")
+
+
 LEGACY = {
     "c_only": dict(N_samples=16, N_importance=0, perturb=0, noise_std=0),
     "c_only_pert_noise": dict(N_samples=16, N_importance=0, perturb=1, noise_std=1),
