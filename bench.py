@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--overlap", action="store_true",
+                    help="data-parallel runs: all-reduce the gradient buffer in two buckets, the first in flight while the "
+                         "weight gradients of the second are computed (dist.GradSync).  Off by default: splitting the "
+                         "batched weight-gradient launch costs ~0.2 ms on one MI355X, more than the all-reduce it hides")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (process group + all-reduce between two graphs) even with one rank")
     a = ap.parse_args()
@@ -101,7 +105,7 @@ def build_workload(a, dev, rank):
             call = coarse._calls[next(iter(coarse._calls))] if hasattr(coarse, "_calls") else None
             return {} if call is None else {"NeRF": (call.program, b * a.nc)}
         workload = f"legacy render_rays, NeRF coarse only, {b} rays x {a.nc} samples, fwd+bwd+Adam"
-        return fwd_bwd, params, programs, workload
+        return fwd_bwd, params, programs, workload, coarse
     kw = dict(hyper_slice_method="bendy_sheet", use_warp=True, use_nerf_embed=True, use_alpha_cond=True)
     if a.kind == "se3":
         kw = dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_warp=True, use_nerf_embed=True,
@@ -126,7 +130,7 @@ def build_workload(a, dev, rank):
         return {name: (prog, pts) for name, prog, pts in model.compiled_programs(b)}
     what = "SE3Field warp + axis_aligned_plane" if a.kind == "se3" else "use_warp bendy_sheet"
     workload = (f"NerfModel {what} nerf_embed+alpha_cond, {b} rays x ({a.nc}+{a.nf}) samples per GPU, fwd+bwd+Adam")
-    return fwd_bwd, list(model.parameters()), programs, workload
+    return fwd_bwd, list(model.parameters()), programs, workload, model
 
 
 def main():
@@ -152,7 +156,7 @@ def main():
     from hypernerf_torch_amd.dist import all_gather_pixels
 
     HN.set_precision(a.precision)
-    fwd_bwd, params, programs, workload = build_workload(a, dev, rank)
+    fwd_bwd, params, programs, workload, model = build_workload(a, dev, rank)
     use_graph = not a.no_graph
     # parameters and gradients live in one flat arena each: the kernels accumulate dW straight into it, Adam steps
     # one tensor, and data parallelism SUM-all-reduces the gradient buffer in place (the 1/N sits in the Adam kernel).
@@ -166,26 +170,42 @@ def main():
         opt.step()
         return out, loss
 
+    sync = None
+    if dp:
+        # gradient all-reduce: ONE in-place SUM of the flat buffer by default; with --overlap in two buckets, template
+        # networks first (in flight while the warp / sheet weight gradients are still being computed), the rest
+        # behind them (hypernerf_torch_amd.dist.GradSync)
+        from hypernerf_torch_amd import functional as HF
+        from hypernerf_torch_amd.dist import GradSync
+        sync = GradSync(arena, model, overlap=a.overlap)
+
+        def fwd_bwd_dp():
+            with sync.splitting():
+                return fwd_bwd()
+
     if use_graph:
         from hypernerf_torch_amd.graphs import GraphedStep
         if not dp:
             step = GraphedStep(whole_step, warmup=3)
         else:
-            # two graphs around the one collective: forward+backward | all-reduce of the gradient buffer | Adam
-            gfb = GraphedStep(fwd_bwd, warmup=3)
+            # graphs around the collectives: forward+backward (+ first weight-gradient bucket) | all-reduce(bucket 0)
+            # with the held weight-gradient bucket replayed next to it | all-reduce(bucket 1) | Adam
+            HF.flush_held_wgrads()
+            gfb = GraphedStep(fwd_bwd_dp, warmup=3, warmup_fn=lambda: (fwd_bwd_dp(), HF.flush_held_wgrads()))
+            gheld = GraphedStep(HF.flush_held_wgrads, warmup=0, pool=gfb.graph.pool()) if HF.held_wgrads() else None
             arena.zero_grad()
             gopt = GraphedStep(opt.step, warmup=1)
 
             def step():
                 res = gfb()
-                arena.all_reduce_sum()
+                sync.reduce(gheld)
                 gopt()
                 return res
     else:
         def step():
-            out, loss = fwd_bwd()
+            out, loss = fwd_bwd_dp() if dp else fwd_bwd()
             if dp:
-                arena.all_reduce_sum()
+                sync.reduce(HF.flush_held_wgrads)
             opt.step()
             return out, loss
 
@@ -226,7 +246,7 @@ def main():
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.precision, "data": "synthetic",
         "config": {"workload": workload, "baseline_config": a.config, "rays_per_gpu": b, "n_samples": a.nc,
-                   "n_importance": a.nf, "parallelism": f"dp{world}", "hip_graph": use_graph, "dp_code_path": dp,
+                   "n_importance": a.nf, "parallelism": f"dp{world}", "hip_graph": use_graph, "dp_code_path": dp, "grad_sync": None if sync is None else ("one all-reduce" if sync.split is None else f"two buckets split at float {sync.split} of {arena.numel}, overlapped"),
                    "ranks_seen_by_collective": ranks_seen},
         "per_gpu": value / world, "final_loss": float(loss.detach()),
         "repeats": len(reps), "ms_per_step_repeats": [1e3 * r / a.steps for r in reps],

@@ -8,6 +8,7 @@ Both messages are latency-bound on xGMI, so they are single collectives, not per
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Iterable, List, Optional
 
 import torch
@@ -78,3 +79,77 @@ def all_gather_pixels(x: torch.Tensor, group=None) -> torch.Tensor:
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x.contiguous(), group=group)
     return out
+
+
+class GradSync:
+    """The gradient all-reduce of one training step, overlapped with the tail of backward (SURVEY.md §5 'overlap with
+    the tail of backward'; what Lightning's DDP bucketing does for the reference, train.py:225-229).
+
+    The last kernel of a backward pass is the batched weight-gradient launch, which produces every dW at once — there
+    is nothing behind it to overlap with.  So that launch is split in two (machine.WGRAD_SPLIT_OFFSET): the jobs of
+    the template networks (the tail of the gradient buffer, ~85 % of its bytes) run at the end of backward; the jobs
+    of the warp field and the hyper sheet are held back and run WHILE the first bucket is being all-reduced on RCCL's
+    stream; their (small, latency-bound) all-reduce follows.
+
+        sync = GradSync(arena, model)              # picks the split from the model's parameter layout
+        with sync.splitting():
+            loss = ...; loss.backward()            # bucket 0 launched at the end of backward, bucket 1 held
+        sync.reduce(functional.flush_held_wgrads)  # or the replay of a graph that captured that call
+        optimizer.step()                           # ArenaAdam(grad_scale=1/world)
+
+    Without a usable split (no `nerf_mlps_*` block at the tail of the arena) or with overlap=False it is the single
+    in-place all-reduce of the whole buffer.
+
+    MEASURED COST (one MI355X, config 2, tools/held_probe.py): the single batched weight-gradient launch takes
+    0.72-0.75 ms; split at the template networks it takes 0.65 + 0.28 ms, split at the fine-level template 0.48 +
+    0.47 ms — each launch pays its own ramp and tail (jobs stream ~5 MB each, ~0.2 ms), so splitting costs ~0.2 ms,
+    which is more than a 6 MB all-reduce over xGMI is expected to take.  TrainStep and bench.py therefore default to
+    the single all-reduce; the overlap is there for topologies where the measured all-reduce exceeds that."""
+
+    def __init__(self, arena, model: Optional[torch.nn.Module] = None, group=None, overlap: bool = True,
+                 tail_prefix: str = "nerf_mlps_"):
+        self.arena, self.group = arena, group
+        self.split = self._template_offset(arena, model, tail_prefix) if (overlap and model is not None) else None
+
+    @staticmethod
+    def _template_offset(arena, model, tail_prefix: str = "nerf_mlps_") -> Optional[int]:
+        """Offset (floats) where the parameters named `tail_prefix*` (default: the template networks) start, if they
+        are exactly the tail of the arena."""
+        tail = [p for name, p in model.named_parameters() if name.startswith(tail_prefix) and p.requires_grad]
+        offs = [arena.attached(p) for p in tail]
+        if not tail or any(o is None for o in offs):
+            return None
+        split = min(offs)
+        ids = {id(p) for p in tail}
+        for p, o in zip(arena.params, arena.offsets):
+            if (o >= split) != (id(p) in ids):
+                return None
+        return split if 0 < split < arena.numel else None
+
+    @contextlib.contextmanager
+    def splitting(self):
+        """Wrap the forward+backward passes of the step: backward passes that END inside hold their bucket-1 jobs
+        (machine.WGRAD_SPLIT_OFFSET is a process-wide switch, so it is only set for the duration)."""
+        from . import machine
+        old = machine.WGRAD_SPLIT_OFFSET
+        machine.WGRAD_SPLIT_OFFSET = self.split
+        try:
+            yield self
+        finally:
+            machine.WGRAD_SPLIT_OFFSET = old
+
+    def reduce(self, run_held=None):
+        """Call after forward+backward.  `run_held` launches the held weight-gradient jobs (eagerly or as a graph
+        replay); it is called even when there is nothing to overlap with, so the gradients are always complete."""
+        if self.split is None:
+            if run_held is not None:
+                run_held()
+            self.arena.all_reduce_sum(self.group)
+            return
+        g = self.arena.grad
+        h0 = dist.all_reduce(g[self.split:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if run_held is not None:
+            run_held()
+        h1 = dist.all_reduce(g[:self.split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        h0.wait()
+        h1.wait()

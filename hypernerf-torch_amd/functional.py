@@ -152,8 +152,9 @@ class _ProgramFn(torch.autograd.Function):
         dsrc, flat = call.runner.backward(ctx.mode, ctx.n_points, ctx.spr, bsrcs, ctx.stash, ctx.masks,
                                           grad_target=(target[0].grad, target[1]) if target else None,
                                           defer=BATCH_WGRADS, embed=embed, want_dsrc=want_dsrc)
-        if isinstance(flat, PendingWgrad):
-            _defer_wgrad(flat)
+        if isinstance(flat, list):          # deferred: this program's share(s) of the batched weight-gradient launch
+            for pend in flat:
+                _defer_wgrad(pend)
             flat = None
         ctx.stash = ctx.masks = None
         src_grads: List[Optional[torch.Tensor]] = []
@@ -208,10 +209,29 @@ _PENDING: List[PendingWgrad] = []
 _PENDING_TASK = [-1]      # autograd graph-task id the pending entries belong to
 
 
+_HELD: List[PendingWgrad] = []       # bucket-1 shares (machine.WGRAD_SPLIT_OFFSET), launched by flush_held_wgrads()
+
+
 def _flush_wgrads():
     pending = list(_PENDING)
     _PENDING.clear()
-    launch_pending_wgrads(pending)
+    now = [p for p in pending if p.bucket == 0]
+    _HELD.extend(p for p in pending if p.bucket != 0)
+    if now:
+        launch_pending_wgrads(now)
+
+
+def held_wgrads() -> int:
+    return len(_HELD)
+
+
+def flush_held_wgrads():
+    """Launch the weight-gradient jobs the last backward pass held back (data-parallel overlap: the all-reduce of the
+    first bucket is already in flight).  A no-op without machine.WGRAD_SPLIT_OFFSET."""
+    held = list(_HELD)
+    _HELD.clear()
+    if held:
+        launch_pending_wgrads(held)
 
 
 def _defer_wgrad(p: PendingWgrad):

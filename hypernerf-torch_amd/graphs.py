@@ -8,22 +8,27 @@ other work) and then replays it.  Inputs must live in fixed tensors that the cal
 """
 from __future__ import annotations
 
-from typing import Callable
+from typing import Callable, Optional
 
 import torch
 
 
 class GraphedStep:
-    def __init__(self, fn: Callable[[], object], warmup: int = 3):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
+    def __init__(self, fn: Callable[[], object], warmup: int = 3, warmup_fn: Optional[Callable[[], object]] = None,
+                 pool=None):
+        """warmup_fn: what the warm-up runs execute instead of `fn` (a step whose tail is captured separately runs
+        that tail as well); warmup=0 with warmup_fn=None: capture only (`fn` consumes state a warm-up run would use
+        up); pool: share the memory pool of another graph (`other.graph.pool()`)."""
+        if warmup > 0 or warmup_fn is not None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):
+                    (warmup_fn or fn)()
+            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, pool=pool):
             self.out = fn()
 
     def __call__(self):

@@ -683,9 +683,19 @@ WGRAD_JOB_BYTES = int(float(os.environ.get("HN_WGRAD_JOB_MB", 5)) * (1 << 20))  
 class PendingWgrad:
     """One program's share of a batched weight-gradient launch.  Holds the stash alive until it ran."""
 
-    def __init__(self, mode, jobs_dev, n_jobs, stash, grads, weights):
+    def __init__(self, mode, jobs_dev, n_jobs, stash, grads, weights, bucket=0):
         self.mode, self.jobs_dev, self.n_jobs, self.stash, self.grads = mode, jobs_dev, n_jobs, stash, grads
         self.weights = weights          # per job: stash tiles it streams (host numpy, for the global order)
+        self.bucket = bucket            # 0 = launched at the end of backward, 1 = held (see WGRAD_SPLIT_OFFSET)
+
+
+# Data-parallel overlap (training.TrainStep / bench.py with more than one rank): when set to an offset (floats) into
+# the flat gradient buffer, the deferred weight-gradient jobs of a backward pass are split in two launches — jobs
+# whose matrix lies at or behind the offset (bucket 0: the template networks, the bulk of the bytes) run at the end
+# of backward, the others (bucket 1: warp field, hyper sheet) are HELD until functional.flush_held_wgrads(); the
+# all-reduce of bucket 0's slice then runs while bucket 1 is still being computed.
+WGRAD_SPLIT_OFFSET: Optional[int] = None
+HELD_JOB_DIV = int(os.environ.get("HN_HELD_JOB_DIV", 6))
 
 
 _ORDER_CACHE: Dict[tuple, torch.Tensor] = {}
@@ -893,15 +903,29 @@ class MlpRunner:
         L.launch("hn_mlp_backward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         goffs = tuple(grad_target[1]) if grad_target is not None else None
         deferred = defer and grad_target is not None
-        jkey = (str(device), mode, n_points, goffs, deferred)
+        split = WGRAD_SPLIT_OFFSET if deferred else None
+        jkey = (str(device), mode, n_points, goffs, deferred, split)
         if jkey not in self._jobs:
             jobs = self.prog.wgrad_jobs(mode, n_points, grad_offsets=goffs,
                                         job_bytes=WGRAD_JOB_BYTES if deferred else None)
-            weights = ((jobs["n_nt"] + jobs["n_kt"]).astype(np.int64) * (jobs["blk1"] - jobs["blk0"]))
-            self._jobs[jkey] = (L.to_device_bytes(jobs, device), len(jobs), weights)
-        jobs_dev, n_jobs, weights = self._jobs[jkey]
+            parts = [jobs]
+            if split is not None:
+                # the held bucket runs as a launch of its own, next to the all-reduce of the first: it holds ~1/6 of
+                # the stash bytes, so its jobs are cut finer to still give every CU a few of them
+                fine = self.prog.wgrad_jobs(mode, n_points, grad_offsets=goffs, job_bytes=WGRAD_JOB_BYTES // HELD_JOB_DIV)
+                parts = [jobs[jobs["w_off"] >= split], fine[fine["w_off"] < split]]
+            entry = []
+            for part in parts:
+                part = np.ascontiguousarray(part)
+                weights = ((part["n_nt"] + part["n_kt"]).astype(np.int64) * (part["blk1"] - part["blk0"]))
+                entry.append((L.to_device_bytes(part, device) if len(part) else None, len(part), weights))
+            self._jobs[jkey] = entry
+        entry = self._jobs[jkey]
         if deferred:        # the caller launches it together with the other programs of this backward pass
-            return dsrc, PendingWgrad(mode, jobs_dev, n_jobs, stash, grad_target[0], weights)
+            pend = [PendingWgrad(mode, jd, nj, stash, grad_target[0], w, bucket=b)
+                    for b, (jd, nj, w) in enumerate(entry) if nj > 0]
+            return dsrc, pend
+        jobs_dev, n_jobs, weights = entry[0]
         if grad_target is not None:
             grads, ret = grad_target[0], None
         else:

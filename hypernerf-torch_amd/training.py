@@ -7,20 +7,24 @@ MI355X way: parameters and gradients in a `ParamArena`, `ArenaAdam` (one kernel 
 and step counter on the device), the whole step (prepare_ray_dict -> model per chunk -> MSE -> backward -> Adam)
 captured once into a HIP graph and replayed on fixed input buffers.  With torch.distributed initialised the initial
 parameters are broadcast from rank 0 (what Lightning's DDP wrapper does), rays are expected pre-sharded per rank,
-the gradient buffer is SUM-all-reduced in place between the captured forward+backward and the optimizer step, and the
-1/world of the mean is folded into the Adam kernel (no separate division launch).
+the gradient buffer is SUM-all-reduced in place between the captured forward+backward and the optimizer step —
+optionally in two buckets, the first in flight while the weight gradients of the second are still being computed
+(dist.GradSync, `overlap_grad_sync=True`) — and the 1/world of the mean is folded into the Adam kernel.
 `step(rays, rgbs)` returns the log the reference's training_step records: {'train/loss', 'train/psnr', 'lr'}
 (device scalars, no host sync).
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
+from . import functional as F
 from . import machine
 from .arena import ParamArena
+from .dist import GradSync
 from .graphs import GraphedStep
 from .hypernerf import model_utils
 from .losses import MSELoss, psnr
@@ -32,17 +36,21 @@ _EXTRA = {'nerf_alpha': None, 'warp_alpha': None, 'hyper_alpha': None, 'hyper_sh
 class TrainStep:
     def __init__(self, model: torch.nn.Module, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, use_graph: bool = True, group=None, chunk: int = 32 * 1024,
-                 decay_step: Optional[Sequence[int]] = None, decay_gamma: float = 0.1):
+                 decay_step: Optional[Sequence[int]] = None, decay_gamma: float = 0.1, overlap_grad_sync: bool = False):
         self.model = model
         self.arena = ParamArena(model.parameters())
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.group = group
         self.use_graph = use_graph
         self.chunk = int(chunk)          # rays per model call (train.py:108-111); the default exceeds any batch size
+        self.sync: Optional[GradSync] = None
         if self.world > 1:
             # replicas must start identical (Lightning DDP broadcasts module state from rank 0 at wrap time)
             dist.broadcast(self.arena.data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             self.arena.bump()
+            # one all-reduce of the flat gradient buffer, or (overlap_grad_sync=True) two buckets with the first in
+            # flight while the second is still being computed — off by default, see dist.GradSync
+            self.sync = GradSync(self.arena, model, group, overlap=overlap_grad_sync)
         # hn_adam_step: one launch for all parameters, clears the gradient buffer on the way out, graph-capturable
         # (on one GPU it is part of the captured step; with N>1 it follows the gradient all-reduce and scales the
         # summed gradient by 1/world itself)
@@ -58,6 +66,10 @@ class TrainStep:
 
     # ---- the step body (what gets captured) ---------------------------------------------------
     def _forward_backward(self):
+        with (self.sync.splitting() if self.sync is not None else contextlib.nullcontext()):
+            self._forward_backward_body()
+
+    def _forward_backward_body(self):
         b = self._rays.shape[0]
         loss_sum, psnr_in = None, []
         # the reference renders `chunk` rays at a time and concatenates the results before the loss
@@ -70,6 +82,9 @@ class TrainStep:
             w = rays.shape[0] / b
             loss = self.loss_fn(results, rgbs)
             (loss if w == 1.0 else loss * w).backward()          # into arena.grad (zeroed by the previous Adam launch)
+            if i + self.chunk < b:
+                F.flush_held_wgrads()        # only the LAST chunk's held jobs overlap with the all-reduce (a held
+                                             # job keeps its chunk's activation stash alive)
             typ = 'fine' if 'fine' in results else 'coarse'
             with torch.no_grad():
                 loss_sum = loss.detach() * w if loss_sum is None else loss_sum + loss.detach() * w
@@ -101,6 +116,18 @@ class TrainStep:
         self._restore(snap)
         return g
 
+    def _capture_data_parallel(self):
+        """Two graphs: forward + backward up to the first weight-gradient bucket | the held bucket (None when the
+        model offers no split).  The warm-up runs execute both; the capture of the first leaves exactly one pass's
+        held jobs behind, which the capture of the second consumes."""
+        snap = self._snapshot()
+        F.flush_held_wgrads()
+        g1 = GraphedStep(self._forward_backward, warmup=2,
+                         warmup_fn=lambda: (self._forward_backward(), F.flush_held_wgrads()))
+        g2 = GraphedStep(F.flush_held_wgrads, warmup=0, pool=g1.graph.pool()) if F.held_wgrads() else None
+        self._restore(snap)
+        return g1, g2
+
     # ---- public -----------------------------------------------------------------------------------
     def step(self, rays: torch.Tensor, rgbs: torch.Tensor, rng: Optional[Dict[str, torch.Tensor]] = None
              ) -> Dict[str, torch.Tensor]:
@@ -121,7 +148,7 @@ class TrainStep:
         if not self.use_graph:
             self._forward_backward()
             if self.world > 1:
-                self.arena.all_reduce_sum(self.group)
+                self.sync.reduce(F.flush_held_wgrads)
             self.optimizer.step()
         elif self.world == 1:
             if self._graph is None:
@@ -129,9 +156,10 @@ class TrainStep:
             self._graph()
         else:
             if self._graph is None:
-                self._graph = self._capture(self._forward_backward)
-            self._graph()
-            self.arena.all_reduce_sum(self.group)
+                self._graph = self._capture_data_parallel()
+            fwd_bwd, held = self._graph
+            fwd_bwd()
+            self.sync.reduce(held)      # all-reduce(bucket 0) || held weight gradients, then all-reduce(bucket 1)
             self.optimizer.step()
         # a replay updates the parameters without running any Python: tell the weight packers (an eval forward
         # after this must repack — see machine.MlpRunner.pack)

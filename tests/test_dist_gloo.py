@@ -1,6 +1,6 @@
 """Data-parallel host logic on CPU: 2 processes, gloo backend (the GPU run uses the same code over RCCL).
 Covers ray sharding, the single flat gradient all-reduce (with a parameter that received no gradient on one
-rank) and the pixel all-gather."""
+rank), the two-bucket overlapped reduction (GradSync) and the pixel all-gather."""
 import os
 import socket
 import sys
@@ -60,6 +60,37 @@ def _worker(rank, world, port, q):
         allpx = all_gather_pixels(px)
         ok = ok and allpx.shape == (8, 3) and torch.equal(allpx[:4], torch.zeros(4, 3)) and \
             torch.equal(allpx[4:], torch.ones(4, 3))
+        # GradSync (dist.py): the all-reduce in two buckets around the held weight-gradient launch.  A module whose
+        # parameter names follow NerfModel's (the template networks are the tail of the arena) gives the split;
+        # `run_held` stands for the held launch: it writes into the HEAD of the buffer after bucket 0's all-reduce
+        # has been issued, and must be part of what bucket 1 reduces.
+        from hypernerf_torch_amd import machine
+        from hypernerf_torch_amd.dist import GradSync
+
+        class Toy(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.warp_field = torch.nn.Linear(3, 4)
+                self.nerf_mlps_coarse = torch.nn.Linear(4, 2)
+                self.nerf_mlps_fine = torch.nn.Linear(4, 2)
+        toy = Toy()
+        ta = ParamArena(toy.parameters())
+        sync = GradSync(ta, toy)
+        ok = ok and sync.split == 16 and ta.numel == 16 + 2 * (8 + 4)
+        ta.grad.fill_(float(rank + 1))
+        with sync.splitting():
+            inside = machine.WGRAD_SPLIT_OFFSET
+        ok = ok and inside == 16 and machine.WGRAD_SPLIT_OFFSET is None
+        sync.reduce(lambda: ta.grad[:16].add_(10.0 * (rank + 1)))
+        ok = ok and torch.allclose(ta.grad[16:], torch.full((24,), 3.0)) and \
+            torch.allclose(ta.grad[:16], torch.full((16,), 33.0))
+        # no usable split (template parameters not the tail): one all-reduce, the held launch still runs first
+        toy2 = torch.nn.Sequential(torch.nn.Linear(2, 2))
+        tb = ParamArena(toy2.parameters())
+        s2 = GradSync(tb, toy2)
+        tb.grad.fill_(1.0)
+        s2.reduce(lambda: tb.grad.add_(float(rank)))
+        ok = ok and s2.split is None and torch.allclose(tb.grad, torch.full((tb.numel,), 3.0))
         q.put((rank, bool(ok), (lo, hi)))
     finally:
         dist.destroy_process_group()

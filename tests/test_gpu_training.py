@@ -17,6 +17,7 @@ import hypernerf_torch_amd as HN
 from gpu_common import DEV, EMB, assert_close, load_hash, rays_for
 from hypernerf_torch_amd import functional as F
 from hypernerf_torch_amd.hypernerf import models
+from hypernerf_torch_amd.dist import GradSync
 from hypernerf_torch_amd.training import TrainStep
 from oracle import hypernerf_oracle as O
 
@@ -186,7 +187,7 @@ def _free_port():
     return p
 
 
-def _dp_worker(rank, world, port, use_graph, q):
+def _dp_worker(rank, world, port, use_graph, overlap, q):
     for pth in (ROOT, os.path.join(ROOT, "tests")):
         if pth not in sys.path:
             sys.path.insert(0, pth)
@@ -205,12 +206,17 @@ def _dp_worker(rank, world, port, use_graph, q):
         m.use_stratified_sampling = False
         _, _, _, rays = ray_rows(51, 64)
         rgbs = H.uniform(51, "rgbs", (64, 3), 0.1, 0.9)
-        ts = TS(m, lr=1e-3, use_graph=use_graph)
+        from hypernerf_torch_amd import functional as F2
+        ts = TS(m, lr=1e-3, use_graph=use_graph, overlap_grad_sync=overlap)
+        # two buckets: the template networks are the tail of the arena, the warp field / sheet / GLO table the head
+        assert (ts.sync.split is not None) == overlap and (not overlap or 0 < ts.sync.split < ts.arena.numel)
         mine_r, mine_c = shard_rays(rays).to(DEV), shard_rays(rgbs).to(DEV)
         # gradient of the first step (before Adam consumes it): run the step body by hand
         ts._rays, ts._rgbs = mine_r.clone(), mine_c.clone()
         ts._forward_backward()
-        ts.arena.all_reduce_sum()
+        assert (F2.held_wgrads() > 0) == overlap       # the warp / sheet weight gradients are still to be launched
+        ts.sync.reduce(F2.flush_held_wgrads)
+        assert F2.held_wgrads() == 0
         grad = (ts.arena.grad / world).cpu().clone()
         ts.arena.zero_grad()
         for _ in range(3):
@@ -220,13 +226,16 @@ def _dp_worker(rank, world, port, use_graph, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_train_step_two_ranks_match_one_rank(use_graph):
+@pytest.mark.parametrize("use_graph,overlap", [(False, True), (True, True), (True, False)])
+def test_train_step_two_ranks_match_one_rank(use_graph, overlap):
+    """N>1 path of TrainStep end to end: broadcast of rank 0's weights, the gradient all-reduce in two overlapped
+    buckets (dist.GradSync: the second bucket's weight gradients are launched while the first is being reduced) or
+    as one, 1/world inside Adam — against one rank on the whole batch: first gradient and the weights after 3 steps."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, use_graph, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, use_graph, overlap, q)) for r in range(2)]
     for p_ in procs:
         p_.start()
     got = {}
@@ -248,11 +257,26 @@ def test_train_step_two_ranks_match_one_rank(use_graph):
     _, _, _, rays = ray_rows(51, 64)
     rgbs = H.uniform(51, "rgbs", (64, 3), 0.1, 0.9)
     ts = TrainStep(m, lr=1e-3, use_graph=False)
+    assert ts.sync is None
+    start = ts.arena.data.cpu().clone()
     ts._rays, ts._rgbs = rays.to(DEV), rgbs.to(DEV)
     ts._forward_backward()
     ref = ts.arena.grad.cpu()
     err = float((torch.from_numpy(got[0][0]) - ref).norm() / ref.norm())
     assert err <= 1e-5, f"mean of the two shard gradients vs the full-batch gradient: rel L2 {err:.2e}"
+    # every bucket got reduced: the error of the head (warp / sheet / GLO) and of the tail (template) separately
+    k = GradSync._template_offset(ts.arena, m)
+    for name, sl in (("head", slice(0, k)), ("tail", slice(k, None))):
+        e = float((torch.from_numpy(got[0][0])[sl] - ref[sl]).norm() / ref[sl].norm())
+        assert e <= 1e-5, f"{name} bucket: rel L2 {e:.2e}"
+    ts.arena.zero_grad()
+    for _ in range(3):
+        ts.step(rays.to(DEV), rgbs.to(DEV))
+    moved = ts.arena.data.cpu() - start
+    err = float((torch.from_numpy(got[0][1]) - ts.arena.data.cpu()).norm() / moved.norm())
+    # Adam's first steps are sign-like (lr * g / (|g| + eps)): the ~1e-5 of elements whose gradient is smaller than the
+    # rounding difference between the two computations move by +-lr either way; measured 1.4e-2 of the update
+    assert err <= 5e-2, f"weights after 3 data-parallel steps vs 3 one-rank steps: rel L2 of the update {err:.2e}"
 
 
 def test_eval_image_loop_vs_oracle_deterministic(tmp_path):
