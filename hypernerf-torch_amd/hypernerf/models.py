@@ -477,6 +477,22 @@ class NerfModel(nn.Module):
         return self._composite_level(out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity,
                                      dust, keep, b, s, points.device)
 
+    def _empty_result(self, like: torch.Tensor, use_warp: bool):
+        """Zero rays in, zero rays out (the reference's ATen ops all accept empty batches): no kernel is launched."""
+        e = lambda *shape: like.new_zeros(shape)
+        hyper = 0
+        if use_warp and self.hyper_slice_method == 'bendy_sheet':
+            hyper = self.hyper_sheet_out_dim
+        elif use_warp and self.hyper_slice_method == 'axis_aligned_plane':
+            hyper = self.GLO_dim
+        out = {}
+        for level, s in (('coarse', self.num_coarse_samples), ('fine', self.num_coarse_samples + self.num_fine_samples)):
+            if level == 'fine' and self.num_fine_samples <= 0:
+                break
+            out[level] = {'points': e(0, s, 3), 'warped_points': e(0, s, 3 + hyper), 'rgb': e(0, 3), 'depth': e(0),
+                          'acc': e(0), 'weights': e(0, s), 'med_depth': e(0), 'med_points': e(0, 1, 1)}
+        return out
+
     def _composite_level(self, out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity, dust, keep,
                          b, s, device):
         """noise_regularize + Softplus + filter_sigma + volumetric_rendering + median-depth gather
@@ -511,6 +527,8 @@ class NerfModel(nn.Module):
         if use_sample_at_infinity is None:
             use_sample_at_infinity = self.use_sample_at_infinity
         b = origins.shape[0]
+        if b == 0:
+            return self._empty_result(origins, use_warp)
         z_vals, points = model_utils.sample_along_rays(origins, directions, self.num_coarse_samples, near, far,
                                                        self.use_stratified_sampling, self.use_linear_disparity,
                                                        t_rand=rng.get('t_rand'))

@@ -50,6 +50,11 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     model_coarse = models[0]
     emb_xyz, emb_dir = embeddings[0], embeddings[1]
     n_rays = rays.shape[0]
+    if n_rays == 0:         # zero rays in, zero rays out (no launch)
+        res = {'opacity_coarse': rays.new_zeros(0)}
+        for typ in ([] if test_time else ['coarse']) + (['fine'] if N_importance > 0 else []):
+            res[f'rgb_{typ}'], res[f'depth_{typ}'], res[f'opacity_{typ}'] = rays.new_zeros(0, 3), rays.new_zeros(0), rays.new_zeros(0)
+        return res
     rays_d = rays[:, 3:6]
     t, omt = _t_vals(N_samples, rays.device)
     t_rand = None

@@ -434,6 +434,24 @@ def test_per_network_launch_path_matches_fused_level(case):
         HN.set_precision("bf16")
 
 
+def test_empty_ray_batch():
+    """Zero rays: the reference's ATen ops return empty tensors of the usual trailing shapes; here no kernel is launched
+    and the same keys / shapes come back (NerfModel.forward and the legacy render_rays)."""
+    m = models.NerfModel(EMB, n_samples_coarse=8, n_samples_fine=16, **CASES["bendy_cond"]).to(DEV)
+    z = torch.zeros(0, 3, device=DEV)
+    idx = torch.zeros(0, dtype=torch.int64, device=DEV)
+    out = m({"origins": z, "directions": z, "viewdirs": None,
+             "metadata": {k: idx for k in ("warp", "camera", "appearance", "time")}}, {})
+    assert set(out) == {"coarse", "fine"}
+    assert out["coarse"]["rgb"].shape == (0, 3) and out["fine"]["weights"].shape == (0, 24)
+    assert out["fine"]["warped_points"].shape == (0, 24, 7) and out["coarse"]["med_points"].shape == (0, 1, 1)
+    nets = [legacy_nerf.NeRF().to(DEV), legacy_nerf.NeRF().to(DEV)]
+    emb = [legacy_nerf.Embedding(3, 10), legacy_nerf.Embedding(3, 4)]
+    res = legacy_rendering.render_rays(nets, emb, torch.zeros(0, 8, device=DEV), N_samples=8, N_importance=8)
+    assert sorted(res) == ["depth_coarse", "depth_fine", "opacity_coarse", "opacity_fine", "rgb_coarse", "rgb_fine"]
+    assert res["rgb_fine"].shape == (0, 3) and res["depth_coarse"].shape == (0,)
+
+
 LEGACY = {
     "c_only": dict(N_samples=16, N_importance=0, perturb=0, noise_std=0),
     "c_only_pert_noise": dict(N_samples=16, N_importance=0, perturb=1, noise_std=1),
