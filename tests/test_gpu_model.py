@@ -508,32 +508,40 @@ def test_golden_legacy_render_rays(golden_dir, name):
             grad_stats_close({k: v.grad for k, v in fine.named_parameters()}, g, "gradf/", 5e-3)
 
 
-def test_config2_full_size_properties():
-    """BASELINE config 2 (1024 rays x (64+64), bendy sheet, bf16): size-independent properties of the result."""
+@pytest.mark.parametrize("b,nc,nf", [(1024, 64, 64), (16384, 64, 128)], ids=["config2", "config3"])
+def test_full_size_properties(b, nc, nf):
+    """BASELINE config 2 (1024 rays x (64+64)) and config 3 (16,384 rays x (64+128) = 4.2 M evaluated points, a 60 GB
+    activation stash), bendy sheet, bf16, forward + backward at FULL size: size-independent properties of the result
+    (ranges, weights sum to <= 1, opacity = sum of weights, merged depths sorted, every gradient finite; linearity
+    of the loss head: d loss / d rgb of the mean-square loss = 2 rgb / numel)."""
     HN.set_precision("bf16")
     torch.manual_seed(0)
-    m = models.NerfModel(EMB, n_samples_coarse=64, n_samples_fine=64, noise_std=1.0,
+    m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=1.0,
                          hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True,
                          view_fourier_dim=6).to(DEV)
-    o, d, idx = rays_for(11, 1024)
+    o, d, idx = rays_for(11, b)
     rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
             "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
     out = m(rays, {})
-    for lvl, s in (("coarse", 64), ("fine", 128)):
+    for lvl, s in (("coarse", nc), ("fine", nc + nf)):
         r = out[lvl]
-        assert r["rgb"].shape == (1024, 3) and r["weights"].shape == (1024, s)
-        assert r["warped_points"].shape == (1024, s, 7) and r["med_points"].shape == (1024, 1, 1)
+        assert r["rgb"].shape == (b, 3) and r["weights"].shape == (b, s)
+        assert r["warped_points"].shape == (b, s, 7) and r["med_points"].shape == (b, 1, 1)
         assert torch.isfinite(r["rgb"]).all() and (r["rgb"] >= 0).all() and (r["rgb"] <= 1.0 + 1e-3).all()
         assert (r["weights"] >= 0).all() and (r["weights"].sum(-1) <= 1.0 + 1e-2).all()
         assert torch.allclose(r["acc"], r["weights"][:, :-1].sum(-1), atol=1e-5)
     z = m.last_sampling["z_fine"]
     assert (z[:, 1:] >= z[:, :-1]).all(), "merged fine depths must be sorted"
+    out["fine"]["rgb"].retain_grad()
     loss = (out["coarse"]["rgb"] ** 2).mean() + (out["fine"]["rgb"] ** 2).mean()
     loss.backward()
+    assert torch.allclose(out["fine"]["rgb"].grad, 2.0 * out["fine"]["rgb"].detach() / (3 * b), rtol=1e-5, atol=1e-12)
     for k, prm in m.named_parameters():
         if k.startswith("nerf_embed"):
             continue    # unused when GLO tables are shared (SURVEY.md §2.1)
         assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
+    used = torch.unique(idx)
+    assert bool((m.warp_embed.embed.weight.grad[used.to(DEV)].abs().sum(-1) > 0).all()), "every GLO row in use gets a gradient"
 
 
 def test_config2_full_size_fp32_vs_oracle():
