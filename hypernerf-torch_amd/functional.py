@@ -105,7 +105,10 @@ class _ProgramFn(torch.autograd.Function):
         ctx.src_shapes = [None if s is None else s.shape for s in srcs]
         ctx.src_tags = [None if s is None else getattr(s, "_hn_embed", None) for s in srcs]
         ctx.stash, ctx.masks = stash, masks
-        ctx.outs = outs
+        # detached aliases: the backward only needs the values.  Keeping the returned tensors themselves on ctx would
+        # close a reference cycle output -> grad_fn (this node) -> ctx -> output that neither Python's collector nor
+        # autograd can break: every eager training step would leak its outputs and sources (~10 MB at config 2)
+        ctx.outs = [o.detach() for o in outs]
         return tuple(outs)
 
     @staticmethod

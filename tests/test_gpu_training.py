@@ -176,6 +176,38 @@ def test_training_tracks_the_cpu_oracle():
     _record("TrainStep vs CPU oracle + torch Adam: loss curve, 16 steps", "max rel", rel.max(), 2e-3)
 
 
+def test_eager_training_steps_do_not_leak_device_memory():
+    """Eager (no HIP graph) training: device memory in use must not grow from step to step.  (The program autograd
+    node once kept its own outputs alive through a reference cycle: ~10 MB per step at config 2, 288 GB after 27,000
+    steps — found by a 5,000-iteration PSNR run.)"""
+    HN.set_precision("bf16")
+    m = models.NerfModel(EMB, n_samples_coarse=32, n_samples_fine=32, noise_std=1.0, **KW).to(DEV)
+    arena = HN.ParamArena(m.parameters())
+    opt = HN.ArenaAdam(arena, lr=1e-4)
+    o, d, idx = rays_for(61, 256)
+    rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+            "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+    gt = H.uniform(61, "gt", (256, 3), 0, 1).to(DEV)
+    from hypernerf_torch_amd.losses import MSELoss
+    lf = MSELoss()
+    used = []
+    for it in range(12):
+        loss = lf(m(rays, {}), gt)
+        loss.backward()
+        opt.step()
+        del loss
+        torch.cuda.synchronize()
+        used.append(torch.cuda.memory_allocated())
+    assert max(used[4:]) == min(used[4:]), f"device memory in use changes from step to step: {used}"
+    # a forward pass in training mode that is never back-propagated must be released as well
+    for it in range(4):
+        out = m(rays, {})
+        del out
+        torch.cuda.synchronize()
+        used.append(torch.cuda.memory_allocated())
+    assert used[-1] == used[-2] == used[4], used
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # two data-parallel ranks on ONE GPU (gloo): the N>1 code path of TrainStep end to end
 # ------------------------------------------------------------------------------------------------------------------

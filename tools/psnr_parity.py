@@ -70,6 +70,11 @@ def run(precision, seed=0):
         loss.backward()
         opt.step()
         sched.step()
+        if os.environ.get("HN_PSNR_DEBUG") and it % 1000 == 0:
+            import resource
+            print(f"[{precision} seed {seed} it {it}] cuda alloc {torch.cuda.memory_allocated() >> 20} MiB reserved "
+                  f"{torch.cuda.memory_reserved() >> 20} MiB host maxrss {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss >> 10} MiB "
+                  f"fds {len(os.listdir('/proc/self/fd'))}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     m.eval()
