@@ -1117,8 +1117,16 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     }
   };
 
-  // STAGES-1 stages in flight.  Every wave issues the same number of LDS-DMA instructions for every FULL stage,
-  // so "all but the youngest k stages landed" is vmcnt(k * per_stage) (the last, partial stage only lowers it).
+  // STAGES-1 stages in flight.  A wave issues `per_stage` LDS-DMA instructions for every FULL stage and `last_cnt`
+  // (<= per_stage) for the last one, which may be partial.  "Stage s has landed" = at most as many instructions
+  // outstanding as were issued AFTER it — counted exactly: allowing younger * per_stage while the partial stage is
+  // among the younger ones would let per_stage - last_cnt loads of stage s itself still be in flight (a race that
+  // small jobs, whose stages are all issued back to back, did hit: stale LDS in the product, flaky gradients).
+  const int nb_last = nb - (nstage - 1) * bps;          // blocks of the last stage
+  int last_cnt = 0;
+#pragma unroll
+  for (int i = 0; i < MAXSLOT; ++i)
+    if ((sinfo[i] >> 1) < nb_last) ++last_cnt;
 #ifdef HN_PROF   // diagnostic build: wave 0 of every 97th workgroup sums the cycles of its four phases per stage
   long long* prof_buf = (long long*)tab.b[HN_MAX_WGRAD_BATCH - 1].jobs;     // set by hn_set_wgrad_prof
   const bool prof_on = prof_buf != nullptr && tab.n < HN_MAX_WGRAD_BATCH && (blockIdx.x % 97) == 0 && wave == 0;
@@ -1128,10 +1136,13 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   for (int s0 = 0; s0 < STAGES - 1 && s0 < nstage; ++s0) issue(s0);
   for (int s = 0; s < nstage; ++s) {
     const int younger = min(STAGES - 2, nstage - 1 - s);     // stages issued after stage s that may stay in flight
+    // the last stage is among them exactly when fewer than STAGES-1 stages remain behind s
+    const int allowed = (younger > 0 && nstage - 1 - s <= STAGES - 2) ? (younger - 1) * per_stage + last_cnt
+                                                                      : younger * per_stage;
 #ifdef HN_PROF
     if (prof_on) HN_TS(t0_);
 #endif
-    hn_wait_vmcnt(younger * per_stage);
+    hn_wait_vmcnt(allowed);
 #ifdef HN_PROF
     if (prof_on) HN_TS(t1_);
 #endif

@@ -208,6 +208,19 @@ def test_eager_training_steps_do_not_leak_device_memory():
     assert used[-1] == used[-2] == used[4], used
 
 
+def test_results_do_not_depend_on_stale_memory_or_timing():
+    """tools/poison_probe.py as a test: the model is run on a clean allocator and again after the allocator has been
+    poisoned (every later torch.empty() returns NaN- / 3.4e38- / 1000-filled memory); every output and every gradient
+    must come out the same within 2 % of its scale — anything else was computed from memory nobody wrote, or by a race
+    (this is what found the counted-vmcnt race of the weight-gradient kernel's last, partial LDS stage: small jobs
+    read LDS that had not landed yet, a handful of gradient tensors came out wrong every few runs)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import poison_probe
+    bad = poison_probe.probe(cases=("bendy_cond", "axis"), arena_modes=(False, True),
+                             sizes=((96, 32, 32), (100, 16, 24)), verbose=False)
+    assert not bad, bad[:8]
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # two data-parallel ranks on ONE GPU (gloo): the N>1 code path of TrainStep end to end
 # ------------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,90 @@
+"""Diagnostic: find reads of uninitialised device memory.  The caching allocator is 'poisoned' — big buffers filled
+with NaN bit patterns are allocated and released, so that every later torch.empty() returns NaN-filled memory — and the
+model is run again: any output or gradient that differs from the clean run (or is not finite) was computed from memory
+nobody wrote."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import hashprng as H                                              # noqa: E402
+import hypernerf_torch_amd as HN                                  # noqa: E402
+from gpu_common import DEV, EMB, load_hash, rays_for              # noqa: E402
+from hypernerf_torch_amd.hypernerf import models                  # noqa: E402
+
+CASES = {"bendy_cond": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True),
+         "axis": dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_nerf_embed=True, use_alpha_cond=True),
+         "nowarp_cond": dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=True, use_alpha_cond=True)}
+
+
+def poison(pattern):
+    bufs = []
+    for mb in (2048, 1024, 512, 256, 128, 64, 64, 32, 32, 16, 16, 8, 8, 4, 4, 2, 2, 1, 1):
+        t = torch.empty(mb << 18, dtype=torch.int32, device=DEV)
+        t.fill_(pattern)
+        bufs.append(t)
+    small = [torch.full((n,), pattern, dtype=torch.int32, device=DEV) for n in (128, 512, 2048, 8192, 32768) for _ in range(8)]
+    torch.cuda.synchronize()
+    del bufs, small
+
+
+def run(m, rays, rng, gt, arena_mode):
+    for p in m.parameters():
+        if arena_mode:
+            p.grad.zero_()
+        else:
+            p.grad = None
+    out = m(rays, {}, rng=rng)
+    loss = ((out["coarse"]["rgb"] - gt) ** 2).mean() + ((out["fine"]["rgb"] - gt) ** 2).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    res = {f"{l}/{k}": out[l][k].detach().clone() for l in out for k in ("rgb", "depth", "acc", "weights", "warped_points")}
+    res.update({"d " + k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    return res
+
+
+def probe(precisions=("bf16", "fp32"), cases=tuple(CASES), arena_modes=(False, True),
+          sizes=((96, 32, 32), (40, 8, 8), (100, 16, 24)), verbose=True):
+    """Returns the list of (description, tensor name, error, scale) that differ between a clean run and runs on a
+    poisoned allocator (or between repeated runs: a race shows up the same way)."""
+    bad = []
+    for prec in precisions:
+        for case in cases:
+            kw = CASES[case]
+            for arena_mode in arena_modes:
+                for (b, nc, nf) in sizes:
+                    HN.set_precision(prec)
+                    m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, **kw)
+                    load_hash(m, 77)
+                    m = m.to(DEV)
+                    if arena_mode:
+                        arena = HN.ParamArena(m.parameters())      # noqa: F841 (keeps the views alive)
+                    o, d, idx = rays_for(77, b)
+                    rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                            "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+                    rng = {"t_rand": H.uniform(77, "t", (b, nc), 0, 1).to(DEV), "u": H.uniform(77, "u", (b, nf), 0, 1).to(DEV),
+                           "noise_coarse": (H.normal(77, "n1", (b, nc, 1)) * 0.5).to(DEV),
+                           "noise_fine": (H.normal(77, "n2", (b, nc + nf, 1)) * 0.5).to(DEV)}
+                    gt = H.uniform(77, "gt", (b, 3), 0, 1).to(DEV)
+                    clean = run(m, rays, rng, gt, arena_mode)
+                    # NaN / huge / 1000.0 as fp32 words; as bf16 pairs: (NaN, 0) / (3.4e38, 3.4e38) / (1000, 0)
+                    for pattern in (0x7fc00000, 0x7f7f7f7f, 0x447a0000):
+                        poison(pattern)
+                        got = run(m, rays, rng, gt, arena_mode)
+                        for k, v in got.items():
+                            ref = clean[k]
+                            scale = float(ref.abs().max()) + 1e-30
+                            err = float((v - ref).abs().max()) if torch.isfinite(v).all() else float("inf")
+                            if not err <= 2e-2 * scale:
+                                what = f"{prec} {case} arena={arena_mode} b={b} nc={nc} nf={nf} pattern={pattern:#x}"
+                                bad.append((what, k, err, scale))
+                                if verbose:
+                                    print(f"UNINIT? {what}: {k} err {err:.3g} scale {scale:.3g}")
+    HN.set_precision("bf16")
+    return bad
+
+
+if __name__ == "__main__":
+    print("suspicious tensors:", len(probe()))
