@@ -16,7 +16,10 @@ from hypernerf_torch_amd.hypernerf import models                  # noqa: E402
 
 CASES = {"bendy_cond": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True),
          "axis": dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_nerf_embed=True, use_alpha_cond=True),
-         "nowarp_cond": dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=True, use_alpha_cond=True)}
+         "nowarp_cond": dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=True, use_alpha_cond=True),
+         # BASELINE config 5: SE3Field warp (own program + hn_se3_apply) in front of the gathered template
+         "se3_axis": dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_nerf_embed=True,
+                          use_alpha_cond=True)}
 
 
 def poison(pattern):
@@ -46,7 +49,7 @@ def run(m, rays, rng, gt, arena_mode):
 
 
 def probe(precisions=("bf16", "fp32"), cases=tuple(CASES), arena_modes=(False, True),
-          sizes=((96, 32, 32), (40, 8, 8), (100, 16, 24)), verbose=True):
+          sizes=((96, 32, 32), (40, 8, 8), (100, 16, 24), (13, 7, 5), (1024, 64, 64)), verbose=True):
     """Returns the list of (description, tensor name, error, scale) that differ between a clean run and runs on a
     poisoned allocator (or between repeated runs: a race shows up the same way)."""
     bad = []
@@ -57,6 +60,9 @@ def probe(precisions=("bf16", "fp32"), cases=tuple(CASES), arena_modes=(False, T
                 for (b, nc, nf) in sizes:
                     HN.set_precision(prec)
                     m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, **kw)
+                    if case == "se3_axis":
+                        from hypernerf_torch_amd.hypernerf import warping
+                        m.warp_field = warping.SE3Field(in_ch=3)
                     load_hash(m, 77)
                     m = m.to(DEV)
                     if arena_mode:
@@ -77,7 +83,10 @@ def probe(precisions=("bf16", "fp32"), cases=tuple(CASES), arena_modes=(False, T
                             ref = clean[k]
                             scale = float(ref.abs().max()) + 1e-30
                             err = float((v - ref).abs().max()) if torch.isfinite(v).all() else float("inf")
-                            if not err <= 2e-2 * scale:
+                            # forward tensors: no atomics anywhere on their path -> bit-identical from run to run;
+                            # gradients: float atomics land in a different order -> 1e-4 of the tensor's scale
+                            tol = 0.0 if not k.startswith("d ") else 1e-4 * scale
+                            if not err <= tol:
                                 what = f"{prec} {case} arena={arena_mode} b={b} nc={nc} nf={nf} pattern={pattern:#x}"
                                 bad.append((what, k, err, scale))
                                 if verbose:
