@@ -452,6 +452,43 @@ def test_empty_ray_batch():
     assert res["rgb_fine"].shape == (0, 3) and res["depth_coarse"].shape == (0,)
 
 
+def test_config2_full_size_bf16_vs_fp32_mode():
+    """BASELINE config 2 at full size, the throughput mode against the parity mode on the same weights and draws
+    (fp32 mode itself is held to the oracle at this size by test_config2_full_size_fp32_vs_oracle): forward within
+    1e-2 of the tensor scale, the WHOLE gradient (1.5 M entries) within a relative L2 of 0.2 and a cosine of >= 0.98 —
+    the small-batch bf16 bounds must also hold where every kernel runs its persistent multi-tile loops."""
+    b, nc, nf, seed = 1024, 64, 64, 85
+    o, d, idx = rays_for(seed, b)
+    rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1).to(DEV), "u": H.uniform(seed, "u", (b, nf), 0, 1).to(DEV),
+           "noise_coarse": (H.normal(seed, "n1", (b, nc, 1)) * 0.5).to(DEV),
+           "noise_fine": (H.normal(seed, "n2", (b, nc + nf, 1)) * 0.5).to(DEV)}
+    gt = H.uniform(seed, "gt", (b, 3), 0, 1).to(DEV)
+    rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+            "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+    res = {}
+    try:
+        for prec in ("fp32", "bf16"):
+            HN.set_precision(prec)
+            m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, view_fourier_dim=6,
+                                 **CASES["bendy_cond"])
+            load_hash(m, seed)
+            m = m.to(DEV)
+            out = m(rays, {}, rng=rng)
+            loss = ((out["coarse"]["rgb"] - gt) ** 2).mean() + ((out["fine"]["rgb"] - gt) ** 2).mean()
+            loss.backward()
+            g = torch.cat([p.grad.reshape(-1).double() for k, p in m.named_parameters() if p.grad is not None])
+            res[prec] = ({k: out["coarse"][k].detach() for k in ("rgb", "depth", "acc", "weights")}, g, float(loss.detach()))
+    finally:
+        HN.set_precision("bf16")
+    for k, v in res["bf16"][0].items():
+        assert_close(v, res["fp32"][0][k].cpu(), 1e-2, f"config2 full size bf16 vs fp32 mode coarse/{k}", elementwise=False)
+    assert abs(res["bf16"][2] - res["fp32"][2]) <= 2e-3 * res["fp32"][2]
+    gb, gf = res["bf16"][1], res["fp32"][1]
+    rel = float((gb - gf).norm() / gf.norm())
+    cos = float((gb * gf).sum() / (gb.norm() * gf.norm()))
+    assert rel <= 0.2 and cos >= 0.98, f"whole gradient bf16 vs fp32 mode: rel L2 {rel:.3f}, cosine {cos:.4f}"
+
+
 LEGACY = {
     "c_only": dict(N_samples=16, N_importance=0, perturb=0, noise_std=0),
     "c_only_pert_noise": dict(N_samples=16, N_importance=0, perturb=1, noise_std=1),
