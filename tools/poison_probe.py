@@ -97,3 +97,47 @@ def probe(precisions=("bf16", "fp32"), cases=tuple(CASES), arena_modes=(False, T
 
 if __name__ == "__main__":
     print("suspicious tensors:", len(probe()))
+
+
+def repeat_probe(case="bendy_cond", prec="bf16", size=(1024, 64, 64), n=200, arena_mode=True):
+    """Race hunt: the same step `n` times on identical inputs.  Forward tensors must repeat bit for bit; gradients to
+    1e-5 of their scale (float atomics).  Returns the deviations found."""
+    kw = CASES[case]
+    b, nc, nf = size
+    HN.set_precision(prec)
+    m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, **kw)
+    if case == "se3_axis":
+        from hypernerf_torch_amd.hypernerf import warping
+        m.warp_field = warping.SE3Field(in_ch=3)
+    load_hash(m, 78)
+    m = m.to(DEV)
+    if arena_mode:
+        arena = HN.ParamArena(m.parameters())      # noqa: F841
+    o, d, idx = rays_for(78, b)
+    rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+            "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+    rng = {"t_rand": H.uniform(78, "t", (b, nc), 0, 1).to(DEV), "u": H.uniform(78, "u", (b, nf), 0, 1).to(DEV),
+           "noise_coarse": (H.normal(78, "n1", (b, nc, 1)) * 0.5).to(DEV),
+           "noise_fine": (H.normal(78, "n2", (b, nc + nf, 1)) * 0.5).to(DEV)}
+    gt = H.uniform(78, "gt", (b, 3), 0, 1).to(DEV)
+    first = run(m, rays, rng, gt, arena_mode)
+    bad = []
+    for it in range(n):
+        got = run(m, rays, rng, gt, arena_mode)
+        for k, v in got.items():
+            ref = first[k]
+            scale = float(ref.abs().max()) + 1e-30
+            err = float((v - ref).abs().max()) if torch.isfinite(v).all() else float("inf")
+            tol = 0.0 if not k.startswith("d ") else 1e-5 * scale
+            if not err <= tol:
+                bad.append((it, k, err, scale))
+    HN.set_precision("bf16")
+    return bad
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "repeat":
+    for case in CASES:
+        for prec, n, size in (("bf16", 200, (1024, 64, 64)), ("fp32", 40, (1024, 64, 64)), ("bf16", 300, (40, 8, 8)),
+                              ("bf16", 300, (100, 16, 24)), ("fp32", 100, (100, 16, 24))):
+            bad = repeat_probe(case, prec, size, n)
+            print(case, prec, size, "runs", n, "deviations", len(bad), bad[:4])
