@@ -95,7 +95,7 @@ def probe(precisions=("bf16", "fp32"), cases=tuple(CASES), arena_modes=(False, T
     return bad
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     print("suspicious tensors:", len(probe()))
 
 
@@ -141,3 +141,56 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "repeat":
                               ("bf16", 300, (100, 16, 24)), ("fp32", 100, (100, 16, 24))):
             bad = repeat_probe(case, prec, size, n)
             print(case, prec, size, "runs", n, "deviations", len(bad), bad[:4])
+
+
+def legacy_probe(prec="bf16", n_rays=50, ns=16, ni=24, verbose=True):
+    """The same for the nerf_pl path (models/rendering.render_rays, two NeRF networks)."""
+    from hypernerf_torch_amd.models import nerf as legacy_nerf
+    from hypernerf_torch_amd.models import rendering as legacy_rendering
+    HN.set_precision(prec)
+    nets = [legacy_nerf.NeRF(), legacy_nerf.NeRF()]
+    for i, n in enumerate(nets):
+        load_hash(n, 90 + i)
+        n.to(DEV)
+    emb = [legacy_nerf.Embedding(3, 10), legacy_nerf.Embedding(3, 4)]
+    o, d, _ = rays_for(91, n_rays)
+    rays = torch.cat([o, d, torch.full((n_rays, 1), 2.0), torch.full((n_rays, 1), 6.0)], 1).to(DEV)
+    rng = {"perturb_rand": H.uniform(91, "p", (n_rays, ns), 0, 1).to(DEV), "noise_coarse": H.normal(91, "n1", (n_rays, ns)).to(DEV),
+           "u": H.uniform(91, "u", (n_rays, ni), 0, 1).to(DEV), "noise_fine": H.normal(91, "n2", (n_rays, ns + ni)).to(DEV)}
+    gt = H.uniform(91, "gt", (n_rays, 3), 0, 1).to(DEV)
+
+    def once():
+        for n in nets:
+            for p in n.parameters():
+                p.grad = None
+        res = legacy_rendering.render_rays(nets, emb, rays, N_samples=ns, N_importance=ni, perturb=1.0, noise_std=1.0, rng=rng)
+        loss = ((res["rgb_coarse"] - gt) ** 2).mean() + ((res["rgb_fine"] - gt) ** 2).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        out = {k: v.detach().clone() for k, v in res.items()}
+        for i, n in enumerate(nets):
+            out.update({f"d net{i}.{k}": p.grad.detach().clone() for k, p in n.named_parameters() if p.grad is not None})
+        return out
+
+    clean = once()
+    bad = []
+    for pattern in (0x7fc00000, 0x7f7f7f7f, 0x447a0000):
+        poison(pattern)
+        got = once()
+        for k, v in got.items():
+            ref = clean[k]
+            scale = float(ref.abs().max()) + 1e-30
+            err = float((v - ref).abs().max()) if torch.isfinite(v).all() else float("inf")
+            tol = 0.0 if not k.startswith("d ") else 1e-4 * scale
+            if not err <= tol:
+                bad.append((f"legacy {prec} pattern={pattern:#x}", k, err, scale))
+                if verbose:
+                    print("UNINIT?", bad[-1])
+    HN.set_precision("bf16")
+    return bad
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "legacy":
+    for prec in ("bf16", "fp32"):
+        for shape in ((50, 16, 24), (256, 64, 64), (7, 5, 3)):
+            print(prec, shape, "suspicious:", len(legacy_probe(prec, *shape)))
