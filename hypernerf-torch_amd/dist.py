@@ -146,6 +146,11 @@ class GradSync:
                 run_held()
             self.arena.all_reduce_sum(self.group)
             return
+        if run_held is None:
+            from . import functional
+            if functional.held_wgrads():
+                raise RuntimeError("GradSync.reduce: weight-gradient jobs are being held back (splitting() was "
+                                   "active during backward) but no `run_held` was given to launch them")
         g = self.arena.grad
         h0 = dist.all_reduce(g[self.split:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if run_held is not None:
