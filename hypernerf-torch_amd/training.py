@@ -144,6 +144,11 @@ class TrainStep:
             if rng is not None:
                 for k, v in rng.items():
                     self._rng[k].copy_(v)
+        # what a captured graph froze besides the shapes: the precision mode and whether the model trains / evaluates
+        state = (F.get_precision(), self.model.training)
+        if getattr(self, "_graph_state", None) != state:
+            self._graph_state = state
+            self._graph = None
         self.optimizer.sync_hyper()      # a replayed Adam launch reads lr & co. from device memory
         if not self.use_graph:
             self._forward_backward()

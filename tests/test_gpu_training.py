@@ -222,6 +222,29 @@ def test_results_do_not_depend_on_stale_memory_or_timing():
     assert not bad, bad[:8]
 
 
+def test_train_step_recaptures_when_the_precision_mode_changes():
+    """A captured step replays the kernels of the mode it was captured in; switching hypernerf_torch_amd.set_precision
+    between steps must lead to a new capture, not to silent replays of the old mode."""
+    HN.set_precision("bf16")
+    try:
+        m = models.NerfModel(EMB, n_samples_coarse=16, n_samples_fine=16, noise_std=None, **KW).to(DEV)
+        m.use_stratified_sampling = False
+        _, _, _, rays = ray_rows(71, 64)
+        rgbs = H.uniform(71, "rgbs", (64, 3), 0.1, 0.9)
+        ts = TrainStep(m, lr=0.0, use_graph=True)                 # lr 0: every step sees the same weights
+        l_bf16 = float(ts.step(rays.to(DEV), rgbs.to(DEV))["train/loss"])
+        g1 = ts._graph
+        HN.set_precision("fp32")
+        l_fp32 = float(ts.step(rays.to(DEV), rgbs.to(DEV))["train/loss"])
+        assert ts._graph is not g1
+        eager = TrainStep(m, lr=0.0, use_graph=False)
+        l_ref = float(eager.step(rays.to(DEV), rgbs.to(DEV))["train/loss"])
+        assert abs(l_fp32 - l_ref) <= 1e-6 * abs(l_ref), (l_fp32, l_ref)
+        assert l_bf16 != l_fp32 and abs(l_bf16 - l_fp32) <= 2e-2 * abs(l_ref)
+    finally:
+        HN.set_precision("bf16")
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # two data-parallel ranks on ONE GPU (gloo): the N>1 code path of TrainStep end to end
 # ------------------------------------------------------------------------------------------------------------------
