@@ -141,6 +141,13 @@ class NerfModel(nn.Module):
         self._det_u: Dict[Any, torch.Tensor] = {}
         self.precision: Optional[str] = None   # None = package default (functional.set_precision)
 
+    def __setattr__(self, name, value):
+        # replacing a sub-module (e.g. `model.warp_field = SE3Field(...)`, BASELINE config 5) after a forward pass:
+        # the compiled level programs hold the OLD module's parameters — drop them, they are rebuilt on the next call
+        if isinstance(value, nn.Module) and "_template_calls" in self.__dict__:
+            self._template_calls.clear()
+        super().__setattr__(name, value)
+
     # ---- properties of the reference ---------------------------------------------------------
     @property
     def num_nerf_embeds(self):

@@ -489,6 +489,33 @@ def test_config2_full_size_bf16_vs_fp32_mode():
     assert rel <= 0.2 and cos >= 0.98, f"whole gradient bf16 vs fp32 mode: rel L2 {rel:.3f}, cosine {cos:.4f}"
 
 
+def test_replacing_a_submodule_after_a_forward_pass_rebuilds_the_programs():
+    """`model.warp_field = ...` after the level programs were compiled (they hold the old module's parameters)."""
+    HN.set_precision("fp32")
+    try:
+        m = models.NerfModel(EMB, n_samples_coarse=8, n_samples_fine=8, noise_std=None, **CASES["bendy_cond"]).to(DEV)
+        m.use_stratified_sampling = False
+        o, d, idx = rays_for(97, 16)
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        with torch.no_grad():
+            a = m(rays, {})["fine"]["rgb"].clone()
+            new = warping.TranslationField(in_ch=3, in_ch_embed=8).to(DEV)
+            with torch.no_grad():
+                for p_ in new.parameters():
+                    p_.mul_(3.0)
+            m.warp_field = new
+            b = m(rays, {})["fine"]["rgb"].clone()
+            fresh = models.NerfModel(EMB, n_samples_coarse=8, n_samples_fine=8, noise_std=None, **CASES["bendy_cond"]).to(DEV)
+            fresh.use_stratified_sampling = False
+            fresh.load_state_dict(m.state_dict())
+            c = fresh(rays, {})["fine"]["rgb"]
+        assert not torch.equal(a, b), "the new warp field must be used"
+        assert torch.equal(b, c), "and give what a freshly built model with the same weights gives"
+    finally:
+        HN.set_precision("bf16")
+
+
 LEGACY = {
     "c_only": dict(N_samples=16, N_importance=0, perturb=0, noise_std=0),
     "c_only_pert_noise": dict(N_samples=16, N_importance=0, perturb=1, noise_std=1),
