@@ -516,6 +516,37 @@ def test_replacing_a_submodule_after_a_forward_pass_rebuilds_the_programs():
         HN.set_precision("bf16")
 
 
+def test_deepcopy_and_pickle_of_a_model_with_compiled_programs():
+    """copy.deepcopy (EMA copies, Lightning) and torch.save(model) after a forward pass: the copy runs on ITS weights,
+    the original is untouched, the pickle round trip renders the same image."""
+    import copy
+    import io
+    HN.set_precision("fp32")
+    try:
+        m = models.NerfModel(EMB, n_samples_coarse=8, n_samples_fine=8, noise_std=None, **CASES["bendy_cond"]).to(DEV)
+        m.use_stratified_sampling = False
+        o, d, idx = rays_for(97, 16)
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        with torch.no_grad():
+            a = m(rays, {})["fine"]["rgb"].clone()
+            m2 = copy.deepcopy(m)
+            for p_ in m2.parameters():
+                p_.mul_(1.5)
+            b = m2(rays, {})["fine"]["rgb"].clone()
+            a2 = m(rays, {})["fine"]["rgb"].clone()
+        assert not torch.equal(a, b) and torch.equal(a, a2)
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        buf.seek(0)
+        m3 = torch.load(buf, weights_only=False)
+        with torch.no_grad():
+            c = m3(rays, {})["fine"]["rgb"]
+        assert torch.equal(a, c)
+    finally:
+        HN.set_precision("bf16")
+
+
 LEGACY = {
     "c_only": dict(N_samples=16, N_importance=0, perturb=0, noise_std=0),
     "c_only_pert_noise": dict(N_samples=16, N_importance=0, perturb=1, noise_std=1),
