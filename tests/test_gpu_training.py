@@ -353,6 +353,79 @@ def test_train_step_two_ranks_match_one_rank(use_graph, overlap):
     assert err <= 5e-2, f"weights after 3 data-parallel steps vs 3 one-rank steps: rel L2 of the update {err:.2e}"
 
 
+def _ddp_worker(rank, world, port, q):
+    for pth in (ROOT, os.path.join(ROOT, "tests")):
+        if pth not in sys.path:
+            sys.path.insert(0, pth)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hypernerf_torch_amd as HN2
+        from hypernerf_torch_amd.dist import shard_rays
+        from hypernerf_torch_amd.losses import MSELoss
+        HN2.set_precision("fp32")
+        m = models.NerfModel(EMB, n_samples_coarse=16, n_samples_fine=16, noise_std=None, **KW)
+        load_hash(m, 50)
+        m = m.to(DEV)
+        m.use_stratified_sampling = False
+        ddp = torch.nn.parallel.DistributedDataParallel(m, find_unused_parameters=True)   # nerf_embed is unused
+        _, _, _, rays = ray_rows(51, 64)
+        rgbs = H.uniform(51, "rgbs", (64, 3), 0.1, 0.9)
+        mine_r, mine_c = shard_rays(rays).to(DEV), shard_rays(rgbs).to(DEV)
+        from hypernerf_torch_amd.hypernerf import model_utils as MU2
+        out = ddp(MU2.prepare_ray_dict(mine_r), dict(nerf_alpha=None, warp_alpha=None, hyper_alpha=None, hyper_sheet_alpha=None))
+        MSELoss()(out, mine_c).backward()
+        g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in m.parameters()])
+        q.put((rank, g.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_model_under_torch_ddp_two_ranks():
+    """The drop-in claim for the reference's own trainer (Lightning wraps the model in DistributedDataParallel,
+    train.py:225-229): without a ParamArena the kernels return their gradients through autograd, so DDP's reducer
+    averages them like any module's — 2 ranks (gloo, one GPU) against the full-batch gradient of one process."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    got = {}
+    try:
+        for _ in range(2):
+            rank, g = q.get(timeout=240)
+            got[rank] = g
+        for p_ in procs:
+            p_.join(timeout=60)
+            assert p_.exitcode == 0
+    finally:
+        for p_ in procs:
+            if p_.is_alive():
+                p_.kill()
+    assert np.array_equal(got[0], got[1]), "DDP leaves the same averaged gradient on both ranks"
+    HN.set_precision("fp32")
+    try:
+        m = models.NerfModel(EMB, n_samples_coarse=16, n_samples_fine=16, noise_std=None, **KW)
+        load_hash(m, 50)
+        m = m.to(DEV)
+        m.use_stratified_sampling = False
+        _, _, _, rays = ray_rows(51, 64)
+        rgbs = H.uniform(51, "rgbs", (64, 3), 0.1, 0.9).to(DEV)
+        from hypernerf_torch_amd.hypernerf import model_utils as MU2
+        from hypernerf_torch_amd.losses import MSELoss
+        out = m(MU2.prepare_ray_dict(rays.to(DEV)), dict(nerf_alpha=None, warp_alpha=None, hyper_alpha=None, hyper_sheet_alpha=None))
+        MSELoss()(out, rgbs).backward()
+        ref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in m.parameters()]).cpu()
+    finally:
+        HN.set_precision("bf16")
+    err = float((torch.from_numpy(got[0]) - ref).norm() / ref.norm())
+    assert err <= 1e-5, f"DDP-averaged shard gradients vs the full-batch gradient: rel L2 {err:.2e}"
+
+
 def test_eval_image_loop_vs_oracle_deterministic(tmp_path):
     """the per-image loop of eval.py:145-178 — rays generated on the device, the fine level rendered
     in chunks with deterministic sampling (use_stratified_sampling=False: linspace depths and linspace u,
