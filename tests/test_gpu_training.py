@@ -353,6 +353,39 @@ def test_train_step_two_ranks_match_one_rank(use_graph, overlap):
     assert err <= 5e-2, f"weights after 3 data-parallel steps vs 3 one-rank steps: rel L2 of the update {err:.2e}"
 
 
+def test_model_under_autocast_and_grad_scaler():
+    """The reference trains with Lightning `precision=16` (opt.py:44): native AMP = torch.autocast(float16) around the
+    forward pass + a GradScaler around backward / optimizer.  The HIP path keeps its own precision mode (autocast only
+    re-types ATen ops): same loss as without autocast, finite unscaled gradients, the scaler's step goes through."""
+    HN.set_precision("bf16")
+    m = models.NerfModel(EMB, n_samples_coarse=16, n_samples_fine=16, noise_std=None, **KW).to(DEV)
+    m.use_stratified_sampling = False
+    _, _, _, rays = ray_rows(73, 64)
+    rgbs = H.uniform(73, "rgbs", (64, 3), 0.1, 0.9).to(DEV)
+    from hypernerf_torch_amd.hypernerf import model_utils as MU2
+    from hypernerf_torch_amd.losses import MSELoss
+    extra = dict(nerf_alpha=None, warp_alpha=None, hyper_alpha=None, hyper_sheet_alpha=None)
+    rd = MU2.prepare_ray_dict(rays.to(DEV))
+    plain = float(MSELoss()(m(rd, extra), rgbs).detach())
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    before = [p.detach().clone() for p in m.parameters()]
+    with torch.autocast(device_type="cuda", dtype=torch.float16):
+        out = m(rd, extra)
+        loss = MSELoss()(out, rgbs)
+    assert out["fine"]["rgb"].dtype == torch.float32
+    assert abs(float(loss.detach()) - plain) <= 1e-6 * plain
+    scaler.scale(loss).backward()
+    scaler.unscale_(opt)
+    grads = [p.grad for p in m.parameters() if p.grad is not None]
+    assert grads and all(torch.isfinite(g).all() for g in grads)
+    scaler.step(opt)
+    scaler.update()
+    assert scaler.get_scale() == 1024.0, "no inf/nan was found, the scale must not have been backed off"
+    moved = sum(float((p.detach() - b).abs().sum()) for p, b in zip(m.parameters(), before))
+    assert moved > 0.0
+
+
 def _ddp_worker(rank, world, port, q):
     for pth in (ROOT, os.path.join(ROOT, "tests")):
         if pth not in sys.path:
