@@ -210,4 +210,10 @@ def to_device_bytes(arr: np.ndarray, device) -> torch.Tensor:
     raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
     if raw.size == 0:
         raw = np.zeros(16, dtype=np.uint8)
-    return torch.from_numpy(raw.copy()).to(device)
+    t = torch.from_numpy(raw.copy()).to(device)
+    # tables are uploaded once and then read by launches on WHATEVER stream is current later on: make the upload
+    # complete now instead of merely stream-ordered (never inside a stream capture, where the first use has long
+    # happened in the warm-up runs)
+    if t.is_cuda and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(t.device).synchronize()
+    return t
