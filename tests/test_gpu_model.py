@@ -700,6 +700,57 @@ def test_config2_full_size_fp32_vs_oracle():
         HN.set_precision("bf16")
 
 
+def test_config5_full_size_fp32_vs_oracle():
+    """BASELINE config 5 (SE3Field warp + axis-aligned slice, GLO conditions) at its FULL size, 1024 rays x (64+64), in
+    fp32 mode against the CPU oracle: coarse tensors element-wise to 1e-4, fine-index agreement, loss, and the whole
+    weight gradient (SE3 trunk and heads through `hn_se3_apply`, template with the table gathered in-kernel)."""
+    HN.set_precision("fp32")
+    try:
+        kw = dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_nerf_embed=True, use_alpha_cond=True)
+        b, nc, nf, seed = 1024, 64, 64, 87
+        m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=1.0, view_fourier_dim=6, **kw)
+        m.warp_field = warping.SE3Field(in_ch=3)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        sd = H.fill_state_dict(shapes, seed)
+        for k in sd:        # small rigid motions: the template re-encodes warped points with sin(2^9 x)
+            if k.startswith(("warp_field.w_net.logit_layer", "warp_field.v_net.logit_layer")):
+                sd[k] = sd[k] * 0.02
+        m.load_state_dict(sd)
+        m = m.to(DEV)
+        o, d, idx = rays_for(seed, b)
+        rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1),
+               "noise_coarse": H.normal(seed, "n1", (b, nc, 1)), "noise_fine": H.normal(seed, "n2", (b, nc + nf, 1))}
+        cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=1.0, view_fourier_dim=6, warp_kind="se3", **kw)
+        torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = O.nerf_model_forward(p, cfg, o, d, idx, rng)
+        gt = H.uniform(seed, "gt", (b, 3), 0, 1)
+        ref_loss = O.mse_loss(ref, gt)
+        ref_loss.backward()
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        out = m(rays, {}, rng={k: v.to(DEV) for k, v in rng.items()})
+        for k in ("rgb", "depth", "acc", "weights", "warped_points"):
+            assert_close(out["coarse"][k], ref["coarse"][k], 1e-4, f"config5 full size coarse/{k}")
+        same = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).float().mean().item()
+        assert same > 0.999, f"only {same:.5f} of the fine-sample indices agree"
+        loss = ((out["coarse"]["rgb"] - gt.to(DEV)) ** 2).mean() + ((out["fine"]["rgb"] - gt.to(DEV)) ** 2).mean()
+        assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 5e-5 * max(1.0, float(ref_loss.detach()))
+        loss.backward()
+        named = dict(m.named_parameters())
+        ks = [k for k in named if p[k].grad is not None and named[k].grad is not None]
+        ga = torch.cat([named[k].grad.detach().cpu().double().reshape(-1) for k in ks])
+        ra = torch.cat([p[k].grad.double().reshape(-1) for k in ks])
+        tot = float(ra.norm())
+        rel = float((ga - ra).norm()) / tot
+        assert rel <= 5e-3, f"config 5 full size: whole-gradient rel L2 {rel:.2e} against the oracle"
+        for k in ks:
+            if float(p[k].grad.norm()) >= 1e-3 * tot:
+                assert_grad_close(named[k].grad, p[k].grad, 2e-2, f"config5 full size d {k}", frobenius=True)
+    finally:
+        HN.set_precision("bf16")
+
+
 @pytest.mark.gpu
 def test_param_arena_gradients_match_autograd_path():
     """The same step with parameters attached to a ParamArena (dW accumulated straight into the flat gradient
