@@ -46,6 +46,12 @@ def mlp_layers(mlp: "MLP", prefix: str, input_aux: Optional[AuxSpec], main_in: O
         raise NotImplementedError(f"{prefix}: skip connections need generated (aux) inputs only")
     layers: List[Layer] = []
     n_hidden = len(mlp.linears)
+    if (n_hidden - 1) in mlp.skips:
+        # the reference concatenates the input after EVERY layer in `skips` (modules.py:122-124), also the last hidden
+        # one, and then dies in logit_layer (in_features = width, modules.py:104) with a shape RuntimeError
+        raise RuntimeError(f"{prefix}: skip after the last hidden layer — logit_layer expects {mlp.width} input "
+                           f"features, the concatenation has more (the reference fails the same way: mat1 and mat2 "
+                           f"shapes cannot be multiplied)")
     for i, lin in enumerate(mlp.linears):
         if i == 0:
             ly = Layer(f"{prefix}.linears.0", lin.weight, lin.bias,

@@ -260,7 +260,13 @@ class Program:
                                     f"{ly.name}: more than {L.HN_MAX_COMPS} distinct encoded source components")
                         if ft.need_grad and (ft.src, ft.comp) not in self.dsrc_map:
                             used = set(self.dsrc_map.values()) | self.reserved_slots
-                            self.dsrc_map[(ft.src, ft.comp)] = next(k for k in range(L.HN_DSRC_COMPS + 1) if k not in used)
+                            free = [k for k in range(L.HN_DSRC_COMPS) if k not in used]
+                            if not free:
+                                raise NotImplementedError(
+                                    f"{self.name}: gradients w.r.t. more than {L.HN_DSRC_COMPS} source components (one "
+                                    "accumulator tile per block); stand-alone modules with wider differentiable inputs "
+                                    "are outside the render path")
+                            self.dsrc_map[(ft.src, ft.comp)] = free[0]
             if ly.main is None and ly.aux is None:
                 raise ValueError(f"{ly.name}: layer without input")
             main_in = 0

@@ -52,6 +52,66 @@ def test_mlp_standalone(precision):
     assert_close(y, y_ref, TOL[precision], "MLP forward", elementwise=precision == "fp32")
 
 
+def test_mlp_random_shapes_fuzz():
+    """modules.MLP on 40 seeded random configurations (input width 1..190, hidden width 8..256 incl. widths that are
+    no multiple of 32, depth 0..8, random skip layers, 1..40 outputs incl. the wide-output path, 1..700 points, output
+    activations) in fp32 mode against the oracle's MLP: forward 1e-4 element-wise, input and weight gradients 5e-3.
+    A configuration the machine does not implement must say so (NotImplementedError), not mis-compute."""
+    HN.set_precision("fp32")
+    rs = np.random.RandomState(1234)
+    done = refused = 0
+    why = []
+    try:
+        for case in range(40):
+            in_ch = int(rs.choice([1, 3, 7, 20, 33, 64, 71, 115, 167, 190]))
+            width = int(rs.choice([8, 24, 32, 53, 64, 96, 128, 160, 200, 256]))
+            depth = int(rs.randint(0, 9))
+            out_ch = int(rs.choice([1, 2, 3, 4, 5, 8, 17, 32, 40]))
+            n_hidden = max(depth, 1)
+            skips = sorted(set(int(v) for v in rs.randint(0, max(1, n_hidden - 1), size=rs.randint(0, 3)))) if n_hidden > 1 else []
+            if rs.rand() < 0.1:
+                skips = sorted(set(skips + [n_hidden - 1]))          # the reference shape-errors on this one
+            out_act = [None, torch.nn.ReLU(), torch.nn.Sigmoid()][int(rs.randint(0, 3))]
+            n = int(rs.choice([1, 5, 31, 32, 33, 100, 257, 700]))
+            what = f"fuzz {case}: in {in_ch} width {width} depth {depth} out {out_ch} skips {skips} act {type(out_act).__name__} n {n}"
+            try:
+                m = modules.MLP(in_ch=in_ch, out_ch=out_ch, depth=depth, width=width, skips=skips, output_activation=out_act)
+                sd = load_hash(m, 300 + case)
+                m = m.to(DEV)
+                x = H.uniform(300 + case, "x", (n, in_ch), -1, 1)
+                want_dx = in_ch <= 24          # the machine differentiates w.r.t. <= 32 source components
+                xg = x.to(DEV).requires_grad_(want_dx)
+                y = m(xg)
+            except NotImplementedError as e:
+                refused += 1
+                why.append(what + " -> " + str(e)[:90])
+                continue
+            except RuntimeError:
+                y = None         # must be a configuration the reference fails on as well (checked below)
+            tp = {"m." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+            xr = x.clone().requires_grad_(True)
+            okw = dict(depth=depth, skips=tuple(skips),
+                       out_act={"NoneType": "none", "ReLU": "relu", "Sigmoid": "sigmoid"}[type(out_act).__name__])
+            if y is None:
+                with pytest.raises(RuntimeError):
+                    O.mlp(tp, "m", xr, **okw)
+                refused += 1
+                continue
+            y_ref = O.mlp(tp, "m", xr, **okw)
+            assert_close(y, y_ref, 1e-4, what + " forward")
+            g = H.uniform(300 + case, "g", tuple(y_ref.shape), -1, 1)
+            (y_ref * g).sum().backward()
+            (y * g.to(DEV)).sum().backward()
+            if want_dx:
+                assert_grad_close(xg.grad, xr.grad, 5e-3, what + " d x")
+            for k, prm in m.named_parameters():
+                assert_grad_close(prm.grad, tp["m." + k].grad, 5e-3, what + " d " + k)
+            done += 1
+    finally:
+        HN.set_precision("bf16")
+    assert done >= 24, (done, refused, why)       # the rest: explicit refusals (wide sigmoid outputs, ...)
+
+
 @pytest.mark.parametrize("n", [64, 100, 1000])
 def test_translation_field(precision, n):
     tf = warping.TranslationField(in_ch=3, in_ch_embed=8)
