@@ -107,6 +107,59 @@ def test_composite_vs_oracle(s, variant):
     assert_grad_close(raw_g.grad, raw_t.grad, 5e-5, "d raw")
 
 
+def test_per_ray_kernels_random_sizes_fuzz():
+    """Compositing (HyperNeRF variant) and inverse-CDF sampling on 30 seeded random (rays, coarse, fine) sizes — 1..300
+    rays, 2..200 coarse and 1..200 fine samples, rays with all-zero, one-hot and huge densities — against the oracle:
+    composite outputs 2e-5, its gradients 5e-5 / 2e-4, fine-sample indices / samples / merged sorted depths BIT-exact."""
+    rs = np.random.RandomState(4321)
+    for case in range(30):
+        b = int(rs.choice([1, 2, 3, 4, 5, 17, 64, 129, 300]))
+        nc = int(rs.choice([2, 3, 5, 8, 16, 33, 64, 100, 128, 200]))
+        nf = int(rs.choice([1, 2, 7, 16, 64, 65, 128, 200]))
+        seed = 500 + case
+        what = f"fuzz {case}: rays {b} coarse {nc} fine {nf}"
+        o, d, _ = rays_for(seed, b)
+        rgb = H.uniform(seed, "rgb", (b, nc, 3), 0, 1)
+        raw = H.uniform(seed, "raw", (b, nc), -3, 6)
+        raw[0] = -40.0                                   # softplus -> 0: a ray with (almost) all-zero weights
+        if b > 1:
+            raw[1] = -40.0
+            raw[1, nc // 2] = 30.0                       # one-hot
+        if b > 2:
+            raw[2] = 30.0                                # everything absorbed by the first sample
+        z, _ = torch.sort(H.uniform(seed, "z", (b, nc), 0, 1), dim=-1)
+        warped = H.uniform(seed, "wp", (b, nc, 7), -1, 1)
+        rgb_t, raw_t = rgb.clone().requires_grad_(True), raw.clone().requires_grad_(True)
+        ref = O.volumetric_rendering(rgb_t, torch.nn.functional.softplus(raw_t), z, d, white_bg=False)
+        rgb_g, raw_g = rgb.to(DEV).requires_grad_(True), raw.to(DEV).requires_grad_(True)
+        outs = F.composite(rgb_g, raw_g, None, z.to(DEV), d.to(DEV), warped.to(DEV), variant=0, white_bg=False,
+                           sample_at_infinity=True, want_median=True)
+        for i, k in enumerate(["rgb", "depth", "acc", "weights", "med_depth"]):
+            assert_close(outs[i], ref[k], 2e-5, f"{what} composite {k}")
+        gr = [H.uniform(seed, f"g{i}", tuple(ref[k].shape), -1, 1) for i, k in enumerate(["rgb", "depth", "acc", "weights"])]
+        sum((ref[k] * g).sum() for k, g in zip(["rgb", "depth", "acc", "weights"], gr)).backward()
+        sum((outs[i] * gr[i].to(DEV)).sum() for i in range(4)).backward()
+        assert_grad_close(rgb_g.grad, rgb_t.grad, 5e-5, what + " d rgb")
+        # 2e-4: in the smallest cases every ray is one of the degenerate ones and the whole gradient is ~1e-4
+        assert_grad_close(raw_g.grad, raw_t.grad, 2e-4, what + " d raw")
+        if nc >= 3:
+            w = ref["weights"].detach()
+            u = H.uniform(seed, "u", (b, nf), 0, 1)
+            mid = 0.5 * (z[:, 1:] + z[:, :-1])
+            z_ref, p_ref, inds_ref = O.sample_pdf(mid, w[:, 1:-1], o, d, z, u)
+            z_all, pts, inds, zs = F.sample_pdf(outs[3].detach(), z.to(DEV), u.to(DEV), o.to(DEV), d.to(DEV))
+            wg = outs[3].detach().cpu()
+            if torch.equal(wg, w):                      # same fp32 weights in -> bit-identical sampling out
+                assert torch.equal(inds.cpu(), inds_ref), what + " indices"
+                assert torch.equal(z_all.cpu(), z_ref), what + " merged depths"
+                assert torch.equal(pts.cpu(), p_ref), what + " points"
+            else:                                       # weights differ in the last ulp: sample from the oracle's
+                z_all, pts, inds, zs = F.sample_pdf(w.to(DEV), z.to(DEV), u.to(DEV), o.to(DEV), d.to(DEV))
+                assert torch.equal(inds.cpu(), inds_ref), what + " indices (oracle weights)"
+                assert torch.equal(z_all.cpu(), z_ref), what + " merged depths (oracle weights)"
+            assert bool((z_all[:, 1:] >= z_all[:, :-1]).all()), what + " sortedness"
+
+
 def test_sample_pdf_bitexact_indices():
     b, nc, nf = 333, 64, 128
     o, d, _ = rays_for(7, b)
