@@ -607,6 +607,69 @@ def test_deepcopy_and_pickle_of_a_model_with_compiled_programs():
         HN.set_precision("bf16")
 
 
+def test_model_random_sizes_fuzz():
+    """The full render path on 16 seeded random (configuration, rays, coarse, fine) combinations — 1..65 rays, 3..70
+    coarse and 1..70 fine samples, i.e. ragged last blocks, samples-per-ray that are and are not multiples of 32 (the
+    in-kernel and the fall-back embedding gradient), all four warp / slice structures — in fp32 mode against the oracle:
+    coarse tensors 1e-4 element-wise, fine-index agreement, whole-gradient relative L2 <= 1e-2."""
+    HN.set_precision("fp32")
+    rs = np.random.RandomState(2468)
+    cases = {"bendy_cond": (CASES["bendy_cond"], "translation"), "axis": (CASES["axis"], "translation"),
+             "nowarp_cond": (CASES["nowarp_cond"], "translation"),
+             "se3_axis": (dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_nerf_embed=True,
+                               use_alpha_cond=True), "se3")}
+    try:
+        for it in range(16):
+            name = list(cases)[it % 4]
+            kw, warp_kind = cases[name]
+            b = int(rs.choice([1, 2, 7, 33, 65]))
+            nc = int(rs.choice([3, 4, 8, 31, 32, 33, 64, 70]))      # 2 coarse samples leave no pdf bin: the reference errors
+            nf = int(rs.choice([1, 2, 8, 32, 33, 64, 70]))
+            seed = 700 + it
+            what = f"model fuzz {it}: {name} rays {b} coarse {nc} fine {nf}"
+            m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, view_fourier_dim=6, **kw)
+            if warp_kind == "se3":
+                m.warp_field = warping.SE3Field(in_ch=3)
+            sd = H.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed)
+            for k in sd:
+                if k.startswith(("warp_field.w_net.logit_layer", "warp_field.v_net.logit_layer")):
+                    sd[k] = sd[k] * 0.02
+            m.load_state_dict(sd)
+            m = m.to(DEV)
+            o, d, idx = rays_for(seed, b)
+            if b == 1:
+                idx = idx[:, None]      # (1,) indices lose their batch axis in the reference's GLOEmbed (modules.py:164-165)
+            rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1),
+                   "noise_coarse": H.normal(seed, "n1", (b, nc, 1)) * 0.5,
+                   "noise_fine": H.normal(seed, "n2", (b, nc + nf, 1)) * 0.5}
+            cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, view_fourier_dim=6,
+                             warp_kind=warp_kind, **kw)
+            p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+            ref = O.nerf_model_forward(p, cfg, o, d, idx, rng)
+            gt = H.uniform(seed, "gt", (b, 3), 0, 1)
+            O.mse_loss(ref, gt).backward()
+            rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                    "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+            out = m(rays, {}, rng={k: v.to(DEV) for k, v in rng.items()})
+            for k in ("rgb", "depth", "acc", "weights", "warped_points"):
+                assert_close(out["coarse"][k], ref["coarse"][k], 1e-4, f"{what} coarse/{k}")
+            same = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).float().mean().item()
+            assert same >= 0.99, f"{what}: only {same:.4f} of the fine-sample indices agree"
+            if same == 1.0:
+                for k in ("rgb", "depth", "acc", "weights"):
+                    assert_close(out["fine"][k], ref["fine"][k], 1e-4, f"{what} fine/{k}")
+            loss = ((out["coarse"]["rgb"] - gt.to(DEV)) ** 2).mean() + ((out["fine"]["rgb"] - gt.to(DEV)) ** 2).mean()
+            loss.backward()
+            named = dict(m.named_parameters())
+            ks = [k for k in named if p[k].grad is not None and named[k].grad is not None]
+            ga = torch.cat([named[k].grad.detach().cpu().double().reshape(-1) for k in ks])
+            ra = torch.cat([p[k].grad.double().reshape(-1) for k in ks])
+            rel = float((ga - ra).norm() / ra.norm())
+            assert rel <= (1e-2 if same == 1.0 else 5e-2), f"{what}: whole-gradient rel L2 {rel:.2e}"
+    finally:
+        HN.set_precision("bf16")
+
+
 LEGACY = {
     "c_only": dict(N_samples=16, N_importance=0, perturb=0, noise_std=0),
     "c_only_pert_noise": dict(N_samples=16, N_importance=0, perturb=1, noise_std=1),
