@@ -607,12 +607,16 @@ def test_deepcopy_and_pickle_of_a_model_with_compiled_programs():
         HN.set_precision("bf16")
 
 
-def test_model_random_sizes_fuzz():
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_model_random_sizes_fuzz(prec):
     """The full render path on 16 seeded random (configuration, rays, coarse, fine) combinations — 1..65 rays, 3..70
     coarse and 1..70 fine samples, i.e. ragged last blocks, samples-per-ray that are and are not multiples of 32 (the
     in-kernel and the fall-back embedding gradient), all four warp / slice structures — in fp32 mode against the oracle:
-    coarse tensors 1e-4 element-wise, fine-index agreement, whole-gradient relative L2 <= 1e-2."""
-    HN.set_precision("fp32")
+    coarse tensors 1e-4 element-wise, fine-index agreement, whole-gradient relative L2 <= 1e-2; and in bf16 mode against
+    the oracle under the same arithmetic contract (O.bf16_operands): coarse tensors 2e-3 of their scale, whole gradient
+    <= 0.2 (tiny batches: a single ReLU decision on a rounding boundary is a visible share of the gradient)."""
+    import contextlib
+    HN.set_precision(prec)
     rs = np.random.RandomState(2468)
     cases = {"bendy_cond": (CASES["bendy_cond"], "translation"), "axis": (CASES["axis"], "translation"),
              "nowarp_cond": (CASES["nowarp_cond"], "translation"),
@@ -645,17 +649,21 @@ def test_model_random_sizes_fuzz():
             cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, view_fourier_dim=6,
                              warp_kind=warp_kind, **kw)
             p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-            ref = O.nerf_model_forward(p, cfg, o, d, idx, rng)
             gt = H.uniform(seed, "gt", (b, 3), 0, 1)
-            O.mse_loss(ref, gt).backward()
+            with (O.bf16_operands() if prec == "bf16" else contextlib.nullcontext()):
+                ref = O.nerf_model_forward(p, cfg, o, d, idx, rng)
+                O.mse_loss(ref, gt).backward()
             rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
                     "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
             out = m(rays, {}, rng={k: v.to(DEV) for k, v in rng.items()})
             for k in ("rgb", "depth", "acc", "weights", "warped_points"):
-                assert_close(out["coarse"][k], ref["coarse"][k], 1e-4, f"{what} coarse/{k}")
+                if prec == "fp32":
+                    assert_close(out["coarse"][k], ref["coarse"][k], 1e-4, f"{what} coarse/{k}")
+                else:
+                    assert_close(out["coarse"][k], ref["coarse"][k], 2e-3, f"bf16 {what} coarse/{k}", elementwise=False)
             same = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).float().mean().item()
-            assert same >= 0.99, f"{what}: only {same:.4f} of the fine-sample indices agree"
-            if same == 1.0:
+            assert same >= (0.99 if prec == "fp32" else 0.9), f"{what}: only {same:.4f} of the fine-sample indices agree"
+            if same == 1.0 and prec == "fp32":
                 for k in ("rgb", "depth", "acc", "weights"):
                     assert_close(out["fine"][k], ref["fine"][k], 1e-4, f"{what} fine/{k}")
             loss = ((out["coarse"]["rgb"] - gt.to(DEV)) ** 2).mean() + ((out["fine"]["rgb"] - gt.to(DEV)) ** 2).mean()
@@ -665,7 +673,8 @@ def test_model_random_sizes_fuzz():
             ga = torch.cat([named[k].grad.detach().cpu().double().reshape(-1) for k in ks])
             ra = torch.cat([p[k].grad.double().reshape(-1) for k in ks])
             rel = float((ga - ra).norm() / ra.norm())
-            assert rel <= (1e-2 if same == 1.0 else 5e-2), f"{what}: whole-gradient rel L2 {rel:.2e}"
+            bound = (1e-2 if same == 1.0 else 5e-2) if prec == "fp32" else 0.2
+            assert rel <= bound, f"{prec} {what}: whole-gradient rel L2 {rel:.2e}"
     finally:
         HN.set_precision("bf16")
 
