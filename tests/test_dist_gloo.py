@@ -1,6 +1,7 @@
 """Data-parallel host logic on CPU: 2 processes, gloo backend (the GPU run uses the same code over RCCL).
 Covers ray sharding, the single flat gradient all-reduce (with a parameter that received no gradient on one
 rank), the two-bucket overlapped reduction (GradSync) and the pixel all-gather."""
+import datetime
 import os
 import socket
 import sys
@@ -27,7 +28,7 @@ def _worker(rank, world, port, q):
     from hypernerf_torch_amd.dist import GradBucket, all_gather_pixels, shard_range, shard_rays
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     try:
         rays = torch.arange(11 * 9, dtype=torch.float32).view(11, 9)
         mine = shard_rays(rays)

@@ -4,6 +4,7 @@ graph replays sees the updated weights, an out-of-range GLO index fails loudly, 
 oracle trained with torch.optim.Adam on the same batches and draws, and 2 data-parallel ranks (gloo, both on this one
 GPU) reproduce the single-rank gradient and stay bit-identical to each other."""
 import math
+import datetime
 import os
 import socket
 import sys
@@ -263,7 +264,7 @@ def _dp_worker(rank, world, port, use_graph, overlap, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     try:
         import hypernerf_torch_amd as HN2
         from hypernerf_torch_amd.dist import shard_rays
@@ -393,7 +394,7 @@ def _ddp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     try:
         import hypernerf_torch_amd as HN2
         from hypernerf_torch_amd.dist import shard_rays
