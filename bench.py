@@ -2,7 +2,12 @@
 """Benchmark of the HyperNeRF render hot path on MI355X (BASELINE.json metric: ray-samples/s, forward + backward).
 
     python bench.py --gpus N --steps K --warmup W [--config {1,2,3,5}]
-(N>1: launched by torch.distributed.run, one rank per GPU, RCCL).  A "step" = one training step of the reference's
+N>1: one rank per GPU over RCCL.  Under `torch.distributed.run` (WORLD_SIZE set) this process IS a rank; started
+plainly, `--gpus N` makes it the LAUNCHER (the reference's Lightning Trainer spawns `devices=num_gpus` ranks itself,
+train.py:224-229): it starts N child rank processes BEFORE any GPU call of its own, relays rank 0's JSON line and
+exits with the children's worst return code.  Every run fails (rc != 0) unless the collective library itself counted
+as many ranks as `--gpus` asked for.  `--launch-plan` prints the N commands + environments instead of running them.
+A "step" = one training step of the reference's
 hot loop on one synthetic ray batch already resident in HBM: model forward (coarse + fine), MSE loss, backward,
 gradient all-reduce (N>1), Adam step.  Workloads (BASELINE.json `configs`):
     2 (default, the configuration the metric is quoted on)  NerfModel use_warp + bendy_sheet, 1024 rays x (64+64), bf16
@@ -57,6 +62,8 @@ def parse():
                     help="data-parallel runs: all-reduce the gradient buffer in two buckets, the first in flight while the "
                          "weight gradients of the second are computed (dist.GradSync).  Off by default: splitting the "
                          "batched weight-gradient launch costs ~0.2 ms on one MI355X, more than the all-reduce it hides")
+    ap.add_argument("--launch-plan", action="store_true",
+                    help="print the rank launch plan of --gpus N (commands + per-rank environment) as JSON and exit")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (process group + all-reduce between two graphs) even with one rank")
     a = ap.parse_args()
@@ -105,7 +112,8 @@ def build_workload(a, dev, rank):
             call = coarse._calls[next(iter(coarse._calls))] if hasattr(coarse, "_calls") else None
             return {} if call is None else {"NeRF": (call.program, b * a.nc)}
         workload = f"legacy render_rays, NeRF coarse only, {b} rays x {a.nc} samples, fwd+bwd+Adam"
-        return fwd_bwd, params, programs, workload, coarse
+        data = dict(o=o, d=d, near=near, far=far, target=target.cpu(), emb=emb)
+        return fwd_bwd, params, programs, workload, coarse, data
     kw = dict(hyper_slice_method="bendy_sheet", use_warp=True, use_nerf_embed=True, use_alpha_cond=True)
     if a.kind == "se3":
         kw = dict(hyper_slice_method="axis_aligned_plane", hyper_slice_out_dim=8, use_warp=True, use_nerf_embed=True,
@@ -130,14 +138,98 @@ def build_workload(a, dev, rank):
         return {name: (prog, pts) for name, prog, pts in model.compiled_programs(b)}
     what = "SE3Field warp + axis_aligned_plane" if a.kind == "se3" else "use_warp bendy_sheet"
     workload = (f"NerfModel {what} nerf_embed+alpha_cond, {b} rays x ({a.nc}+{a.nf}) samples per GPU, fwd+bwd+Adam")
-    return fwd_bwd, list(model.parameters()), programs, workload, model
+    data = dict(o=o, d=d, ids=ids, target=target.cpu(), model_kw=kw, extra=extra)
+    return fwd_bwd, list(model.parameters()), programs, workload, model, data
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_plan(n, argv, port=None, env=None):
+    """The N rank processes of `bench.py --gpus N`: [(command, environment overrides)], rank 0 first.  Pure host
+    logic (tests/test_host_api.py::test_bench_launch_plan): same script, same arguments, the torch.distributed
+    environment contract per rank, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    env = dict(os.environ if env is None else env)
+    port = int(env.get("MASTER_PORT") or port or _free_port())
+    args = [x for x in argv if x != "--launch-plan"]
+    plan = []
+    for r in range(n):
+        e = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+             "MASTER_ADDR": env.get("MASTER_ADDR", "127.0.0.1"), "MASTER_PORT": str(port),
+             # dmabuf IPC: without it RCCL's cross-process handle exchange fails on this driver
+             "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+        plan.append(([sys.executable, os.path.abspath(__file__)] + args, e))
+    return plan
+
+
+def launch_ranks(a, argv):
+    """Parent of a plain `bench.py --gpus N` (N > 1): no GPU call happens in this process.  Children are ordinary
+    child processes (never an exec of a process that touched the GPU); rank 0's stdout is relayed, its JSON line
+    checked against --gpus, and the exit code is the worst of the children's."""
+    import subprocess
+    plan = launch_plan(a.gpus, argv)
+    if a.launch_plan:
+        print(json.dumps({"n_ranks": len(plan), "ranks": [{"cmd": c, "env": e} for c, e in plan]}))
+        return 0
+    procs = []
+    for r, (cmd, e) in enumerate(plan):
+        procs.append(subprocess.Popen(cmd, env={**os.environ, **e}, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None, text=True))
+    # rank 0's stdout is drained by a thread; the main loop watches for a rank that died (the survivors would sit in
+    # the rendezvous / a collective until its timeout) and ends exactly the processes it started
+    import threading
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    rd.join(timeout=10.0)
+    out0 = buf[0] if buf else ""
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln)
+    rc = max((abs(r) for r in rcs), default=0)
+    if rc == 0 and line is None:
+        print("bench.py launcher: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    if line is not None:
+        res = json.loads(line)
+        seen = res.get("config", {}).get("ranks_seen_by_collective")
+        if res.get("n_gpus") != a.gpus or seen != a.gpus:
+            print(f"bench.py launcher: asked for {a.gpus} ranks, result says n_gpus={res.get('n_gpus')}, "
+                  f"collective saw {seen}", file=sys.stderr)
+            rc = rc or 3
+        res["config"]["launched_by"] = "bench.py (self-spawned ranks)"
+        print(json.dumps(res), flush=True)
+    return rc
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.launch_plan):
+        sys.exit(launch_ranks(a, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        # the driver's contract: `--gpus N` under a launcher that started N ranks; anything else would report a
+        # curve point for a job that is not the one asked for
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(4)
     # one process per GPU over RCCL ("nccl" on ROCm).  HN_DIST_BACKEND=gloo + more ranks than GPUs is a debugging
     # aid only: it runs the N>1 code path (graph capture, gradient all-reduce, Adam) on a single-GPU box.
     local = local % max(1, torch.cuda.device_count())
@@ -156,7 +248,7 @@ def main():
     from hypernerf_torch_amd.dist import all_gather_pixels
 
     HN.set_precision(a.precision)
-    fwd_bwd, params, programs, workload, model = build_workload(a, dev, rank)
+    fwd_bwd, params, programs, workload, model, data = build_workload(a, dev, rank)
     use_graph = not a.no_graph
     # parameters and gradients live in one flat arena each: the kernels accumulate dW straight into it, Adam steps
     # one tensor, and data parallelism SUM-all-reduces the gradient buffer in place (the 1/N sits in the Adam kernel).
@@ -253,12 +345,16 @@ def main():
         "ms_per_step_spread": [1e3 * min(reps) / a.steps, 1e3 * max(reps) / a.steps],
     }
 
+    res["build"] = L.build_id()
     if rank == 0 and not a.no_roofline:
         res.update(roofline(a, L, fwd_bwd, opt, programs(), dt / a.steps, b))
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.kind == "hypernerf":
-        res["cpu_baseline"] = cpu_baseline(a)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(a, model, data, dev)
     if dp:
         dist.destroy_process_group()
+    if ranks_seen != world or world != a.gpus:
+        print(f"bench.py: the collective counted {ranks_seen} ranks, WORLD_SIZE={world}, --gpus {a.gpus}", file=sys.stderr)
+        sys.exit(3)
     # the JSON line is the LAST thing on stdout: RCCL writes a "Librccl path" banner through C stdio, which would
     # otherwise be flushed at exit, after the line
     sys.stdout.flush()
@@ -311,7 +407,7 @@ def roofline(a, L, fwd_bwd, opt, progs, step_s, b):
         dom = max(kern, key=lambda k: kern[k][0])
         ms_step, launches = kern[dom]
         pk = per_kernel[sym[dom]]["mfma"]
-        traffic = _pmc_traffic(a)
+        traffic, traffic_note = _pmc_traffic(a)
         # rays 36 B + target 12 B + outputs 20 B per ray; weights read once forward and once backward
         # in the operand dtype; fp32 gradients written once
         uniq = {id(p): p for p, _ in progs.values()}
@@ -336,6 +432,8 @@ def roofline(a, L, fwd_bwd, opt, progs, step_s, b):
             hbm["wasted_ratio"] = traffic["bytes_per_step"] / alg_bytes
             hbm["traffic_source"] = traffic["source"]
             rl["traffic"] = traffic["per_kernel_launch"].get(sym[dom])
+        else:
+            rl["traffic_note"] = traffic_note
         out["roofline"] = rl
         out["hbm"] = hbm
     out["step_tflops"] = 3.0 * flops_pass / step_s / 1e12
@@ -352,28 +450,39 @@ def _points_by_program(progs):
 
 def _pmc_traffic(a):
     """HBM bytes per step measured with rocprofv3 PMC passes on this configuration (tools/collect_profiles.sh ->
-    tools/make_profiles.py -> profiles/rNN_traffic_configC.json), newest round first; None if not collected."""
+    tools/make_profiles.py -> profiles/rNN_traffic_configC.json), newest round first.  A summary is only quoted when
+    it was collected on THESE kernels (its `build.kernel_src_sha256` equals the running build's): a round that changes
+    the stash must not report last round's bytes.  Returns (summary | None, note | None)."""
     import glob
+    from hypernerf_torch_amd import _lib as L
+    mine = L.build_id()["kernel_src_sha256"]
     hits = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_config{a.config}.json")), reverse=True)
+    stale = None
     for h in hits:
         try:
             t = json.load(open(h))
-            if t.get("rays") == a.rays and t.get("nc") == a.nc and t.get("nf") == a.nf:
-                t["source"] = os.path.relpath(h, ROOT)
-                return t
         except (OSError, ValueError):
-            pass
-    return None
+            continue
+        if not (t.get("rays") == a.rays and t.get("nc") == a.nc and t.get("nf") == a.nf):
+            continue
+        theirs = (t.get("build") or {}).get("kernel_src_sha256")
+        if theirs == mine:
+            t["source"] = os.path.relpath(h, ROOT)
+            return t, None
+        stale = stale or (f"{os.path.relpath(h, ROOT)} was collected on kernel sources {theirs}, this build is {mine}: "
+                          "not quoted")
+    return None, stale or "no PMC summary for this configuration under profiles/"
 
 
-def cpu_baseline(a):
+def cpu_baseline(a, model, data, dev):
     """The CPU oracle (oracle/hypernerf_oracle.py, validated against the reference's own outputs) timed on this
-    node's host cores, fp32, forward + backward: on the FULL ray batch of the configuration when that fits the time
-    budget (config 2: 1024 rays), else on a 2048-ray sample (config 3; per-ray-sample rate)."""
-    import hashprng as H
-    from gpu_common import EMB, rays_for
-    from hypernerf_torch_amd.hypernerf.models import NerfModel
+    node's host cores, fp32, forward + backward, on the SAME rays, targets and weights as the GPU run (the model's
+    current state_dict) and one seeded set of random draws: the FULL ray batch of the configuration when that fits
+    the time budget (configs 1, 2, 5), else its first 2048 rays (config 3; per-ray-sample rate).  One 64-ray warm-up,
+    then >= 3 timed iterations; `value` is the MEDIAN.  The same draws are then pushed through the GPU model once
+    (`check`): the thing measured and the baseline beside it computed the same render."""
     from oracle import hypernerf_oracle as O
+    from hypernerf_torch_amd.hypernerf import model_utils
     try:
         cores = len(os.sched_getaffinity(0))        # cores this process may actually use (cgroup-aware)
     except AttributeError:
@@ -381,32 +490,67 @@ def cpu_baseline(a):
     cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
     b = min(a.rays, 2048)
-    kw = dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True)
-    m = NerfModel(EMB, n_samples_coarse=a.nc, n_samples_fine=a.nf, noise_std=1.0, view_fourier_dim=6, **kw)
-    p = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-    cfg = O.ModelCfg(n_samples_coarse=a.nc, n_samples_fine=a.nf, noise_std=1.0, view_fourier_dim=6, **kw)
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    gt = data["target"][:b]
+    o, d = data["o"][:b], data["d"][:b]
+    if a.kind == "legacy":
+        rays = torch.cat([o, d, data["near"][:b], data["far"][:b]], dim=1)
+        rng = {"perturb_rand": torch.rand(b, a.nc, generator=g), "noise_coarse": torch.randn(b, a.nc, generator=g)}
 
-    def one(n):
-        o, d, idx = rays_for(1, n)
-        gt = H.uniform(1, "gt", (n, 3), 0, 1)
-        rng = {"t_rand": torch.rand(n, a.nc), "noise_coarse": torch.randn(n, a.nc, 1),
-               "u": torch.rand(n, a.nf), "noise_fine": torch.randn(n, a.nc + a.nf, 1)}
+        def one(n):
+            out = O.legacy_render_rays([p], (10, 4), rays[:n], {k: v[:n] for k, v in rng.items()}, N_samples=a.nc,
+                                       perturb=1.0, noise_std=1.0)
+            ((out["rgb_coarse"] - gt[:n]) ** 2).mean().backward()
+            return out["rgb_coarse"].detach()
+
+        def gpu_once():
+            from hypernerf_torch_amd.models.rendering import render_rays
+            res = render_rays([model], data["emb"], rays.to(dev), N_samples=a.nc, N_importance=0, perturb=1.0,
+                              noise_std=1.0, rng={k: v.to(dev) for k, v in rng.items()})
+            return res["rgb_coarse"]
+    else:
+        idx = data["ids"][:b].reshape(-1).long()
+        kw = dict(data["model_kw"])
+        kw.pop("use_warp", None)
+        cfg = O.ModelCfg(n_samples_coarse=a.nc, n_samples_fine=a.nf, noise_std=1.0, view_fourier_dim=6,
+                         warp_kind="se3" if a.kind == "se3" else "translation", **kw)
+        rng = {"t_rand": torch.rand(b, a.nc, generator=g), "noise_coarse": torch.randn(b, a.nc, 1, generator=g),
+               "u": torch.rand(b, a.nf, generator=g), "noise_fine": torch.randn(b, a.nc + a.nf, 1, generator=g)}
+
+        def one(n):
+            out = O.nerf_model_forward(p, cfg, o[:n], d[:n], idx[:n], {k: v[:n] for k, v in rng.items()})
+            O.mse_loss(out, gt[:n]).backward()
+            return out["fine"]["rgb"].detach()
+
+        def gpu_once():
+            rays = torch.cat([o, d, torch.zeros(b, 1), torch.ones(b, 1), data["ids"][:b]], dim=1).to(dev)
+            out = model(model_utils.prepare_ray_dict(rays), data["extra"], rng={k: v.to(dev) for k, v in rng.items()})
+            return out["fine"]["rgb"]
+
+    def clear():
         for v in p.values():
             v.grad = None
-        out = O.nerf_model_forward(p, cfg, o, d, idx, rng)
-        O.mse_loss(out, gt).backward()
 
-    one(64)                         # warm-up (thread pool, allocator) on a small batch
-    t0 = time.perf_counter()
-    n = 0
-    while n < 2 or (time.perf_counter() - t0 < 12.0 and n < 10):
-        one(b)
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return {"value": b * (a.nc + a.nf) / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{b} rays x ({a.nc}+{a.nf}) samples (the configuration's batch"
-                                      f"{'' if b == a.rays else ', capped at 2048 rays'}), fp32, fwd+bwd (no "
-                                      f"optimizer), {n} timed iterations after a 64-ray warm-up"}
+    one(min(64, b))                 # warm-up (thread pool, allocator) on a small batch
+    times, ref = [], None
+    t_all = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_all < 12.0 and len(times) < 9):
+        clear()
+        t0 = time.perf_counter()
+        ref = one(b)
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    with torch.no_grad():
+        diff = float((gpu_once().float().cpu() - ref).abs().max())
+    n_s = a.nc + a.nf
+    return {"value": b * n_s / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{b} rays x {n_s} samples of the GPU run's own batch (same rays, targets, weights"
+                      f"{'' if b == a.rays else '; first 2048 rays'}), fp32, fwd+bwd (no optimizer), median of "
+                      f"{len(times)} timed iterations after a 64-ray warm-up",
+            "s_per_iteration": times,
+            "check": {"gpu_vs_cpu_rgb_max_abs_diff": diff, "gpu_precision": a.precision,
+                      "note": "the GPU model rendered the baseline's rays with the baseline's draws"}}
 
 
 if __name__ == "__main__":

@@ -95,7 +95,7 @@ EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_
            "hn_mlp_wgrad_batched", "hn_mlp_workspace_bytes",
            "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf",
            "hn_embed_gather", "hn_embed_backward", "hn_se3_apply_forward", "hn_se3_apply_backward", "hn_generate_rays", "hn_adam_step",
-           "hn_mse_loss_forward", "hn_mse_loss_backward",
+           "hn_mse_loss_forward", "hn_mse_loss_backward", "hn_depth_index",
            "hn_probe_mfma"]
 
 _lib = None
@@ -135,6 +135,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(res.stdout + res.stderr)
     return LIB_PATH
+
+
+def build_id() -> dict:
+    """Identity of the kernels a measurement was taken on: sha256 over the kernel sources (+ the build-time tuning
+    macros in the environment) and over the built library.  bench.py prints it; tools/make_profiles.py stamps the PMC
+    traffic summaries with it, and bench.py only quotes a summary whose source hash equals the running build's."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "hn_common.h"), HEADER]:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    for macro in ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX"):
+        h.update(f"{macro}={os.environ.get(macro, '')};".encode())
+    lib = None
+    if os.path.exists(LIB_PATH):
+        with open(LIB_PATH, "rb") as f:
+            lib = hashlib.sha256(f.read()).hexdigest()[:16]
+    return {"kernel_src_sha256": h.hexdigest()[:16], "lib_sha256": lib}
 
 
 def load():

@@ -350,6 +350,48 @@ extern "C" int hn_composite_backward(const HnCompositeArgs* a, hnStream_t stream
 }
 
 // ------------------------------------------------------------------------------------------------
+// median depth from given weights: model_utils.compute_opaqueness_mask / compute_depth_index / compute_depth_map
+// (hypernerf/model_utils.py:319-362).  One wave per ray; the same inclusive scan + ballot the compositing kernel
+// uses for its own `med_depth`.  mask[b, s] = 1 at the FIRST sample whose inclusive weight sum reaches the
+// threshold (0 everywhere if none does), index = argmax(mask) (0 if none), depth = sum(mask * z).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hn_depth_index_kernel(const float* __restrict__ w, const float* __restrict__ z,
+                                                             int n_rays, int S, float thr, int64_t* out_idx,
+                                                             float* out_depth, float* out_mask) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const size_t row = (size_t)ray * S;
+  float csum = 0.0f;
+  int found = -1;
+  for (int k = 0; k * 64 < S; ++k) {
+    const int s = k * 64 + lane;
+    const bool in = s < S;
+    const float cs = csum + hn_wave_incl_scan_add(in ? w[row + s] : 0.0f, lane);
+    const unsigned long long m = __ballot(in && cs >= thr);
+    if (found < 0 && m != 0ull) found = k * 64 + __ffsll((long long)m) - 1;
+    csum = __shfl(cs, 63, 64);
+  }
+  if (out_mask != nullptr)
+    for (int s = lane; s < S; s += 64) out_mask[row + s] = s == found ? 1.0f : 0.0f;
+  if (lane == 0) {
+    if (out_idx != nullptr) out_idx[ray] = found < 0 ? 0 : found;
+    if (out_depth != nullptr) out_depth[ray] = (found >= 0 && z != nullptr) ? z[row + found] : 0.0f;
+  }
+}
+
+extern "C" int hn_depth_index(const float* weights, const float* z, int n_rays, int n_samples, float threshold,
+                              int64_t* out_index, float* out_depth, float* out_mask, hnStream_t stream) {
+  if (n_rays < 0 || n_samples <= 0) return -2;
+  if (n_rays == 0) return 0;
+  if (weights == nullptr || (out_depth != nullptr && z == nullptr)) return -3;
+  hipLaunchKernelGGL(hn_depth_index_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, weights, z,
+                     n_rays, n_samples, threshold, out_index, out_depth, out_mask);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // inverse-CDF sampling + merge sort (one wave per ray; LDS: cdf/bins + 512-entry sort buffer)
 // ------------------------------------------------------------------------------------------------
 constexpr int HN_PDF_MAXC = 256;   // max coarse samples

@@ -81,6 +81,59 @@ def sample_pdf(bins, weights, origins, directions, z_vals, num_coarse_samples, u
     return z_all, pts
 
 
+def posenc_orig(x, N_freqs, log_scale=True):
+    """[x, sin(2^0 x), cos(2^0 x), ..., sin(2^(N-1) x), cos(2^(N-1) x)] in blocks of C channels — the
+    "SinusoidalEncoder" (reference: hypernerf/model_utils.py:234-246).  `log_scale=False` takes the reference's
+    linspace(0, N-1, N) bands (frequency 0 included).  One HIP launch (hn_posenc), differentiable w.r.t. x."""
+    L.require_gpu(x)
+    n = int(N_freqs)
+    bands = 2 ** torch.linspace(0, n - 1, n) if log_scale else torch.linspace(0, n - 1, n)      # the reference's ATen ops
+    return F.posenc(x, bands.to(x.device), identity=True, jax_cos=False)
+
+
+def posenc(x, min_deg, max_deg, use_identity=False, alpha=None):
+    """JAX-style encoder of the SE3 field (reference: hypernerf/model_utils.py:255-274), quirks kept: scales =
+    2**linspace(min_deg, max_deg, steps=max_deg-min_deg) (non-integer exponents), cos as sin(x + 0.5*3.1415926),
+    layout (*, F, 2, C) flattened; `alpha` windowing is disabled upstream (:264-266) and ignored here too."""
+    L.require_gpu(x)
+    scales = 2. ** torch.linspace(min_deg, max_deg, steps=max_deg - min_deg)
+    return F.posenc(x, scales.to(x.device), identity=bool(use_identity), jax_cos=True)
+
+
+def _depth_index(weights, z_vals, depth_threshold, want_index, want_depth, want_mask):
+    L.require_gpu(weights)
+    L.load()
+    import ctypes as C
+    shp = weights.shape
+    s = shp[-1]
+    w = weights.detach().reshape(-1, s).contiguous().float()
+    b = w.shape[0]
+    z = z_vals.detach().expand(shp).reshape(-1, s).contiguous().float() if z_vals is not None else None
+    idx = torch.empty(b, dtype=torch.int64, device=w.device) if want_index else None
+    dep = torch.empty(b, dtype=torch.float32, device=w.device) if want_depth else None
+    msk = torch.empty(b, s, dtype=torch.float32, device=w.device) if want_mask else None
+    L.launch("hn_depth_index", L.ptr(w), L.ptr(z), C.c_int(b), C.c_int(s), C.c_float(float(depth_threshold)),
+             L.ptr(idx), L.ptr(dep), L.ptr(msk), L.stream_handle())
+    return (idx.view(shp[:-1]) if idx is not None else None, dep.view(shp[:-1]) if dep is not None else None,
+            msk.view(shp).to(weights.dtype) if msk is not None else None)
+
+
+def compute_opaqueness_mask(weights, depth_threshold=0.5):
+    """1.0 at the first sample whose accumulated weight reaches the threshold (reference: model_utils.py:319-340)."""
+    return _depth_index(weights, None, depth_threshold, False, False, True)[2]
+
+
+def compute_depth_index(weights, depth_threshold=0.5):
+    """Sample index of the median depth accumulation (reference: model_utils.py:342-345)."""
+    return _depth_index(weights, None, depth_threshold, True, False, False)[0]
+
+
+def compute_depth_map(weights, z_vals, depth_threshold=0.5):
+    """Depth by median accumulation = z at compute_depth_index, 0 where the threshold is never reached
+    (reference: model_utils.py:347-362)."""
+    return _depth_index(weights, z_vals, depth_threshold, False, True, False)[1]
+
+
 def get_posenc_ch_orig(in_ch, N_freq, log_scale=True):
     """Channel count of posenc_orig (reference: hypernerf/model_utils.py:248-252), no device work."""
     return in_ch * (1 + 2 * N_freq)

@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* hnStream_t; /* hipStream_t */
 
-#define HN_VERSION 200
+#define HN_VERSION 300
 
 /* numeric modes of the MLP machine */
 #define HN_MODE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode (<=1e-4 vs oracle) */
@@ -305,6 +305,13 @@ typedef struct {
 } HnCompositeArgs;
 int hn_composite_forward(const HnCompositeArgs* a, hnStream_t stream);
 int hn_composite_backward(const HnCompositeArgs* a, hnStream_t stream);
+
+/* Median depth from given compositing weights: model_utils.compute_opaqueness_mask / compute_depth_index /
+ * compute_depth_map (hypernerf/model_utils.py:319-362).  weights, z: (B, S) row-major.  Outputs (each may be NULL):
+ * index (B) int64 = first sample whose inclusive weight sum reaches `threshold` (0 if none does: argmax of an
+ * all-zero mask), depth (B) = z at that sample (0 if none), mask (B, S) = 1 at that sample, 0 elsewhere. */
+int hn_depth_index(const float* weights, const float* z, int n_rays, int n_samples, float threshold,
+                   int64_t* out_index, float* out_depth, float* out_mask, hnStream_t stream);
 
 /* Inverse-CDF hierarchical sampling + merge-sort + points.  model_utils.piecewise_constant_pdf /
  * sample_pdf (hypernerf/model_utils.py:160-232) == legacy models/rendering.py:14-55,225-233.

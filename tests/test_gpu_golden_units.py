@@ -60,6 +60,59 @@ def test_g01_posenc_hip(golden_dir):
         assert_rel_close(y, g[key], 1e-4, 1e-2, f"posenc (JAX style) {key}")
 
 
+def test_g01_through_the_model_utils_names(golden_dir):
+    """The drop-in names of hypernerf/model_utils.py:234-274 (`posenc_orig`, `posenc`) with the reference's
+    signatures, on the reference's own G1 vectors; `log_scale=False` and the gradient against the oracle/autograd."""
+    g = G(golden_dir, "g01_posenc")
+    for n in (4, 6, 7, 10):
+        for tag in ("2", "3"):
+            assert_rel_close(MU.posenc_orig(T(g[f"x{tag}_{n}"]), n), g[f"y{tag}_{n}"], 1e-4, 1e-2,
+                             f"model_utils.posenc_orig N={n} {tag}-D")
+            assert MU.get_posenc_ch_orig(g[f"x{tag}_{n}"].shape[-1], n) == g[f"y{tag}_{n}"].shape[-1]
+    for key, lo, hi, ident in (("yj_id", 0, 8, True), ("yj", 0, 8, False), ("yj_24", 2, 6, False)):
+        assert_rel_close(MU.posenc(T(g["xj"]), lo, hi, use_identity=ident), g[key], 1e-4, 1e-2,
+                         f"model_utils.posenc {key}")
+        assert MU.get_posenc_ch(g["xj"].shape[-1], lo, hi, ident) == g[key].shape[-1]
+    x = H.uniform(3, "pe_lin", (50, 3), -1, 1)
+    bands = torch.linspace(0, 4, 5)
+    ref = torch.cat([x] + [f(b * x) for b in bands for f in (torch.sin, torch.cos)], -1)     # model_utils.py:238-246
+    assert_rel_close(MU.posenc_orig(x.to(DEV), 5, log_scale=False), ref, 1e-4, 1e-2, "posenc_orig log_scale=False")
+    xr = x.clone().requires_grad_(True)
+    gw = H.normal(3, "pe_g", (50, 3 * 13))
+    (O.posenc_orig(xr, 6) * gw).sum().backward()
+    xd = x.clone().to(DEV).requires_grad_(True)
+    (MU.posenc_orig(xd, 6) * gw.to(DEV)).sum().backward()
+    assert_close(xd.grad, xr.grad, 1e-4, "d posenc_orig / dx")
+
+
+@pytest.mark.parametrize("inf,wb", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_g09_depth_index_names(golden_dir, inf, wb):
+    """model_utils.compute_depth_index / compute_depth_map / compute_opaqueness_mask (model_utils.py:319-362) on the
+    reference's own weights: its depth index and median depth (G9), exact; the mask against the oracle's restatement,
+    also for a threshold no ray reaches (all-zero mask, index 0, depth 0) and (B, R, S)-shaped weights."""
+    g = G(golden_dir, "g09_volrend")
+    w, z = T(g[f"weights_inf{inf}_wb{wb}"]), T(g["z"])
+    idx = MU.compute_depth_index(w)
+    assert idx.dtype == torch.int64 and np.array_equal(idx.cpu().numpy(), g[f"dindex_inf{inf}_wb{wb}"])
+    assert np.array_equal(MU.compute_depth_map(w, z).cpu().numpy(), g[f"med_depth_inf{inf}_wb{wb}"])
+    mask_ref, idx_ref = O.median_depth_index(w.cpu())
+    assert torch.equal(MU.compute_opaqueness_mask(w).cpu(), mask_ref.float()) and torch.equal(idx.cpu(), idx_ref)
+    for thr in (0.1, 0.9, 5.0):
+        m_ref, i_ref = O.median_depth_index(w.cpu(), thr)
+        assert torch.equal(MU.compute_opaqueness_mask(w, thr).cpu(), m_ref.float()), thr
+        assert torch.equal(MU.compute_depth_index(w, thr).cpu(), i_ref), thr
+        assert torch.equal(MU.compute_depth_map(w, z, thr).cpu(), (m_ref.float() * z.cpu()).sum(-1)), thr
+    w3 = H.uniform(5, "w3", (6, 7, 130), 0, 0.02)
+    z3 = torch.sort(H.uniform(5, "z3", (6, 7, 130), 0, 1), dim=-1)[0]
+    m_ref, i_ref = O.median_depth_index(w3)
+    # the scan order differs from ATen's sequential cumsum: exclude rays whose running sum passes within 1e-6 of 0.5
+    cs = torch.cumsum(w3.double(), -1)
+    safe = ((cs - 0.5).abs().min(dim=-1)[0] > 1e-6)
+    assert safe.float().mean() > 0.9
+    assert torch.equal(MU.compute_depth_index(w3.to(DEV)).cpu()[safe], i_ref[safe])
+    assert torch.equal(MU.compute_depth_map(w3.to(DEV), z3.to(DEV)).cpu()[safe], (m_ref.float() * z3).sum(-1)[safe])
+
+
 @pytest.mark.parametrize("name,kw", [
     ("d0", dict(in_ch=128, out_ch=3, depth=0, width=128)),
     ("skip2", dict(in_ch=20, out_ch=5, depth=5, width=32, skips=[2])),

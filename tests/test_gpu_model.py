@@ -23,6 +23,7 @@ import hashprng as H
 import hypernerf_torch_amd as HN
 from gpu_common import DEV, EMB, assert_close, assert_grad_close, load_hash, rays_for
 from hypernerf_torch_amd import _lib as L
+from hypernerf_torch_amd import functional as F
 from hypernerf_torch_amd.hypernerf import models, modules, warping
 from hypernerf_torch_amd.models import nerf as legacy_nerf
 from hypernerf_torch_amd.models import rendering as legacy_rendering
@@ -800,6 +801,19 @@ def test_config2_full_size_fp32_vs_oracle():
             assert_close(out["coarse"][k], ref["coarse"][k], 1e-4, f"config2 full size coarse/{k}")
         same = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).float().mean().item()
         assert same > 0.9995, f"only {same:.5f} of the 65,536 fine-sample indices agree"
+        # the isolating statement behind "bit-exact fine-sample indices": end to end the indices depend on the coarse
+        # weights, which two fp32 implementations agree on to ~1e-6 — a draw u that sits that close to a cdf step lands
+        # in the neighbouring bin (the <= 0.05 % above).  Fed the ORACLE's coarse weights and depths, the HIP inverse-CDF
+        # kernel reproduces every one of the 65,536 indices, the samples and the merged sort exactly.
+        z_c = m.last_sampling["z_coarse"]
+        assert torch.equal(z_c.cpu(), O.sample_along_rays(o, d, nc, 0.0, 1.0, rng["t_rand"])[0]), "coarse depths bit-exact"
+        z_all, _, inds_iso, _ = F.sample_pdf(ref["coarse"]["weights"].detach().to(DEV), z_c, rng["u"].to(DEV),
+                                             o.to(DEV), d.to(DEV))
+        flips = int((inds_iso.cpu() != ref["fine"]["_inds"]).sum())
+        assert flips == 0, f"{flips} index flips with identical coarse weights"
+        mid = 0.5 * (z_c[:, 1:] + z_c[:, :-1]).cpu()
+        z_ref2, _, _ = O.sample_pdf(mid, ref["coarse"]["weights"].detach()[:, 1:-1], o, d, z_c.cpu(), rng["u"])
+        assert torch.equal(z_all.cpu(), z_ref2), "merged sorted fine depths bit-exact on identical coarse weights"
         # a fine sample that lands in the neighbouring pdf bin changes that ray's fine render: compare the rays whose
         # indices all agree (> 97 % of them)
         ok = (m.last_sampling["inds"].cpu() == ref["fine"]["_inds"]).all(dim=1)
@@ -969,6 +983,26 @@ def test_weights_are_repacked_after_fused_optimizer_step(use_arena):
         assert_close(out1_train, ref, 1e-6, "training forward after optimizer step")
     finally:
         HN.set_precision("bf16")
+
+
+@pytest.mark.gpu
+def test_g13_se3_transform_through_the_kernel(golden_dir):
+    """The one reference pin of row a19 — `rigid_body.exp_se3(S=(0,0,1,1,0,0), theta=0.5)` (tests/golden/g13_misc.npz
+    `se3_T`, produced by the reference itself) — THROUGH hn_se3_apply: the kernel maps the origin and the three basis
+    points with w = S_w * theta, v = S_v * theta; t = f(0), column i of R = f(e_i) - f(0); compared with the
+    reference's 4x4 at 1e-4 (measured ~1e-7)."""
+    g = np.load(os.path.join(golden_dir, "g13_misc.npz"))
+    T_ref = torch.from_numpy(g["se3_T"]).reshape(4, 4)
+    theta = 0.5
+    pts = torch.tensor([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    w = torch.tensor([0.0, 0.0, 1.0]).expand(4, 3) * theta
+    v = torch.tensor([1.0, 0.0, 0.0]).expand(4, 3) * theta
+    y = F.se3_apply(w.contiguous().to(DEV), v.contiguous().to(DEV), pts.to(DEV)).cpu()
+    t = y[0]
+    R = (y[1:] - t).T
+    assert_close(R, T_ref[:3, :3], 1e-4, "g13 se3_T rotation through hn_se3_apply")
+    assert_close(t, T_ref[:3, 3], 1e-4, "g13 se3_T translation through hn_se3_apply")
+    assert torch.equal(T_ref[3], torch.tensor([0.0, 0.0, 0.0, 1.0]))
 
 
 # ------------------------------------------------------------------------------------------------------------

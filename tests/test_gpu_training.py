@@ -494,3 +494,78 @@ def test_eval_image_loop_vs_oracle_deterministic(tmp_path):
         assert abs(res["psnrs"][i] - psnr_ref) <= 1e-3, (res["psnrs"][i], psnr_ref)
         assert os.path.getsize(os.path.join(str(tmp_path), f"{i:03d}.ppm")) == len(f"P6 {w} {h} 255\n") + h * w * 3
     assert abs(res["mean_psnr"] - sum(res["psnrs"]) / 2) < 1e-12
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no outer launcher: the parent spawns the two ranks before any GPU call of its
+    own (reference: Lightning spawns `devices=num_gpus` ranks, train.py:224-229), relays rank 0's line and fails unless
+    the collective library counted 2 ranks.  On this one-GPU box the ranks share the device and talk gloo
+    (HN_DIST_BACKEND) — the N>1 code path of bench.py itself: two graphs around the gradient all-reduce, 1/N in Adam."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HN_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                          "--repeats", "2", "--rays", "256", "--no-roofline", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen_by_collective"] == 2
+    assert line["config"]["dp_code_path"] and line["config"]["parallelism"] == "dp2"
+    assert line["config"]["launched_by"].startswith("bench.py")
+    assert line["value"] > 0 and np.isfinite(line["final_loss"])
+
+
+def test_checkpoint_into_the_hip_model_renders_like_the_oracle(tmp_path):
+    """SURVEY.md §8 f3 on the GPU: a Lightning-layout checkpoint ({'state_dict': {'nerf.<name>': ...}}, train.py:48,
+    200-204) holding hash weights -> utils.load_ckpt into an ARENA-backed NerfModel already on the device -> the HIP
+    render equals the CPU oracle on those weights (1e-4) -> two TrainStep replays -> save_ckpt -> reload into a fresh
+    model -> the same render, bit for bit, and the file holds the trained weights, not the loaded ones."""
+    from hypernerf_torch_amd.utils import load_ckpt, save_ckpt
+    nc = nf = 16
+    b, seed = 48, 61
+    HN.set_precision("fp32")
+    donor = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=None, **KW)
+    sd = load_hash(donor, seed)
+    path = os.path.join(tmp_path, "epoch=1.ckpt")
+    torch.save({"epoch": 1, "global_step": 10, "state_dict": {"nerf." + k: v.clone() for k, v in sd.items()}}, path)
+
+    m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=None, **KW).to(DEV)
+    ts = TrainStep(m, lr=1e-3, use_graph=True)                      # parameters now live in ts.arena
+    assert ts.arena.attached(m.warp_field.mlp.linears[0].weight) is not None
+    load_ckpt(m, path, "nerf")
+    assert ts.arena.attached(m.warp_field.mlp.linears[0].weight) is not None, "loading must go through the arena views"
+    o, d, idx, rays = ray_rows(seed, b)
+    rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1)}
+    cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=None, **KW)
+    ref = O.nerf_model_forward({k: v.clone() for k, v in sd.items()}, cfg, o, d, idx, rng)
+    from hypernerf_torch_amd.hypernerf import model_utils
+
+    def render(model):
+        with torch.no_grad():
+            return model(model_utils.prepare_ray_dict(rays.to(DEV)), {}, rng={k: v.to(DEV) for k, v in rng.items()})
+    out = render(m)
+    for lvl in ("coarse", "fine"):
+        for key in ("rgb", "depth", "acc", "weights"):
+            assert_close(out[lvl][key], ref[lvl][key], 1e-4, f"render from a loaded checkpoint: {lvl}/{key}")
+    gt = 0.5 + 0.5 * torch.sin(3.0 * o + 2.0 * d)
+    for _ in range(2):
+        ts.step(rays.to(DEV), gt.to(DEV), rng={k: v.to(DEV) for k, v in rng.items()})
+    trained = render(m)
+    assert float((trained["fine"]["rgb"] - out["fine"]["rgb"]).abs().max()) > 1e-5, "two Adam steps must move the render"
+    p2 = save_ckpt(m, os.path.join(tmp_path, "epoch=2.ckpt"), model_name="nerf", epoch=2, global_step=12,
+                   optimizer=ts.optimizer)
+    blob = torch.load(p2, map_location="cpu")
+    assert blob["epoch"] == 2 and float(blob["hn_optimizer"]["step"].reshape(-1)[0]) == 2.0
+    moved = sum(float((blob["state_dict"]["nerf." + k] - v).abs().max()) > 0 for k, v in sd.items())
+    assert moved >= 60, f"only {moved} tensors differ from the loaded weights after two steps"
+    fresh = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=None, **KW).to(DEV)
+    HN.ParamArena(fresh.parameters())
+    load_ckpt(fresh, p2, "nerf")
+    again = render(fresh)
+    for lvl in ("coarse", "fine"):
+        for key in ("rgb", "depth", "weights"):
+            assert torch.equal(again[lvl][key], trained[lvl][key]), f"reloaded model renders differently: {lvl}/{key}"

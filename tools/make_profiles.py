@@ -12,6 +12,13 @@ dst = os.path.join(ROOT, "profiles")
 sfx = "" if cfg == 2 else f"_config{cfg}"
 
 
+try:
+    import subprocess
+    GIT_SHA = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except OSError:
+    GIT_SHA = None
+
+
 def one(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
     if not hits:
@@ -54,6 +61,8 @@ with open(os.path.join(dst, f"{tag}_pmc_per_kernel{sfx}.csv"), "w") as f:
 line = json.load(open(os.path.join(src, "bench_line.json")))
 traffic = {"config": cfg, "rays": line["config"]["rays_per_gpu"], "nc": line["config"]["n_samples"],
            "nf": line["config"]["n_importance"], "pmc_steps": PMC_STEPS, "bytes_per_step": step_bytes,
+           # the kernels these counters were collected on (bench.py refuses to quote the file for any other build)
+           "build": dict(line.get("build") or {}, git_sha=GIT_SHA),
            "per_kernel_launch": {k: per_kernel_bytes[k] / per_kernel_n[k] for k in per_kernel_bytes if k.startswith("hn_")},
            "per_kernel_step": {k: per_kernel_bytes[k] / PMC_STEPS for k in per_kernel_bytes if k.startswith("hn_")},
            "note": "FETCH_SIZE x 1024 x 2 (gfx950 half-count of wide coalesced reads) + WRITE_SIZE x 1024, separate "
