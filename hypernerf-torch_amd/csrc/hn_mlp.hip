@@ -2,6 +2,7 @@
 // See include/hn_kernels.h for the program format and hn_common.h for the register layouts.
 #include "hn_common.h"
 #include <algorithm>
+#include <type_traits>
 
 // Diagnostic build only (-DHN_PROF): wave 0 of workgroup 0 logs (code, shader clock) pairs into HnMlpArgs.prof.
 #ifdef HN_PROF
@@ -303,12 +304,25 @@ HN_DEV char* hn_slot_base(const HnMlpArgs& a, int off_kib, int nt, int blk) {
 HN_DEV uint32_t* hn_mask_base(const HnMlpArgs& a, int off256, int nt, int blk, int lane) {
   return a.masks + (size_t)(unsigned)off256 * 64 + (size_t)blk * nt * 64 + lane;
 }
-// transpose one tile through the matrix core and store it as tile t of the slot
+// Store one 32-feature tile of a block as tile t of a stash slot.
+// bf16: the operand fragments AS THEY ARE (points on lanes) — no transposing MFMAs, no second conversion: unit u of the
+// tile holds fragment u, lane (r, h) at 16-byte slot hn_stash_slot(r, h, u) of the unit; the weight-gradient kernel
+// turns "points on lanes" into "features on lanes" on its LDS read (ds_read_b64_tr_b16, DwFrag<true>::load), and the
+// slot permutation is what makes those reads bank-conflict free.  The 64 lanes still fill exactly one 1-KiB unit.
+// fp32 (parity mode; no 32-bit transposing read exists): transposed through the matrix core as before.
+HN_DEV int hn_stash_slot(int r, int h, int u) { return 32 * h + (r ^ (4 * h + 8 * u)); }
 template <bool BF16>
 HN_DEV void hn_stash(const typename ModeT<BF16>::Frag* fr, char* slot_base, int t, int lane) {
   using M = ModeT<BF16>;
-  const f32x16 z = hn_transpose_tile(fr, lane);
-  hn_store_tile(z, slot_base + (size_t)t * (M::TILE_UNITS * 1024), lane, (typename M::Frag*)nullptr);
+  char* dst = slot_base + (size_t)t * (M::TILE_UNITS * 1024);
+  if constexpr (BF16) {
+    const int off0 = hn_stash_slot(lane & 31, lane >> 5, 0) * 16;        // unit 1: the same slot with bit 3 flipped
+    __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(&fr[0]), reinterpret_cast<u32x4*>(dst + off0));
+    __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(&fr[1]), reinterpret_cast<u32x4*>(dst + 1024 + (off0 ^ 128)));
+  } else {
+    const f32x16 z = hn_transpose_tile(fr, lane);
+    hn_store_tile(z, dst, lane, (typename M::Frag*)nullptr);
+  }
 }
 
 // ReLU masks: one 32-bit word per lane and PAIR of tiles; element i of tile (2d + q) is bit 31 - (16 q + i), and a
@@ -355,12 +369,10 @@ HN_DEV HnOpWords hn_load_op(const int* ops, int op, int n_ops) {
 // ------------------------------------------------------------------------------------------------
 // one share of the previous tile's epilogue + stash, written so that share k only needs shares < k:
 //   k = 0..7   elements 2k, 2k+1: mask bit, ReLU, pack to bf16 (fragment k>>2 complete after k = 3 / 7)
-//   k = 8..11  pack the transposed tile z (4 of its 16 values each)
-//   k = 12     the two 16-byte stash stores (+ the mask word of a finished tile pair)
-// The two identity-MFMAs that transpose the tile are issued by the caller before shares 4 and 8.
+//   k = 8      the two 16-byte stash stores of the finished fragments (+ the mask word of a finished tile pair)
 template <bool TRAIN, int NT>
-HN_DEV void hn_epilogue_share(int k, int tp, f32x16& a, bf16x8* frag, unsigned& bits, const f32x16& z, bf16x8* zo,
-                              char* out_base, uint32_t* mask_base, int lane) {
+HN_DEV void hn_epilogue_share(int k, int tp, f32x16& a, bf16x8* frag, unsigned& bits, char* out_base,
+                              uint32_t* mask_base, int lane) {
   if (k < 8) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -368,16 +380,8 @@ HN_DEV void hn_epilogue_share(int k, int tp, f32x16& a, bf16x8* frag, unsigned& 
       if (TRAIN) bits = hn_push_mask<true>(bits, a[i]);
       frag[i >> 3][i & 7] = (__bf16)__int_as_float(max(__float_as_int(a[i]), 0));
     }
-  } else if (TRAIN && k < 12) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = 4 * (k - 8) + e;
-      zo[i >> 3][i & 7] = (__bf16)z[i];
-    }
-  } else if (TRAIN && k == 12) {
-    char* dst = out_base + (size_t)tp * 2048 + lane * 16;
-    __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(&zo[0]), reinterpret_cast<u32x4*>(dst));
-    __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(&zo[1]), reinterpret_cast<u32x4*>(dst + 1024));
+  } else if (TRAIN && k == 8) {
+    hn_stash<true>(frag, out_base, tp, lane);
     if ((tp & 1) || tp == NT - 1) {
       mask_base[(tp >> 1) * 64] = (tp & 1) ? bits : bits << 16;
       bits = 0;
@@ -390,17 +394,10 @@ HN_DEV void hn_layer_pipelined(bf16x8* cur, bf16x8* nxt, const float* bias, WStr
                                char* out_base, uint32_t* mask_base, int lane) {
   constexpr int N = 2 * K32;            // MFMAs (= issue slots) per tile
   constexpr int D = 2;                  // fragment reads in flight
-  constexpr int SHARES = 13;
+  constexpr int SHARES = 9;
   constexpr int PER_SLOT = (SHARES + N - 1) / N;      // 2 for 8 slots
-  const int h = lane >> 5, c = lane & 31;
-  bf16x8 id[2];                          // permuted identity: B operand of the transposing MFMAs
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) id[u][j] = (c == 16 * u + hn_pi16(h, j)) ? (__bf16)1.0f : (__bf16)0.0f;
+  const int h = lane >> 5;
   f32x16 acc[2];
-  f32x16 z;
-  bf16x8 zo[2];
   unsigned bits = 0;
 #pragma unroll
   for (int t = 0; t <= NT; ++t) {
@@ -425,11 +422,8 @@ HN_DEV void hn_layer_pipelined(bf16x8* cur, bf16x8* nxt, const float* bias, WStr
 #pragma unroll
         for (int e = 0; e < PER_SLOT; ++e) {
           const int k = u * PER_SLOT + e;
-          if (k < SHARES) {
-            if (TRAIN && k == 4) z = hn_mfma_bf16(nxt[tp * 2], id[0], f32x16{0});
-            if (TRAIN && k == 8) z = hn_mfma_bf16(nxt[tp * 2 + 1], id[1], z);
-            hn_epilogue_share<TRAIN, NT>(k, tp, acc[tp & 1], nxt + tp * 2, bits, z, zo, out_base, mask_base, lane);
-          }
+          if (k < SHARES)
+            hn_epilogue_share<TRAIN, NT>(k, tp, acc[tp & 1], nxt + tp * 2, bits, out_base, mask_base, lane);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -940,15 +934,59 @@ __global__ void hn_pack_kernel(const HnPackUnit* units, int n_units, const float
 // ------------------------------------------------------------------------------------------------
 // weight gradient: dW[n][k] += sum_p dZ[p][n] X[p][k] straight from the transposed stashes
 // ------------------------------------------------------------------------------------------------
+template <class F>
+HN_DEV void static_for4(F&& f) {
+  f(std::integral_constant<int, 0>{});
+  f(std::integral_constant<int, 1>{});
+  f(std::integral_constant<int, 2>{});
+  f(std::integral_constant<int, 3>{});
+}
 template <bool BF16>
 struct DwFrag;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+// byte offsets inside a 2-KiB bf16 stash tile of this lane's transposed reads (hn_stash's layout).  The MFMA operand
+// of the dW product wants "feature on the lane, 8 points in the registers"; the stash has "point on the lane, 8
+// features in the registers".  ds_read_b64_tr_b16 gathers, per group of 16 lanes, 4 rows x 16 columns and hands lane
+// i column i: rows = 4 points, columns = 16 features (four 8-byte pieces of 4 features each).  Lane 4q + p of group
+// G supplies the piece (unit G&1, lane half p&1, register half p>>1) of point 16 mm + 8 (G>>1) + 4 jh + q for read
+// (mm, jh); it receives feature 16 (G&1) + (its index in the group) at those 4 points.  Reads jh = 0, 1 make the 8
+// points of one operand (k = 8 hh + 4 jh + q), mm = 0, 1 the two operands of a 32-point block.  With the slot
+// permutation of hn_stash_slot the 32 lanes of a half hit 64 distinct banks.
+HN_DEV void hn_dw_tr_offsets(int lane, int& o0, int& o1) {
+  const int G = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+  const int u = G & 1, hh = G >> 1, h = pp & 1, g = pp >> 1;
+  o0 = u * 1024 + hn_stash_slot(8 * hh + q, h, u) * 16 + 8 * g;
+  o1 = u * 1024 + hn_stash_slot(8 * hh + 4 + q, h, u) * 16 + 8 * g;
+}
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// The four transposed reads of one tile + the wait for them, as ONE asm statement.  (The compiler builtin of
+// ds_read_b64_tr_b16 carries no memory operand, so next to LDS-DMA in flight hipcc guards every one of them with
+// s_waitcnt vmcnt(0) — which drains the whole stage ring: measured 0.70 -> 1.00 ms on the weight-gradient launch.  The
+// asm form is invisible to that rule; the data dependence of the MFMAs on its outputs orders them behind the wait.)
+// a0 / a1: LDS byte addresses of the lane's reads jh = 0 / 1 in tile 0; OFF: byte offset of the tile.
+template <int OFF>
+HN_DEV void hn_tr_tile(bf16x8* v, unsigned a0, unsigned a1) {
+  u32x2 l0, h0, l1, h1;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %4 offset:%6\n\t"
+      "ds_read_b64_tr_b16 %1, %5 offset:%6\n\t"
+      "ds_read_b64_tr_b16 %2, %4 offset:%7\n\t"
+      "ds_read_b64_tr_b16 %3, %5 offset:%7\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1)
+      : "v"(a0), "v"(a1), "n"(OFF), "n"(OFF + 256)
+      : "memory");
+  const u32x4 w0 = {l0[0], l0[1], h0[0], h0[1]}, w1 = {l1[0], l1[1], h1[0], h1[1]};
+  v[0] = __builtin_bit_cast(bf16x8, w0);
+  v[1] = __builtin_bit_cast(bf16x8, w1);
+}
 template <>
 struct DwFrag<true> {
   bf16x8 v[2];
-  HN_DEV void load(const char* tile, int lane) {
-    v[0] = *reinterpret_cast<const bf16x8*>(tile + lane * 16);
-    v[1] = *reinterpret_cast<const bf16x8*>(tile + 1024 + lane * 16);
-  }
+  template <int OFF>
+  HN_DEV void load_tr(unsigned a0, unsigned a1) { hn_tr_tile<OFF>(v, a0, a1); }
+  HN_DEV void load(const char*, int, int, int) {}
   HN_DEV static void mma(f32x16& acc, const DwFrag& a, const DwFrag& b) {
     acc = hn_mfma_bf16(a.v[0], b.v[0], acc);
     acc = hn_mfma_bf16(a.v[1], b.v[1], acc);
@@ -964,10 +1002,12 @@ struct DwFrag<true> {
 template <>
 struct DwFrag<false> {
   f32x4 v[4];
-  HN_DEV void load(const char* tile, int lane) {
+  HN_DEV void load(const char* tile, int lane, int, int) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(tile + g * 1024 + lane * 16);
   }
+  template <int OFF>
+  HN_DEV void load_tr(unsigned, unsigned) {}
   HN_DEV static void mma(f32x16& acc, const DwFrag& a, const DwFrag& b) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -1133,6 +1173,8 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   unsigned long long tw = 0, tb = 0, ti = 0, tc = 0, t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0, t4_ = 0;
 #define HN_TS(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
 #endif
+  int tro0 = 0, tro1 = 0;       // bf16: this lane's transposed-read offsets inside a stash tile
+  hn_dw_tr_offsets(lane, tro0, tro1);
   for (int s0 = 0; s0 < STAGES - 1 && s0 < nstage; ++s0) issue(s0);
   for (int s = 0; s < nstage; ++s) {
     const int younger = min(STAGES - 2, nstage - 1 - s);     // stages issued after stage s that may stay in flight
@@ -1162,20 +1204,29 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     for (int bi = 0; bi < nblk_s; ++bi) {
       const char* sb = st + (size_t)bi * UB * 1024;
       DwFrag<BF16> xb[2];
+      // bf16: LDS byte addresses of this lane's transposed reads in the block's first dZ tile / first X tile of the wave
+      const unsigned a_blk = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)sb;
+      const unsigned ax = a_blk + (unsigned)((jb.n_nt + k0) * TB), az = a_blk + (unsigned)(n0 * TB);
+      if constexpr (BF16) {
+        if (0 < my_k) xb[0].template load_tr<0>(ax + tro0, ax + tro1);
+        if (1 < my_k) xb[1].template load_tr<2048>(ax + tro0, ax + tro1);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (j < my_k) xb[j].load(sb + (size_t)(jb.n_nt + k0 + j) * TB, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 2; ++j)
+          if (j < my_k) xb[j].load(sb + (size_t)(jb.n_nt + k0 + j) * TB, lane, 0, 0);
+      }
+      static_for4([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
         if (i < my_n) {
           DwFrag<BF16> za;
-          za.load(sb + (size_t)(n0 + i) * TB, lane);
+          if constexpr (BF16) za.template load_tr<2048 * i>(az + tro0, az + tro1);
+          else za.load(sb + (size_t)(n0 + i) * TB, lane, 0, 0);
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             if (j < my_k) DwFrag<BF16>::mma(acc[i][j], za, xb[j]);
           if (bias_mask & (1u << i)) DwFrag<BF16>::mma_ones(accb[i], za);
         }
-      }
+      });
     }
 #ifdef HN_PROF
     if (prof_on) { HN_TS(t4_); tw += t1_ - t0_; tb += t2_ - t1_; ti += t3_ - t2_; tc += t4_ - t3_; }

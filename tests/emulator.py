@@ -150,6 +150,41 @@ def transpose_tile(mode, frags):
     return z
 
 
+def stash_slot(r, h, u):
+    """hn_stash_slot (hn_mlp.hip): 16-byte slot of lane (r, h) inside unit u of a bf16 stash tile."""
+    return 32 * h + (r ^ (4 * h + 8 * u))
+
+
+def dw_tr_offsets(lane):
+    """hn_dw_tr_offsets (hn_mlp.hip): byte offsets of a lane's two transposed reads (jh = 0, 1) inside a tile."""
+    G, i = lane >> 4, lane & 15
+    q, pp = i >> 2, i & 3
+    u, hh, h, g = G & 1, G >> 1, pp & 1, pp >> 1
+    return (u * 1024 + stash_slot(8 * hh + q, h, u) * 16 + 8 * g,
+            u * 1024 + stash_slot(8 * hh + 4 + q, h, u) * 16 + 8 * g)
+
+
+def ds_read_b64_tr_b16(img, addr):
+    """gfx950 semantics (cdna_hip_programming.md T10): per group of 16 lanes, lane 4q+p supplies the address of row q,
+    columns 4p..4p+3 (8 bytes) of a 4 x 16 block; lane i receives column i, row q in element q.  img: one entry per
+    16-bit element; addr: byte address per lane.  Also checks the bank rule the layout was designed for: the 32 lanes
+    of a half must touch 64 distinct banks (bank = (addr / 4) % 64, two banks per 8-byte piece)."""
+    out = np.zeros((64, 4))
+    for half in range(2):
+        banks = set()
+        for l in range(32 * half, 32 * half + 32):
+            assert addr[l] % 8 == 0
+            banks.update({(addr[l] // 4) % 64, (addr[l] // 4 + 1) % 64})
+        assert len(banks) == 64, "transposed stash read is not bank-conflict free"
+    for G in range(4):
+        for i in range(16):
+            p, e = i >> 2, i & 3
+            for q in range(4):
+                src = addr[16 * G + 4 * q + p]
+                out[16 * G + i, q] = img[src // 2 + e]
+    return out
+
+
 def store_tile(mode, z):
     """-> (TILE_UNITS, 64, elems) as written to the stash."""
     if mode.bf16:
@@ -221,12 +256,33 @@ class Stash:
         self.tiles = {}     # (byte offset) -> (TILE_UNITS,64,elems)
         self.masks = {}
 
-    def put_tile(self, slot, blk, t, z):
+    def put_frags(self, slot, blk, t, frags):
+        """hn_stash: fp32 transposes the tile through the matrix core and stores [g][lane][4]; bf16 stores the operand
+        fragments as they are, lane (r, h) of unit u at 16-byte slot stash_slot(r, h, u) of the unit."""
         off, nt = self.offs[slot]
-        self.tiles[off + (blk * nt + t) * self.tile_bytes] = store_tile(self.mode, z)
+        key = off + (blk * nt + t) * self.tile_bytes
+        if not self.mode.bf16:
+            self.tiles[key] = store_tile(self.mode, transpose_tile(self.mode, frags))
+            return
+        img = np.zeros(1024)                         # the 2-KiB tile, one entry per bf16 element
+        for u in range(2):
+            for l in range(64):
+                a = u * 1024 + stash_slot(l & 31, l >> 5, u) * 16
+                img[a // 2:a // 2 + 8] = frags[u][l]
+        self.tiles[key] = img
 
     def get_tile(self, byte_off):
-        return self.tiles[byte_off]
+        """The operand fragments the weight-gradient kernel builds from one stashed tile (DwFrag::load)."""
+        if not self.mode.bf16:
+            return self.tiles[byte_off]
+        img = self.tiles[byte_off]
+        out = np.zeros((2, 64, 8))
+        for mm in range(2):
+            for jh in range(2):
+                addr = [dw_tr_offsets(l)[jh] + 256 * mm for l in range(64)]
+                got = ds_read_b64_tr_b16(img, addr)
+                out[mm][:, 4 * jh:4 * jh + 4] = got
+        return out
 
     def put_mask(self, slot, blk, d, bits):
         off, nt = self.offs[slot]
@@ -282,8 +338,8 @@ def run_forward(prog, mode, tables, params, srcs, n_points, spr, dst_widths, tra
                     fr = make_group(mode, feat[w[3] + 64 * g: w[3] + 64 * g + 64], srcs, p, ray, valid)
                     aux.append(fr)
                     if training and w[6] >= 0:
-                        stash.put_tile(w[6], blk, 2 * g, transpose_tile(mode, fr[:mode.steps32]))
-                        stash.put_tile(w[6], blk, 2 * g + 1, transpose_tile(mode, fr[mode.steps32:]))
+                        stash.put_frags(w[6], blk, 2 * g, fr[:mode.steps32])
+                        stash.put_frags(w[6], blk, 2 * g + 1, fr[mode.steps32:])
                 nxt = mode.zero_frags(8 * mode.steps32)
                 bits = np.zeros(64, dtype=np.uint64)
                 for t in range(nt):
@@ -305,7 +361,7 @@ def run_forward(prog, mode, tables, params, srcs, n_points, spr, dst_widths, tra
                             stash.put_mask(w[4], blk, t >> 1, bits)
                         bits = np.zeros(64, dtype=np.uint64)
                     if training and w[5] >= 0:
-                        stash.put_tile(w[5], blk, t, transpose_tile(mode, nxt[t * mode.steps32:(t + 1) * mode.steps32]))
+                        stash.put_frags(w[5], blk, t, nxt[t * mode.steps32:(t + 1) * mode.steps32])
                 if not (flags & 1):
                     cur[:nt * mode.steps32] = nxt[:nt * mode.steps32]
             elif code == 4:
@@ -384,7 +440,7 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
                         else:
                             tmp[i, l] = g
                 if w[7] >= 0:
-                    stash.put_tile(w[7], blk, 0, transpose_tile(mode, tmp))
+                    stash.put_frags(w[7], blk, 0, tmp)
                 if to2:
                     cur2 = tmp
                 else:
@@ -403,7 +459,7 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
                                 v[l, i] = arr[p[l], w[2] + row]
                     cur[t * mode.steps32:(t + 1) * mode.steps32] = acc_to_frags(mode, v)
                     if w[7] >= 0:
-                        stash.put_tile(w[7], blk, t, transpose_tile(mode, cur[t * mode.steps32:(t + 1) * mode.steps32]))
+                        stash.put_frags(w[7], blk, t, cur[t * mode.steps32:(t + 1) * mode.steps32])
             elif code == 3:
                 k32, k32b, nt = w[1] & 255, (w[1] >> 8) & 255, (w[1] >> 16) & 255
                 nxt = mode.zero_frags(8 * mode.steps32)
@@ -420,7 +476,7 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
                                     acc[l, i] = 0.0
                     nxt[t * mode.steps32:(t + 1) * mode.steps32] = acc_to_frags(mode, acc)
                     if w[5] >= 0:
-                        stash.put_tile(w[5], blk, t, transpose_tile(mode, nxt[t * mode.steps32:(t + 1) * mode.steps32]))
+                        stash.put_frags(w[5], blk, t, nxt[t * mode.steps32:(t + 1) * mode.steps32])
                 cur[:nt * mode.steps32] = nxt[:nt * mode.steps32]
             elif code == 4:
                 k32, k32b, ng = w[1] & 255, (w[1] >> 8) & 255, (w[1] >> 16) & 255
