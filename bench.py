@@ -62,6 +62,10 @@ def parse():
                     help="data-parallel runs: all-reduce the gradient buffer in two buckets, the first in flight while the "
                          "weight gradients of the second are computed (dist.GradSync).  Off by default: splitting the "
                          "batched weight-gradient launch costs ~0.2 ms on one MI355X, more than the all-reduce it hides")
+    ap.add_argument("--fork-wgrad", action="store_true",
+                    help="fork each program's weight-gradient jobs onto a side stream behind its backward-data kernel "
+                         "(parallel graph branches) instead of one batched launch at the end of backward.  Measured "
+                         "slower on one MI355X (functional.py, profiles/r03_wgrad_fork_trace.txt); off by default")
     ap.add_argument("--launch-plan", action="store_true",
                     help="print the rank launch plan of --gpus N (commands + per-rank environment) as JSON and exit")
     ap.add_argument("--force-dp", action="store_true",
@@ -82,6 +86,7 @@ def macs_per_point(prog):
 def build_workload(a, dev, rank):
     """(model-like callable returning (out, loss), parameters, {program name: (program, points per step)})."""
     import hypernerf_torch_amd as HN
+    from hypernerf_torch_amd import functional as HF
     from hypernerf_torch_amd.hypernerf import model_utils
     from hypernerf_torch_amd.losses import MSELoss
     from gpu_common import EMB
@@ -105,7 +110,7 @@ def build_workload(a, dev, rank):
         def fwd_bwd():
             res = render_rays([coarse], emb, rays, N_samples=a.nc, N_importance=0, perturb=1.0, noise_std=1.0)
             loss = ((res["rgb_coarse"] - target) ** 2).mean()     # losses.py:10 on the coarse level only
-            loss.backward()
+            HF.backward(loss)
             return {"fine": {"rgb": res["rgb_coarse"]}}, loss
 
         def programs():
@@ -131,7 +136,7 @@ def build_workload(a, dev, rank):
     def fwd_bwd():
         out = model(model_utils.prepare_ray_dict(rays), extra)
         loss = loss_fn(out, target)
-        loss.backward()             # accumulates into arena.grad, which the previous opt.step() left zeroed
+        HF.backward(loss)           # accumulates into arena.grad, which the previous opt.step() left zeroed
         return out, loss
 
     def programs():
@@ -248,6 +253,10 @@ def main():
     from hypernerf_torch_amd.dist import all_gather_pixels
 
     HN.set_precision(a.precision)
+    from hypernerf_torch_amd import functional as HF0
+    if a.fork_wgrad:
+        HF0.set_wgrad_overlap(True)
+    wgrad_schedule = "forked: side stream / parallel graph branch" if HF0.WGRAD_OVERLAP else "serial: one batched launch"
     fwd_bwd, params, programs, workload, model, data = build_workload(a, dev, rank)
     use_graph = not a.no_graph
     # parameters and gradients live in one flat arena each: the kernels accumulate dW straight into it, Adam steps
@@ -338,7 +347,7 @@ def main():
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.precision, "data": "synthetic",
         "config": {"workload": workload, "baseline_config": a.config, "rays_per_gpu": b, "n_samples": a.nc,
-                   "n_importance": a.nf, "parallelism": f"dp{world}", "hip_graph": use_graph, "dp_code_path": dp, "grad_sync": None if sync is None else ("one all-reduce" if sync.split is None else f"two buckets split at float {sync.split} of {arena.numel}, overlapped"),
+                   "n_importance": a.nf, "parallelism": f"dp{world}", "hip_graph": use_graph, "wgrad_schedule": wgrad_schedule, "dp_code_path": dp, "grad_sync": None if sync is None else ("one all-reduce" if sync.split is None else f"two buckets split at float {sync.split} of {arena.numel}, overlapped"),
                    "ranks_seen_by_collective": ranks_seen},
         "per_gpu": value / world, "final_loss": float(loss.detach()),
         "repeats": len(reps), "ms_per_step_repeats": [1e3 * r / a.steps for r in reps],
@@ -372,6 +381,10 @@ def roofline(a, L, fwd_bwd, opt, progs, step_s, b):
     algorithmic bytes (§8d: rays, targets, outputs, weights read forward + backward, gradients written), the bytes
     the design really moves (`stash_bytes`: activations written by forward / backward and read once by the
     weight-gradient kernel) and, when profiles/ holds a PMC summary for this configuration, the measured traffic."""
+    # per-kernel timing needs the kernels one after the other: concurrent launches (the forked weight-gradient
+    # schedule of the timed region) share the chip and inflate each other's durations
+    from hypernerf_torch_amd import functional as HF
+    HF.set_wgrad_overlap(False)
     L.KERNEL_TIMES = {}
     for _ in range(a.steps):
         fwd_bwd()           # rank-local: no collective here, the other ranks are not in this pass

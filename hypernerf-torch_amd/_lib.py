@@ -18,6 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libhn_hip.so")
 SOURCES = ["hn_mlp.hip", "hn_render.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hn_kernels.h")
+BUILD_MACROS = ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX", "HN_PIPE256", "HN_EXP")     # build-time tuning knobs (A/B experiments)
 
 HN_MODE_F32, HN_MODE_BF16 = 0, 1
 HN_MAX_SRC, HN_MAX_DST, HN_MAX_SLOTS = 8, 4, 128
@@ -65,6 +66,11 @@ class HnDwBatch(C.Structure):
 
 
 HN_MAX_WGRAD_BATCH = 8
+HN_MAX_DRAWS = 8
+
+
+class HnDraw(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("n", C.c_int64), ("kind", C.c_int32), ("pad", C.c_int32)]
 
 
 class HnCompositeArgs(C.Structure):
@@ -95,7 +101,7 @@ EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_
            "hn_mlp_wgrad_batched", "hn_mlp_workspace_bytes",
            "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf",
            "hn_embed_gather", "hn_embed_backward", "hn_se3_apply_forward", "hn_se3_apply_backward", "hn_generate_rays", "hn_adam_step",
-           "hn_mse_loss_forward", "hn_mse_loss_backward", "hn_depth_index",
+           "hn_mse_loss_forward", "hn_mse_loss_backward", "hn_depth_index", "hn_random_fill",
            "hn_probe_mfma"]
 
 _lib = None
@@ -126,7 +132,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
            "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    for macro in ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX"):          # build-time tuning knobs (A/B experiments)
+    for macro in BUILD_MACROS:          # build-time tuning knobs (A/B experiments)
         if os.environ.get(macro):
             cmd.insert(1, f"-D{macro}={os.environ[macro]}")
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -146,7 +152,7 @@ def build_id() -> dict:
     for d in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "hn_common.h"), HEADER]:
         with open(d, "rb") as f:
             h.update(f.read())
-    for macro in ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX"):
+    for macro in BUILD_MACROS:
         h.update(f"{macro}={os.environ.get(macro, '')};".encode())
     lib = None
     if os.path.exists(LIB_PATH):

@@ -533,6 +533,13 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             else hn_layer_pipelined<4, 4, false>(cur, nxt, bias, ws, out_base, mask_base, lane);
             continue;
           }
+#ifdef HN_PIPE256
+          if (plain && K32 == 8 && NT == 8) {
+            if (do_stash) hn_layer_pipelined<8, 8, true>(cur, nxt, bias, ws, out_base, mask_base, lane);
+            else hn_layer_pipelined<8, 8, false>(cur, nxt, bias, ws, out_base, mask_base, lane);
+            continue;
+          }
+#endif
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {

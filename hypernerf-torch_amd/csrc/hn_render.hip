@@ -715,6 +715,108 @@ extern "C" int hn_adam_step(float* params, float* grads, float* exp_avg, float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// random draws of a render step in ONE launch: the reference draws t_rand ~ U[0,1) (model_utils.py:31), the density
+// noise ~ N(0,1) per level (model_utils.py:300-317) and u ~ U[0,1) (model_utils.py:226) with four ATen launches; here
+// up to HN_MAX_DRAWS buffers are filled by one counter-based generator (Philox4x32-10, the generator torch itself
+// uses on the GPU): thread i of the launch encrypts counter (offset + i, buffer id) under the key `seed` into four
+// 32-bit words = four uniforms ((x >> 8) * 2^-24, as torch.rand) or two Box-Muller pairs.  seed / offset / ticket
+// live in device memory (state[0..2]): every block reads the offset first, the block that finishes last advances it
+// by the number of threads — so a captured launch draws fresh numbers on every HIP-graph replay.
+// ------------------------------------------------------------------------------------------------
+struct HnDrawTable {
+  float* ptr[HN_MAX_DRAWS];
+  long long n[HN_MAX_DRAWS];
+  long long first_thread[HN_MAX_DRAWS + 1];    // prefix sums of ceil(n / 4)
+  int kind[HN_MAX_DRAWS];                      // 0 = uniform [0,1), 1 = standard normal
+  int count;
+};
+
+HN_DEV void hn_philox_round(uint32_t (&c)[4], const uint32_t (&k)[2]) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+HN_DEV void hn_philox4x32_10(uint32_t (&c)[4], uint64_t seed) {
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    hn_philox_round(c, k);
+    k[0] += 0x9E3779B9u;
+    k[1] += 0xBB67AE85u;
+  }
+}
+
+__global__ __launch_bounds__(256) void hn_random_kernel(const HnDrawTable t, unsigned long long* state) {
+  const unsigned long long seed = state[0], offset = state[1];
+  const long long total = t.first_thread[t.count];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int b = 0;
+#pragma unroll
+    for (int k = 1; k < HN_MAX_DRAWS; ++k)
+      if (k < t.count && i >= t.first_thread[k]) b = k;
+    const long long j = (i - t.first_thread[b]) * 4;
+    const unsigned long long ctr = offset + (unsigned long long)i;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)b, 0x484e3033u};
+    hn_philox4x32_10(c, seed);
+    float v[4];
+    if (t.kind[b] == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)(c[e] >> 8) * 5.9604644775390625e-8f;           // [0, 1)
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float u1 = ((float)(c[2 * e] >> 8) + 1.0f) * 5.9604644775390625e-8f;              // (0, 1]
+        const float u2 = (float)(c[2 * e + 1] >> 8) * 5.9604644775390625e-8f;
+        const float r = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        v[2 * e] = r * cs;
+        v[2 * e + 1] = r * sn;
+      }
+    }
+    float* dst = t.ptr[b] + j;
+    if (j + 4 <= t.n[b] && (((uintptr_t)dst) & 15) == 0) {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+      for (int e = 0; e < 4 && j + e < t.n[b]; ++e) dst[e] = v[e];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* ticket = reinterpret_cast<unsigned*>(state + 2);
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {      // every block has read the old offset by now
+      state[1] = offset + (unsigned long long)total;
+      *ticket = 0u;
+    }
+  }
+}
+
+extern "C" int hn_random_fill(const HnDraw* draws_host, int n_draws, uint64_t* state_dev, hnStream_t stream) {
+  if (n_draws < 0 || n_draws > HN_MAX_DRAWS) return -1;
+  if (n_draws == 0) return 0;
+  if (draws_host == nullptr || state_dev == nullptr) return -3;
+  HnDrawTable t = {};
+  long long threads = 0;
+  for (int i = 0; i < n_draws; ++i) {
+    if (draws_host[i].n < 0 || (draws_host[i].kind != 0 && draws_host[i].kind != 1)) return -2;
+    if (draws_host[i].n > 0 && draws_host[i].ptr == nullptr) return -3;
+    t.ptr[i] = draws_host[i].ptr; t.n[i] = draws_host[i].n; t.kind[i] = draws_host[i].kind;
+    t.first_thread[i] = threads;
+    threads += (draws_host[i].n + 3) / 4;
+  }
+  t.count = n_draws;
+  t.first_thread[n_draws] = threads;
+  if (threads == 0) return 0;
+  long long blocks = (threads + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(hn_random_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t,
+                     (unsigned long long*)state_dev);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // loss head (losses.py:4-14): mean squared error of the coarse and the fine render against the same target
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void hn_mse_fwd_kernel(const float* __restrict__ c, const float* __restrict__ f,

@@ -109,6 +109,9 @@ class _ProgramFn(torch.autograd.Function):
         # close a reference cycle output -> grad_fn (this node) -> ctx -> output that neither Python's collector nor
         # autograd can break: every eager training step would leak its outputs and sources (~10 MB at config 2)
         ctx.outs = [o.detach() for o in outs]
+        # outputs nobody differentiates (warped_points of a level program: P x 7 floats) arrive as None in backward,
+        # not as a zero fill launched by autograd; the ('go', k) sources are simply absent then
+        ctx.set_materialize_grads(False)
         return tuple(outs)
 
     @staticmethod
@@ -205,14 +208,68 @@ class _ProgramFn(torch.autograd.Function):
         return (None, None, None, None, None, None, *src_grads, *out_p)
 
 
-# Arena mode: the weight-gradient kernels of all programs of one backward pass run as ONE launch, queued as an
-# autograd end-of-backward callback (they only feed arena.grad, which nothing reads before backward() returns).
+# Arena mode: the weight-gradient kernels only feed arena.grad, which nothing reads before backward() returns, so
+# they need not sit between the backward-data kernels.  Two schedules:
+#   serial (default): ONE batched launch over all programs of the backward pass, queued as the end-of-backward
+#     callback (one global heaviest-first job order, one ramp and one tail).
+#   forked (set_wgrad_overlap(True), env HN_WGRAD_OVERLAP=1, bench.py --fork-wgrad): each program's weight-gradient
+#     launch goes onto a SIDE stream right behind its own backward-data kernel (event on the main stream -> wait on
+#     the side stream) and is joined by the end-of-backward callback; inside a stream capture the fork/join becomes
+#     two parallel branches of the HIP graph, which the runtime does execute concurrently on two hardware queues.
+#     MEASURED SLOWER on one MI355X (config 2: 2.00 ms against 1.87 ms per step; config 3: 38.29 against 38.39 ms;
+#     kernel timeline in profiles/r03_wgrad_fork_trace.txt): forward / backward / weight-gradient workgroups each fill
+#     a CU (512 threads x 256 registers, 75-128 KiB of LDS), so the two launches can only share the chip CU by CU —
+#     and the weight-gradient stream is limited PER CU (~9-10 B/clk: LDS-DMA in flight over HBM latency), not chip-wide:
+#     every CU handed to the backward machine takes its share of the stream rate away, the 8-us compositing kernel
+#     between the two waits 230 us for a free CU behind 0.2-ms jobs, and the split launch pays a second ramp and tail.
+#     Kept as an option for chips / shapes where that balance differs; per-kernel timing (bench.py's roofline leg,
+#     rocprofv3 --stats) is always taken in the serial schedule.
 BATCH_WGRADS = True
+WGRAD_OVERLAP = os.environ.get("HN_WGRAD_OVERLAP", "0") == "1"
 _PENDING: List[PendingWgrad] = []
 _PENDING_TASK = [-1]      # autograd graph-task id the pending entries belong to
+_FORKED: List[PendingWgrad] = []     # launched on the side stream, not yet joined (keeps their stashes alive)
+_SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
 
 
 _HELD: List[PendingWgrad] = []       # bucket-1 shares (machine.WGRAD_SPLIT_OFFSET), launched by flush_held_wgrads()
+
+
+def set_wgrad_overlap(on: bool):
+    """Switch between the forked (side-stream) and the serial (one batched launch) weight-gradient schedule.
+    A captured graph keeps the schedule it was captured with."""
+    global WGRAD_OVERLAP
+    WGRAD_OVERLAP = bool(on)
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = str(device)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _fork_wgrad(p: PendingWgrad):
+    """Launch one program's weight-gradient jobs on the side stream, ordered behind everything the main stream has
+    been given so far (its backward-data kernel wrote the dZ stash the jobs read)."""
+    dev = p.stash.device
+    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        launch_pending_wgrads([p])
+    _FORKED.append(p)
+
+
+def _join_wgrads():
+    """Main stream waits for the side stream; only then may the stashes return to the allocator (they were
+    allocated on the main stream: freed after the join, every later use is ordered behind the side stream's reads)."""
+    if not _FORKED:
+        return
+    devs = {str(p.stash.device): p.stash.device for p in _FORKED}
+    for dev in devs.values():
+        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+    _FORKED.clear()
 
 
 def _flush_wgrads():
@@ -222,6 +279,7 @@ def _flush_wgrads():
     _HELD.extend(p for p in pending if p.bucket != 0)
     if now:
         launch_pending_wgrads(now)
+    _join_wgrads()
 
 
 def held_wgrads() -> int:
@@ -239,12 +297,15 @@ def flush_held_wgrads():
 
 def _defer_wgrad(p: PendingWgrad):
     task = torch._C._current_graph_task_id()
-    if _PENDING and _PENDING_TASK[0] != task:
+    if (_PENDING or _FORKED) and _PENDING_TASK[0] != task:
         _flush_wgrads()     # left over from a backward pass that did not reach its callback (an exception)
-    if not _PENDING:
+    if not _PENDING and not _FORKED:
         _PENDING_TASK[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
-    _PENDING.append(p)
+    if WGRAD_OVERLAP and p.bucket == 0:
+        _fork_wgrad(p)
+    else:
+        _PENDING.append(p)
 
 
 def run_program(call: ProgramCall, srcs: Sequence[Optional[torch.Tensor]], samples_per_ray: int,
@@ -411,6 +472,48 @@ def sample_pdf(weights, z, u, origins=None, directions=None, want_points=True, b
 
 
 # --------------------------------------------------------------------------------------------
+# random draws
+# --------------------------------------------------------------------------------------------
+_DRAW_STATE: Dict[str, torch.Tensor] = {}
+FAST_DRAWS = os.environ.get("HN_FAST_DRAWS", "1") != "0"
+
+
+def seed_draws(seed: Optional[int] = None, device=None):
+    """(Re)seed the on-device generator of `random_draws` (default: torch.initial_seed(), i.e. what torch.manual_seed
+    set).  The state {seed, offset, ticket} lives in device memory and is advanced by the kernel itself."""
+    L.load()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    seed = torch.initial_seed() if seed is None else int(seed)
+    st = torch.tensor([seed & 0x7fffffffffffffff, 0, 0], dtype=torch.int64, device=device)
+    _DRAW_STATE[str(device)] = st
+    return st
+
+
+def random_draws(specs: Sequence[Tuple[Tuple[int, ...], str]], device) -> List[torch.Tensor]:
+    """One launch (hn_random_fill) for all the random tensors of a render step.  specs: [(shape, 'uniform' | 'normal')]
+    -> fp32 tensors on `device`: U[0,1) (24 bits, as torch.rand) / N(0,1).  Philox4x32-10 with a device-resident
+    counter: graph replays draw fresh numbers; `torch.manual_seed` before the first call (or `seed_draws`) makes the
+    sequence reproducible.  Not the same stream as torch's own generator (nor is torch's GPU stream its CPU one)."""
+    L.load()
+    if len(specs) > L.HN_MAX_DRAWS:
+        raise L.HnError(f"at most {L.HN_MAX_DRAWS} buffers per random_draws call")
+    device = torch.device(device)
+    st = _DRAW_STATE.get(str(device))
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.HnError("random_draws: first use inside a stream capture (run a warm-up step first)")
+        st = seed_draws(None, device)
+    outs = [torch.empty(shape, dtype=torch.float32, device=device) for shape, _ in specs]
+    arr = (L.HnDraw * len(specs))()
+    for i, ((shape, kind), t) in enumerate(zip(specs, outs)):
+        if kind not in ("uniform", "normal"):
+            raise ValueError(kind)
+        arr[i].ptr, arr[i].n, arr[i].kind = t.data_ptr(), t.numel(), 0 if kind == "uniform" else 1
+    L.launch("hn_random_fill", arr, C.c_int(len(specs)), L.ptr(st), L.stream_handle())
+    return outs
+
+
+# --------------------------------------------------------------------------------------------
 # compositing
 # --------------------------------------------------------------------------------------------
 class _CompositeFn(torch.autograd.Function):
@@ -525,6 +628,22 @@ class _MseFn(torch.autograd.Function):
         L.launch("hn_mse_loss_backward", L.ptr(c), L.ptr(f), L.ptr(t), C.c_int64(c.numel()), L.ptr(g), L.ptr(dc),
                  L.ptr(df), L.stream_handle())
         return dc, df, None
+
+
+_ROOT_GRADS: Dict[tuple, torch.Tensor] = {}
+
+
+def backward(loss: torch.Tensor, weight: float = 1.0):
+    """`(weight * loss).backward()` without the two launches autograd adds around it: the root gradient is a cached
+    device scalar holding `weight` (loss.backward() alone fills a fresh ones_like every call, and `loss * w` is one
+    more elementwise kernel) — what training.TrainStep and bench.py call once per step / chunk."""
+    key = (str(loss.device), float(weight), loss.dtype)
+    g = _ROOT_GRADS.get(key)
+    if g is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.HnError("functional.backward: first use of a new weight inside a stream capture (run a warm-up step)")
+        g = _ROOT_GRADS[key] = torch.full((), float(weight), dtype=loss.dtype, device=loss.device)
+    loss.backward(gradient=g)
 
 
 def mse_loss(coarse: torch.Tensor, fine: Optional[torch.Tensor], target: torch.Tensor) -> torch.Tensor:

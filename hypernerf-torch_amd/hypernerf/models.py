@@ -427,7 +427,7 @@ class NerfModel(nn.Module):
                                                gather_idx=idx)
             warped = warped.view(b, s, -1)
             return self._composite_level(out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity,
-                                         dust, keep, b, s, points.device)
+                                         dust, keep, b, s, points.device, level)
         tab = None
         if (self.FUSE_LEVELS and not metadata_encoded and metadata.get('hyper_point') is None
                 and not return_warp_jacobian and not (use_warp and self.hyper_slice_method == 'bendy_sheet')):
@@ -458,7 +458,7 @@ class NerfModel(nn.Module):
             else:
                 warped = xyz
             return self._composite_level(out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity,
-                                         dust, keep, b, s, points.device)
+                                         dust, keep, b, s, points.device, level)
         if use_warp:
             warp_embed = metadata['encoded_warp'] if metadata_encoded else self.warp_embed(metadata[self.warp_embed_key])
         else:
@@ -482,7 +482,7 @@ class NerfModel(nn.Module):
         rgb, alpha = F.run_program(call, [warped.reshape(b * s, n_ch), viewdirs if self.use_viewdirs else None,
                                           nerf_embed], s, self.precision)
         return self._composite_level(out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity,
-                                     dust, keep, b, s, points.device)
+                                     dust, keep, b, s, points.device, level)
 
     def _empty_result(self, like: torch.Tensor, use_warp: bool):
         """Zero rays in, zero rays out (the reference's ATen ops all accept empty batches): no kernel is launched."""
@@ -501,13 +501,15 @@ class NerfModel(nn.Module):
         return out
 
     def _composite_level(self, out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity, dust, keep,
-                         b, s, device):
+                         b, s, device, level=None):
         """noise_regularize + Softplus + filter_sigma + volumetric_rendering + median-depth gather
         (models.py:485-489, 650-669) in the compositing kernel."""
         scale = 1.0
         if noise is None and (self.noise_std is not None) and self.noise_std > 0.0 and self.use_stratified_sampling:
-            noise = torch.randn((b, s, 1), device=device, dtype=torch.float32)      # scaled inside the kernel
-            scale = float(self.noise_std)
+            noise = getattr(self, '_auto_noise', {}).pop(level, None) if level is not None else None   # drawn by forward()
+            if noise is None or tuple(noise.shape) != (b, s, 1):
+                noise = torch.randn((b, s, 1), device=device, dtype=torch.float32)
+            scale = float(self.noise_std)                                              # scaled inside the kernel
         res = F.composite(rgb.view(b, s, 3), alpha.view(b, s), noise, z_vals, directions, warped, variant=0,
                           white_bg=self.use_white_background, sample_at_infinity=use_sample_at_infinity,
                           want_median=True, dust_threshold=dust, keep=keep, noise_scale=scale)
@@ -536,6 +538,30 @@ class NerfModel(nn.Module):
         b = origins.shape[0]
         if b == 0:
             return self._empty_result(origins, use_warp)
+        # every draw the caller did not supply, in ONE launch (F.random_draws) instead of the reference's four ATen
+        # calls (model_utils.py:31 t_rand, :226 u, :300-317 the density noise of each level); the noise stays N(0,1)
+        # and is scaled by noise_std inside the compositing kernel
+        self._auto_noise = {}
+        if self.use_stratified_sampling and F.FAST_DRAWS:
+            nc, nf = self.num_coarse_samples, self.num_fine_samples
+            noisy = (self.noise_std is not None) and self.noise_std > 0.0
+            want = []
+            if 't_rand' not in rng:
+                want.append(('t_rand', (b, nc), 'uniform'))
+            if noisy and 'noise_coarse' not in rng:
+                want.append(('noise_coarse', (b, nc, 1), 'normal'))
+            if nf > 0 and 'u' not in rng:
+                want.append(('u', (b, nf), 'uniform'))
+            if nf > 0 and noisy and 'noise_fine' not in rng:
+                want.append(('noise_fine', (b, nc + nf, 1), 'normal'))
+            if want:
+                got = F.random_draws([(shape, kind) for _, shape, kind in want], origins.device)
+                rng = dict(rng)
+                for (name, _, _), t in zip(want, got):
+                    if name.startswith('noise_'):
+                        self._auto_noise[name[6:]] = t
+                    else:
+                        rng[name] = t
         z_vals, points = model_utils.sample_along_rays(origins, directions, self.num_coarse_samples, near, far,
                                                        self.use_stratified_sampling, self.use_linear_disparity,
                                                        t_rand=rng.get('t_rand'))

@@ -81,7 +81,7 @@ class TrainStep:
             results = self.model(model_utils.prepare_ray_dict(rays), dict(_EXTRA), **kw)
             w = rays.shape[0] / b
             loss = self.loss_fn(results, rgbs)
-            (loss if w == 1.0 else loss * w).backward()          # into arena.grad (zeroed by the previous Adam launch)
+            F.backward(loss, w)          # into arena.grad (zeroed by the previous Adam launch); cached root gradient = w
             if i + self.chunk < b:
                 F.flush_held_wgrads()        # only the LAST chunk's held jobs overlap with the all-reduce (a held
                                              # job keeps its chunk's activation stash alive)

@@ -335,6 +335,19 @@ int hn_embed_gather(const float* table, const int64_t* idx, int n_rays, int dim,
 int hn_embed_backward(const float* d_points, int ld, int col0, const int64_t* idx, int n_rays,
                       int n_samples, int dim, int n_rows, float* d_table, hnStream_t stream);
 
+/* Random draws of a render step in one launch (replaces the reference's torch.rand / torch.randn calls:
+ * model_utils.py:31 t_rand, :226 u, :300-317 density noise).  Counter-based Philox4x32-10; state_dev = uint64[3]
+ * {seed, offset, ticket (must start 0)} in device memory: the kernel advances `offset` itself, so a launch captured
+ * in a HIP graph draws new numbers on every replay.  kind 0 = U[0,1) (24-bit, as torch.rand), 1 = N(0,1). */
+#define HN_MAX_DRAWS 8
+typedef struct HnDraw {
+  float* ptr;      /* device buffer */
+  int64_t n;       /* floats to fill */
+  int32_t kind;
+  int32_t pad;
+} HnDraw;
+int hn_random_fill(const HnDraw* draws_host, int n_draws, uint64_t* state_dev, hnStream_t stream);
+
 /* The reference's loss head (losses.py:4-14): loss = mean((coarse - gt)^2) [+ mean((fine - gt)^2)] over (B,3) pixels,
  * one launch forward (one workgroup; the result is written, not accumulated) and one launch backward:
  * d_coarse = d_fine-style 2 (pred - gt) / n * g_loss[0] (g_loss on the device; NULL = 1).  fine / d_fine may be NULL. */

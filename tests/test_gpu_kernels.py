@@ -8,8 +8,8 @@ import pytest
 import torch
 
 import hashprng as H
-import hypernerf_torch_amd  # noqa: F401
-from gpu_common import DEV, assert_close, assert_grad_close, rays_for
+import hypernerf_torch_amd as HN
+from gpu_common import DEV, EMB, assert_close, assert_grad_close, rays_for
 from hypernerf_torch_amd import _lib as L
 from hypernerf_torch_amd import functional as F
 from hypernerf_torch_amd.hypernerf import model_utils as MU
@@ -298,3 +298,82 @@ def test_arena_adam_matches_torch_adam(weight_decay):
     o0, n0 = arena.offsets[0], p1[0].numel()
     assert_close(opt.exp_avg[o0:o0 + n0].view_as(p1[0]), st["exp_avg"], 5e-6, "exp_avg")
     assert_close(opt.exp_avg_sq[o0:o0 + n0].view_as(p1[0]), st["exp_avg_sq"], 5e-6, "exp_avg_sq")
+
+
+def test_random_draws_one_launch_statistics_and_replay():
+    """hn_random_fill (the render step's draws in one launch; replaces torch.rand / torch.randn of model_utils.py:31,
+    226, 300-317): ranges, moments and a Kolmogorov-Smirnov distance of both distributions, independence across
+    buffers and launches, reproducibility from the seed, ragged sizes, and a HIP-graph replay drawing fresh numbers
+    (the offset lives on the device and is advanced by the kernel itself)."""
+    from scipy import stats
+    F.seed_draws(1234)
+    shapes = [((1024, 64), "uniform"), ((1024, 64, 1), "normal"), ((1024, 64), "uniform"), ((1024, 128, 1), "normal"),
+              ((7,), "normal"), ((5, 3), "uniform")]
+    a = F.random_draws(shapes, DEV)
+    assert [tuple(t.shape) for t in a] == [s for s, _ in shapes]
+    u0, n0, u1, n1 = (t.cpu().double().reshape(-1).numpy() for t in a[:4])
+    for u in (u0, u1):
+        assert u.min() >= 0.0 and u.max() < 1.0
+        assert abs(u.mean() - 0.5) < 4 * (1 / 12 / u.size) ** 0.5 and abs(u.var() - 1 / 12) < 2e-3
+        assert stats.kstest(u, "uniform").statistic < 1.63 / u.size ** 0.5            # 1 % level
+    for n in (n0, n1):
+        assert np.isfinite(n).all() and abs(n.mean()) < 4 / n.size ** 0.5 and abs(n.var() - 1.0) < 2e-2
+        assert stats.kstest(n, "norm").statistic < 1.63 / n.size ** 0.5
+        assert np.abs(n).max() < 6.0
+    assert abs(np.corrcoef(u0, u1)[0, 1]) < 0.02 and abs(np.corrcoef(n0, n1[:n0.size])[0, 1]) < 0.02
+    assert abs(np.corrcoef(n0[:-1], n0[1:])[0, 1]) < 0.02                            # the two Box-Muller outputs of a pair
+    b = F.random_draws(shapes, DEV)
+    assert not torch.equal(a[0], b[0]) and abs(np.corrcoef(u0, b[0].cpu().double().reshape(-1).numpy())[0, 1]) < 0.02
+    F.seed_draws(1234)
+    c = F.random_draws(shapes, DEV)
+    assert all(torch.equal(x, y) for x, y in zip(a, c)), "same seed, same sequence"
+    F.seed_draws(99)
+    assert not torch.equal(F.random_draws(shapes, DEV)[0], a[0])
+    # graph replay: the captured launch must not repeat its numbers
+    F.seed_draws(5)
+    F.random_draws(shapes[:2], DEV)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = F.random_draws(shapes[:2], DEV)
+    seen = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        seen.append([t.clone() for t in outs])
+    assert not torch.equal(seen[0][0], seen[1][0]) and not torch.equal(seen[1][1], seen[2][1])
+
+
+def test_model_draws_are_one_launch_and_reproducible():
+    """NerfModel.forward draws t_rand, u and both levels' noise through ONE hn_random_fill launch (no ATen RNG kernel
+    left in the step); torch.manual_seed + seed_draws reproduces a stochastic forward exactly; supplied draws are
+    honoured (the fixtures' path) and HN_FAST_DRAWS=0 falls back to torch's generator."""
+    from hypernerf_torch_amd.hypernerf import models as M
+    HN.set_precision("fp32")
+    m = M.NerfModel(EMB, n_samples_coarse=16, n_samples_fine=16, noise_std=1.0, hyper_slice_method="bendy_sheet",
+                    use_nerf_embed=True, use_alpha_cond=True, view_fourier_dim=6).to(DEV)
+    o, d, idx = rays_for(3, 24)
+    rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+            "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+    L.KERNEL_TIMES = {}
+    try:
+        with torch.no_grad():
+            F.seed_draws(7)
+            a = m(rays, {})
+        names = [k.split("[")[0] for k in L.collect_kernel_times()]
+    finally:
+        L.KERNEL_TIMES = None
+    assert names.count("hn_random_fill") == 1
+    with torch.no_grad():
+        b = m(rays, {})
+        F.seed_draws(7)
+        c = m(rays, {})
+    assert not torch.equal(a["fine"]["rgb"], b["fine"]["rgb"]), "a second forward must draw new numbers"
+    assert torch.equal(a["fine"]["rgb"], c["fine"]["rgb"]) and torch.equal(a["coarse"]["weights"], c["coarse"]["weights"])
+    # supplied draws win over the generator
+    rng = {"t_rand": H.uniform(3, "t", (24, 16), 0, 1).to(DEV), "u": H.uniform(3, "u", (24, 16), 0, 1).to(DEV),
+           "noise_coarse": H.normal(3, "n1", (24, 16, 1)).to(DEV), "noise_fine": H.normal(3, "n2", (24, 32, 1)).to(DEV)}
+    with torch.no_grad():
+        x = m(rays, {}, rng=rng)
+        y = m(rays, {}, rng=rng)
+    assert torch.equal(x["fine"]["rgb"], y["fine"]["rgb"])
