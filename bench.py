@@ -292,8 +292,10 @@ def main():
             # graphs around the collectives: forward+backward (+ first weight-gradient bucket) | all-reduce(bucket 0)
             # with the held weight-gradient bucket replayed next to it | all-reduce(bucket 1) | Adam
             HF.flush_held_wgrads()
-            gfb = GraphedStep(fwd_bwd_dp, warmup=3, warmup_fn=lambda: (fwd_bwd_dp(), HF.flush_held_wgrads()))
-            gheld = GraphedStep(HF.flush_held_wgrads, warmup=0, pool=gfb.graph.pool()) if HF.held_wgrads() else None
+            gfb = GraphedStep(fwd_bwd_dp, warmup=3, mutates_params=False,
+                              warmup_fn=lambda: (fwd_bwd_dp(), HF.flush_held_wgrads()))
+            gheld = (GraphedStep(HF.flush_held_wgrads, warmup=0, pool=gfb.graph.pool(), mutates_params=False)
+                     if HF.held_wgrads() else None)
             arena.zero_grad()
             gopt = GraphedStep(opt.step, warmup=1)
 

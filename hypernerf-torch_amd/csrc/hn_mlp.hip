@@ -90,6 +90,9 @@ HN_DEV void hn_stage_sources(float* srcv, const HnMlpArgs& a, int p, int ray, in
   }
 }
 
+// (Never a gathered source: machine.Program refuses to leave identity features of a source in `no_direct` unstaged.
+// Handling the gather here as well makes hipcc address the kernel arguments dynamically and copy all 2.5 KB of them
+// to scratch, in every forward kernel.)
 HN_DEV float hn_direct_source(const HnFeat e, const HnMlpArgs& a, int p, int ray) {
   const int sid = (e.packed >> 8) & 15, col = (e.packed >> 24) & 255;
   const float* base = a.src[0].ptr;

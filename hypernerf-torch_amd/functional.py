@@ -92,12 +92,24 @@ class _ProgramFn(torch.autograd.Function):
             flat_srcs.append((s2, per_ray))
         if n_points is None:
             raise L.HnError("a program needs at least one per-point source")
+        if samples_per_ray <= 0 or n_points % samples_per_ray:
+            raise L.HnError(f"{n_points} points are not a whole number of rays of {samples_per_ray} samples")
+        n_rays = n_points // samples_per_ray
+        for i, fs in enumerate(flat_srcs):      # the kernels index per-ray sources and gather indices by ray, unchecked
+            if fs is None:
+                continue
+            if len(fs) > 2 and fs[2].numel() != n_rays:
+                raise L.HnError(f"gather index holds {fs[2].numel()} rows for {n_rays} rays")
+            if len(fs) == 2 and fs[1] and fs[0].shape[0] != n_rays:
+                raise L.HnError(f"per-ray source {i} holds {fs[0].shape[0]} rows for {n_rays} rays")
         outs = [torch.empty(n_points, w, dtype=torch.float32, device=device) for w in call.dst_widths]
         stash, masks = call.runner.forward(mode, n_points, samples_per_ray, flat_srcs, outs, training)
         if call.fill_from_gather is not None:
             k, c0 = call.fill_from_gather
             table, _, gidx = flat_srcs[call.gather_src]
-            rows = table.index_select(0, gidx.clamp(0, table.shape[0] - 1))
+            safe = gidx.clamp(0, table.shape[0] - 1)
+            rows = table.index_select(0, safe)
+            rows.masked_fill_((safe != gidx)[:, None], float("nan"))    # the kernels stage NaN for such a ray: so does the copy
             outs[k].view(-1, samples_per_ray, outs[k].shape[1])[:, :, c0:c0 + table.shape[1]] = rows[:, None, :]
         ctx.call, ctx.mode, ctx.spr, ctx.n_src, ctx.n_points = call, mode, samples_per_ray, n_src, n_points
         ctx.flat_srcs = flat_srcs

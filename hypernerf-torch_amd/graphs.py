@@ -15,10 +15,13 @@ import torch
 
 class GraphedStep:
     def __init__(self, fn: Callable[[], object], warmup: int = 3, warmup_fn: Optional[Callable[[], object]] = None,
-                 pool=None):
+                 pool=None, mutates_params: bool = True):
         """warmup_fn: what the warm-up runs execute instead of `fn` (a step whose tail is captured separately runs
         that tail as well); warmup=0 with warmup_fn=None: capture only (`fn` consumes state a warm-up run would use
-        up); pool: share the memory pool of another graph (`other.graph.pool()`)."""
+        up); pool: share the memory pool of another graph (`other.graph.pool()`); mutates_params: the captured work
+        contains an optimizer launch (False for inference / forward+backward-only graphs: their replays then do not
+        invalidate every packed weight stream of the process)."""
+        self.mutates_params = bool(mutates_params)
         if warmup > 0 or warmup_fn is not None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -35,6 +38,7 @@ class GraphedStep:
         self.graph.replay()
         # the replay may have stepped an optimizer (parameters changed behind Python's back): packed weight streams
         # of inference forwards that follow must be rebuilt
-        from . import machine
-        machine.note_parameters_changed()
+        if self.mutates_params:
+            from . import machine
+            machine.note_parameters_changed()
         return self.out

@@ -140,13 +140,32 @@ class NerfModel(nn.Module):
         self._template_calls: Dict[Any, F.ProgramCall] = {}
         self._det_u: Dict[Any, torch.Tensor] = {}
         self.precision: Optional[str] = None   # None = package default (functional.set_precision)
+        # the constructor's own public attributes shape the compiled programs (hyper_slice_method, use_viewdirs,
+        # use_alpha_condition, the frequencies, sample counts ...): changing one later drops the program cache
+        self._structural = frozenset(k for k in self.__dict__ if not k.startswith("_") and k != "training")
 
     def __setattr__(self, name, value):
         # replacing a sub-module (e.g. `model.warp_field = SE3Field(...)`, BASELINE config 5) after a forward pass:
         # the compiled level programs hold the OLD module's parameters — drop them, they are rebuilt on the next call
-        if isinstance(value, nn.Module) and "_template_calls" in self.__dict__:
+        # ... and so does any public non-tensor attribute that shapes the programs (hyper_slice_method, use_viewdirs,
+        # use_alpha_condition, the frequencies, ...): the cached programs were compiled for the old value
+        if "_template_calls" in self.__dict__ and (isinstance(value, nn.Module) or
+                                                   name in self.__dict__.get("_structural", ())):
             self._template_calls.clear()
         super().__setattr__(name, value)
+
+    def _live_call(self, key):
+        """Cached program for `key`, unless a parameter it was compiled over is no longer a parameter of this model
+        (a nested module swapped from outside, e.g. `model.warp_field.mlp = MLP(...)`, which __setattr__ of the
+        top-level module never sees): then every cached program is dropped and rebuilt."""
+        call = self._template_calls.get(key)
+        if call is None:
+            return None
+        ids = {id(p) for p in self.parameters()}
+        if any(id(p) not in ids for p in call.program.params):
+            self._template_calls.clear()
+            return None
+        return call
 
     # ---- properties of the reference ---------------------------------------------------------
     @property
@@ -206,7 +225,7 @@ class NerfModel(nn.Module):
         """Program of query_template (models.py:447-493): sources 0 = (warped) points (P, 3+H),
         1 = viewdirs (B,3), 2 = template GLO embedding (B,G)."""
         key = (level, n_point_ch, xyz_grad, hyper_grad)
-        call = self._template_calls.get(key)
+        call = self._live_call(key)
         if call is None:
             m = self.nerf_mlps_fine if level == 'fine' else self.nerf_mlps_coarse
             feats = posenc_features(0, range(3), self.xyz_freq, xyz_grad)
@@ -251,7 +270,7 @@ class NerfModel(nn.Module):
         by the kernels — conditions and, for the axis-aligned slice, the hyper coordinates are read from the row, and
         the row's gradient is reduced and scattered by the backward machine."""
         key = ("tgather", level, hyper_from_table, xyz_grad)
-        call = self._template_calls.get(key)
+        call = self._live_call(key)
         if call is None:
             m = self.nerf_mlps_fine if level == 'fine' else self.nerf_mlps_coarse
             G = self.GLO_dim
@@ -271,7 +290,7 @@ class NerfModel(nn.Module):
                     rgb_feats += copy_features(2, range(G), True)
             layers = modules.nerf_mlp_layers(m, f"nerf_mlps_{level}", AuxSpec(feats), alpha_aux,
                                              AuxSpec(rgb_feats) if rgb_feats else None)
-            call = F.ProgramCall(Program(layers, name=f"template_{level}"), [False, True, True], [3, 1],
+            call = F.ProgramCall(Program(layers, name=f"template_{level}", no_direct=(2,)), [False, True, True], [3, 1],
                                  [("g", 0), ("g", 1), ("y", 0)], gather_src=2)
             self._template_calls[key] = call
         return call
@@ -295,7 +314,19 @@ class NerfModel(nn.Module):
             return False
         if metadata.get('hyper_point') is not None:
             return False
-        return self.hyper_sheet_out_dim <= 4 or self.hyper_slice_method != 'bendy_sheet'
+        if not (self.hyper_sheet_out_dim <= 4 or self.hyper_slice_method != 'bendy_sheet'):
+            return False
+        # warp, sheet and template share ONE budget of staged source components / source-gradient rows in a fused
+        # program (32 each): a configuration that compiles network by network (a large GLO_dim) may not fit — then the
+        # level runs unfused instead of raising
+        if ("nofuse",) in self._template_calls:
+            return False
+        try:
+            self._level_call('coarse')
+        except NotImplementedError:
+            self._template_calls[("nofuse",)] = None
+            return False
+        return True
 
     def _level_call(self, level: str) -> F.ProgramCall:
         """The whole level as one program of the MLP machine (reference: map_points models.py:545-581 followed by
@@ -304,7 +335,7 @@ class NerfModel(nn.Module):
         launch (they never leave the workgroup), read back from the output tensor in the backward launch.
         Outputs: 0 = warped points (P, 3+H), 1 = rgb (P,3), 2 = alpha (P,1)."""
         key = ("level", level)
-        call = self._template_calls.get(key)
+        call = self._live_call(key)
         if call is None:
             m = self.nerf_mlps_fine if level == 'fine' else self.nerf_mlps_coarse
             G = self.GLO_dim
@@ -341,7 +372,8 @@ class NerfModel(nn.Module):
                     rgb_feats += copy_features(2, range(G), True)
             layers += modules.nerf_mlp_layers(m, f"nerf_mlps_{level}", AuxSpec(feats), alpha_aux,
                                               AuxSpec(rgb_feats) if rgb_feats else None, dst_rgb=1, dst_alpha=2)
-            call = F.ProgramCall(Program(layers, name=f"level_{level}"), [False, True, True, False], [3 + h, 3, 1],
+            call = F.ProgramCall(Program(layers, name=f"level_{level}", no_direct=(2,)), [False, True, True, False],
+                                 [3 + h, 3, 1],
                                  [("g", 1), ("g", 2), ("y", 1), ("go", 0)], gather_src=2, bwd_src_from_out={3: 0},
                                  fill_from_gather=fill)
             self._template_calls[key] = call
@@ -354,6 +386,8 @@ class NerfModel(nn.Module):
         out = []
         fused = False
         for key, call in self._template_calls.items():
+            if call is None:            # the ("nofuse",) marker
+                continue
             if key[0] == "level":
                 out.append((f"level_{key[1]}", call.program, n_rays * (nc if key[1] == 'coarse' else nc + nf)))
                 fused = True
@@ -433,6 +467,18 @@ class NerfModel(nn.Module):
                 and not return_warp_jacobian and not (use_warp and self.hyper_slice_method == 'bendy_sheet')):
             tab = self._gather_table(use_warp)
         if tab is not None:
+            # a GLO table too wide for the staging / source-gradient budget of ONE program: the generic path below
+            # (embedding rows looked up first, surplus copies read directly) takes over instead of raising
+            if ("nogather",) in self._template_calls:
+                tab = None
+            else:
+                try:
+                    self._template_gather_call(level, use_warp and self.hyper_slice_method == 'axis_aligned_plane',
+                                               torch.is_grad_enabled() and use_warp)
+                except NotImplementedError:
+                    self._template_calls[("nogather",)] = None
+                    tab = None
+        if tab is not None:
             # the warp (if any) runs as its own program; the template reads conditions / axis-aligned hyper
             # coordinates straight from the GLO table (no gather kernel, no (B,S,H) expand + cat in front of it, the
             # row gradient reduced in the backward machine)
@@ -453,7 +499,10 @@ class NerfModel(nn.Module):
                                               emb_mod.embed.weight], s, self.precision, gather_idx=idx)
             if from_table:
                 with torch.no_grad():
-                    rows = emb_mod.embed.weight.index_select(0, idx.reshape(-1).clamp(0, emb_mod.embed.weight.shape[0] - 1))
+                    flat = idx.reshape(-1)
+                    safe = flat.clamp(0, emb_mod.embed.weight.shape[0] - 1)
+                    rows = emb_mod.embed.weight.index_select(0, safe)
+                    rows.masked_fill_((safe != flat)[:, None], float("nan"))   # as the kernels' own gather poisons it
                 warped = torch.cat([xyz, rows[:, None, :].expand(b, s, rows.shape[-1])], dim=-1)
             else:
                 warped = xyz

@@ -161,10 +161,13 @@ class SlotInfo:
 class Program:
     """Compiles a list of `Layer`s (forward order) into device tables for both numeric modes."""
 
-    def __init__(self, layers: List[Layer], n_src: int = 4, name: str = "mlp"):
+    def __init__(self, layers: List[Layer], n_src: int = 4, name: str = "mlp", no_direct: Sequence[int] = ()):
+        """no_direct: source indices whose components must all be staged in LDS (a GATHERED per-ray source: the direct
+        global read of surplus identity features, hn_direct_source, does not gather)."""
         self.name = name
         self.layers = layers
         self.n_src = n_src
+        self.no_direct = frozenset(no_direct)
         self.params: List[torch.nn.Parameter] = []
         self.slots: List[SlotInfo] = []
         self.feat_table: List[Feature] = []
@@ -211,6 +214,17 @@ class Program:
                     self.dsrc_map[(gi.from_dsrc[0], gi.from_dsrc[1] + i)] = 8 * q + i
                 self.reserved_slots.update(range(8 * q, 8 * q + 4))
                 q += 1
+        # staging slots go to the components of TRIGONOMETRIC features first, whichever layer uses them (they can only
+        # be evaluated from LDS); identity copies take what is left and are read directly from global memory beyond that
+        # — otherwise a wide per-ray condition early in the program (GLO_dim >= ~24) starves a later encoder
+        for ly in self.layers:
+            if ly.aux is not None:
+                for ft in ly.aux.feats:
+                    if ft.kind not in (L.HN_FEAT_ZERO, L.HN_FEAT_ID) and (ft.src, ft.comp) not in self.comp_map:
+                        if len(self.comp_map) >= L.HN_MAX_COMPS:
+                            raise NotImplementedError(
+                                f"{ly.name}: more than {L.HN_MAX_COMPS} distinct encoded source components")
+                        self.comp_map[(ft.src, ft.comp)] = len(self.comp_map)
         for ly in self.layers:
             ws = list(ly.weight) if isinstance(ly.weight, (list, tuple)) else [ly.weight]
             bs = list(ly.bias) if isinstance(ly.bias, (list, tuple)) else [ly.bias] * len(ws)
@@ -255,9 +269,11 @@ class Program:
                             # identity features (wide raw inputs of stand-alone modules) are read directly
                             if len(self.comp_map) < L.HN_MAX_COMPS:
                                 self.comp_map[(ft.src, ft.comp)] = len(self.comp_map)
-                            elif ft.kind != L.HN_FEAT_ID or ft.comp > 255:
+                            elif ft.kind != L.HN_FEAT_ID or ft.comp > 255 or ft.src in self.no_direct:
                                 raise NotImplementedError(
-                                    f"{ly.name}: more than {L.HN_MAX_COMPS} distinct encoded source components")
+                                    f"{ly.name}: more than {L.HN_MAX_COMPS} distinct encoded source components"
+                                    + (" (identity features of a gathered source cannot be read directly)"
+                                       if ft.src in self.no_direct else ""))
                         if ft.need_grad and (ft.src, ft.comp) not in self.dsrc_map:
                             used = set(self.dsrc_map.values()) | self.reserved_slots
                             free = [k for k in range(L.HN_DSRC_COMPS) if k not in used]

@@ -110,3 +110,127 @@ class MultiStepLR:
         self.milestones, self.gamma = list(sd["milestones"]), float(sd["gamma"])
         self.base_lr, self.last_epoch = float(sd["base_lr"]), int(sd["last_epoch"])
         self._apply()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the rest of the reference's `get_scheduler` (utils/__init__.py:43-59): 'cosine', 'poly', and the GradualWarmup wrapper
+# (utils/warmup_scheduler.py) it puts around any of them when warmup_epochs > 0.  Pure host arithmetic on
+# `optimizer.param_groups[0]['lr']` (any object with that attribute: ArenaAdam or a torch optimizer), stepped once per
+# epoch; the device copy follows at the next `sync_hyper()`.  Pinned by tests/golden/g17_lr_schedules.npz, recorded
+# from the reference's own get_scheduler (incl. what torch's chainable schedulers make of the warm-up hand-over).
+# ------------------------------------------------------------------------------------------------------------------
+class _EpochScheduler:
+    def __init__(self, optimizer):
+        self.optimizer = optimizer
+        self.base_lr = float(optimizer.param_groups[0]["lr"])
+        self.last_epoch = 0
+
+    @property
+    def lr(self) -> float:
+        return float(self.optimizer.param_groups[0]["lr"])
+
+    def _set(self, lr: float):
+        self.optimizer.param_groups[0]["lr"] = float(lr)
+
+    def get_lr(self) -> float:          # the chainable form: next lr from last_epoch and the CURRENT lr
+        raise NotImplementedError
+
+    def step(self):
+        self.last_epoch += 1
+        self._set(self.get_lr())
+
+    def get_last_lr(self):
+        return [self.lr]
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k not in ("optimizer", "after")}
+
+    def load_state_dict(self, sd):
+        self.__dict__.update(sd)
+
+
+class StepLR(_EpochScheduler):
+    """'steplr' in torch's chainable form (lr *= gamma at every milestone): what MultiStepLR above computes in closed
+    form; this one can follow a warm-up that has changed the optimizer's lr."""
+
+    def __init__(self, optimizer, milestones: Sequence[int], gamma: float = 0.1):
+        super().__init__(optimizer)
+        self.milestones = sorted(int(m) for m in milestones)
+        self.gamma = float(gamma)
+
+    def get_lr(self):
+        return self.lr * self.gamma ** self.milestones.count(self.last_epoch)
+
+
+class CosineAnnealingLR(_EpochScheduler):
+    """'cosine' (utils/__init__.py:47-48: T_max = num_epochs, eta_min = 1e-8), torch's recursion."""
+
+    def __init__(self, optimizer, T_max: int, eta_min: float = 1e-8):
+        super().__init__(optimizer)
+        self.T_max, self.eta_min = int(T_max), float(eta_min)
+
+    def get_lr(self):
+        import math
+        e, T = self.last_epoch, self.T_max
+        if (e - 1 - T) % (2 * T) == 0:
+            return self.lr + (self.base_lr - self.eta_min) * (1 - math.cos(math.pi / T)) / 2
+        return ((1 + math.cos(math.pi * e / T)) / (1 + math.cos(math.pi * (e - 1) / T)) * (self.lr - self.eta_min)
+                + self.eta_min)
+
+
+class PolyLR(_EpochScheduler):
+    """'poly' as the reference states it (utils/__init__.py:49-52): lr = base_lr * (1 - epoch / num_epochs) ** poly_exp.
+    Upstream raises NameError here (`LambdaLR` is never imported), so there is nothing to pin it to."""
+
+    def __init__(self, optimizer, num_epochs: int, poly_exp: float = 0.9):
+        super().__init__(optimizer)
+        self.num_epochs, self.poly_exp = int(num_epochs), float(poly_exp)
+
+    def get_lr(self):
+        return self.base_lr * max(0.0, 1.0 - self.last_epoch / self.num_epochs) ** self.poly_exp
+
+
+class GradualWarmup(_EpochScheduler):
+    """GradualWarmupScheduler (utils/warmup_scheduler.py:4-66): lr ramps linearly from base_lr to base_lr * multiplier
+    over `total_epoch` epochs, then `after` takes over with its base_lr scaled by the multiplier — including the
+    hand-over epoch, where the reference asks the wrapped scheduler for a learning rate before ever stepping it."""
+
+    def __init__(self, optimizer, multiplier: float, total_epoch: int, after: _EpochScheduler = None):
+        if multiplier < 1.0:
+            raise ValueError('multiplier should be greater thant or equal to 1.')
+        super().__init__(optimizer)
+        self.multiplier, self.total_epoch, self.after, self.finished = float(multiplier), int(total_epoch), after, False
+
+    def get_lr(self):
+        if self.last_epoch > self.total_epoch:
+            if self.after is not None:
+                if not self.finished:
+                    self.after.base_lr = self.base_lr * self.multiplier
+                    self.finished = True
+                return self.after.get_lr()
+            return self.base_lr * self.multiplier
+        return self.base_lr * ((self.multiplier - 1.0) * self.last_epoch / self.total_epoch + 1.0)
+
+    def step(self):
+        if self.finished and self.after is not None:
+            self.after.step()
+        else:
+            super().step()
+
+
+def get_scheduler(hparams, optimizer):
+    """The reference's get_scheduler (utils/__init__.py:43-59) for ArenaAdam: hparams needs `lr_scheduler` and, per
+    kind, decay_step / decay_gamma | num_epochs | num_epochs / poly_exp, plus warmup_epochs / warmup_multiplier."""
+    kind = hparams.lr_scheduler
+    warm = getattr(hparams, "warmup_epochs", 0) > 0 and getattr(hparams, "optimizer", "adam") not in ("radam", "ranger")
+    if kind == 'steplr':
+        sch = (StepLR if warm else MultiStepLR)(optimizer, hparams.decay_step, hparams.decay_gamma)
+    elif kind == 'cosine':
+        sch = CosineAnnealingLR(optimizer, hparams.num_epochs, 1e-8)
+    elif kind == 'poly':
+        sch = PolyLR(optimizer, hparams.num_epochs, hparams.poly_exp)
+    else:
+        raise ValueError('scheduler not recognized!')
+    if warm:
+        sch = GradualWarmup(optimizer, hparams.warmup_multiplier, hparams.warmup_epochs, sch)
+    return sch

@@ -28,7 +28,7 @@ from .dist import GradSync
 from .graphs import GraphedStep
 from .hypernerf import model_utils
 from .losses import MSELoss, psnr
-from .optim import ArenaAdam, MultiStepLR
+from .optim import ArenaAdam, MultiStepLR, get_scheduler
 
 _EXTRA = {'nerf_alpha': None, 'warp_alpha': None, 'hyper_alpha': None, 'hyper_sheet_alpha': None}
 
@@ -36,7 +36,8 @@ _EXTRA = {'nerf_alpha': None, 'warp_alpha': None, 'hyper_alpha': None, 'hyper_sh
 class TrainStep:
     def __init__(self, model: torch.nn.Module, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, use_graph: bool = True, group=None, chunk: int = 32 * 1024,
-                 decay_step: Optional[Sequence[int]] = None, decay_gamma: float = 0.1, overlap_grad_sync: bool = False):
+                 decay_step: Optional[Sequence[int]] = None, decay_gamma: float = 0.1, overlap_grad_sync: bool = False,
+                 hparams=None):
         self.model = model
         self.arena = ParamArena(model.parameters())
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -58,6 +59,10 @@ class TrainStep:
                                    grad_scale=1.0 / self.world)
         # 'steplr' of the reference (utils/__init__.py:43-46): stepped once per epoch by the caller (`epoch_end`)
         self.scheduler = MultiStepLR(self.optimizer, decay_step, decay_gamma) if decay_step else None
+        # any scheduler of the reference's get_scheduler (utils/__init__.py:43-59): `hparams` carries lr_scheduler
+        # ('steplr' | 'cosine' | 'poly') and its arguments, warmup_epochs / warmup_multiplier for the warm-up wrapper
+        if hparams is not None and getattr(hparams, "lr_scheduler", None):
+            self.scheduler = get_scheduler(hparams, self.optimizer)
         self.loss_fn = MSELoss()
         self._graph: Optional[GraphedStep] = None
         self._rays = self._rgbs = None
@@ -122,9 +127,10 @@ class TrainStep:
         held jobs behind, which the capture of the second consumes."""
         snap = self._snapshot()
         F.flush_held_wgrads()
-        g1 = GraphedStep(self._forward_backward, warmup=2,
+        g1 = GraphedStep(self._forward_backward, warmup=2, mutates_params=False,
                          warmup_fn=lambda: (self._forward_backward(), F.flush_held_wgrads()))
-        g2 = GraphedStep(F.flush_held_wgrads, warmup=0, pool=g1.graph.pool()) if F.held_wgrads() else None
+        g2 = (GraphedStep(F.flush_held_wgrads, warmup=0, pool=g1.graph.pool(), mutates_params=False)
+              if F.held_wgrads() else None)
         self._restore(snap)
         return g1, g2
 

@@ -363,6 +363,12 @@ OPTION_CASES = {
     # every size argument of the constructor off its default
     "dims": (dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True, use_rgb_cond=True,
                   GLO_dim=4, xyz_fourier_dim=6, hyper_fourier_dim=3, view_fourier_dim=2, hyper_slice_out_dim=2), {}),
+    # GLO_dim 24: 3 + 3 + 24 + 7 = 37 source components for the fused level program, 5 more than the LDS staging
+    # holds, and surplus copies of a GATHERED table cannot be read directly -> per-network launches, not an error
+    "glo24": (dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True, GLO_dim=24), {}),
+    # GLO_dim 25: 25 + the 8 reserved head rows exceed the 32 source-gradient rows of ONE fused program -> the level
+    # falls back to per-network launches instead of raising
+    "glo25": (dict(hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True, GLO_dim=25), {}),
     # near / far overridden per call (models.py:690-693)
     "near_far": (dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=False, use_alpha_cond=False),
                  dict(near=0.15, far=0.85)),
@@ -434,6 +440,12 @@ def test_model_option_matrix_vs_oracle(case):
             # 1e-2 of the tensor's largest entry: measured worst 6.2e-3, the skip layer of the un-warped model, which
             # multiplies dZ with sin(2^9 x) features of raw points (two fp32 summation orders of ~1300 such terms)
             assert_grad_close(prm.grad, p[k].grad, 1e-2 if same == 1.0 else 2e-2, f"options {case} d {k}")
+        if case == "glo24":
+            # 37 source components for the fused level program, 5 more than the LDS staging holds, and the surplus
+            # belongs to the GATHERED table, which the direct global read does not gather: per-network launches
+            assert ("nofuse",) in m._template_calls and not any(k[0] == "level" for k in m._template_calls)
+        if case == "glo25":
+            assert ("nofuse",) in m._template_calls and not any(k[0] == "level" for k in m._template_calls)
         if case == "viewdirs":
             # the same forward with the embeddings looked up by the caller (metadata_encoded, models.py:609-622, 425-436)
             with torch.no_grad():
@@ -573,6 +585,55 @@ def test_replacing_a_submodule_after_a_forward_pass_rebuilds_the_programs():
             c = fresh(rays, {})["fine"]["rgb"]
         assert not torch.equal(a, b), "the new warp field must be used"
         assert torch.equal(b, c), "and give what a freshly built model with the same weights gives"
+    finally:
+        HN.set_precision("bf16")
+
+
+def test_structural_attribute_change_and_nested_swap_rebuild_the_programs():
+    """The compiled-program cache must not outlive what shaped it: (a) a structural attribute flipped after the first
+    forward (`use_viewdirs`), (b) a NESTED module replaced from outside (`model.warp_field.mlp = ...`, which the
+    top-level __setattr__ never sees) — both must render what a freshly built model with the same weights renders;
+    (c) a gather index of the wrong length is refused instead of indexing out of bounds."""
+    HN.set_precision("fp32")
+    try:
+        def build():
+            mm = models.NerfModel(EMB, n_samples_coarse=8, n_samples_fine=8, noise_std=None, **CASES["bendy_cond"]).to(DEV)
+            mm.use_stratified_sampling = False
+            return mm
+        m = build()
+        o, d, idx = rays_for(98, 16)
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        with torch.no_grad():
+            a = m(rays, {})["fine"]["rgb"].clone()
+            # (b) nested swap
+            new_mlp = modules.MLP(in_ch=m.warp_field.mlp.in_ch, out_ch=3, depth=6, width=128).to(DEV)
+            for p_ in new_mlp.parameters():
+                p_.mul_(2.0)
+            m.warp_field.mlp = new_mlp
+            b = m(rays, {})["fine"]["rgb"].clone()
+            fresh = build()
+            fresh.load_state_dict(m.state_dict())
+            c = fresh(rays, {})["fine"]["rgb"]
+            assert not torch.equal(a, b) and torch.equal(b, c), "nested module swap must rebuild the level programs"
+            # (a) structural flag
+            assert m.use_viewdirs
+            m.use_viewdirs = False
+            fresh2 = build()
+            fresh2.use_viewdirs = False
+            fresh2.load_state_dict(m.state_dict())
+            try:
+                e = m(rays, {})["fine"]["rgb"]
+                f = fresh2(rays, {})["fine"]["rgb"]
+                assert torch.equal(e, f), "flag flipped after the first forward must not reuse the stale program"
+            except (RuntimeError, ValueError) as exc:      # a flag the constructor sized layers for: both must refuse alike
+                with pytest.raises(type(exc)):
+                    fresh2(rays, {})
+            # (c)
+            m2 = build()
+            bad = dict(rays, metadata={k: idx[:5].to(DEV) for k in ("warp", "camera", "appearance", "time")})
+            with pytest.raises(L.HnError):
+                m2(bad, {})
     finally:
         HN.set_precision("bf16")
 
