@@ -70,7 +70,18 @@ struct WStream {
 // (srcv[ci][point]); a feature then costs two LDS reads (table entry, value) instead of a chain of global loads.
 // A source without a pointer is skipped: its components are published by the program itself (HN_OP_OUT w7).  A per-ray
 // source with a gather index reads row gather_idx[ray] (the GLO lookup); an index outside the table stages NaN.
-HN_DEV void hn_stage_sources(float* srcv, const HnMlpArgs& a, int p, int ray, int lane) {
+// x / 2pi as an unevaluated sum hi + lo (the product x * C_HI exactly, plus the tail of 1/2pi): what lets the bf16
+// forward take sin(2^k x) at full fp32 accuracy — 2^k * hi is exact, so is its fract (see hn_features4)
+#define HN_INV2PI_HI 0.15915494309189535f
+#define HN_INV2PI_LO ((float)(0.15915494309189535 - (double)0.15915494309189535f))
+HN_DEV void hn_rev_split(float x, float& hi, float& lo) {
+  hi = __fmul_rn(x, HN_INV2PI_HI);
+  lo = __builtin_fmaf(x, HN_INV2PI_LO, __builtin_fmaf(x, HN_INV2PI_HI, -hi));
+}
+// `rev` (bf16 forward only, else nullptr): planes [hi | lo] of n_trig x 32 floats behind the wave's value plane, for
+// the first n_trig staged components (the host orders components so that every encoded one comes first).
+HN_DEV void hn_stage_sources(float* srcv, const HnMlpArgs& a, int p, int ray, int lane, float* rev = nullptr,
+                             int n_trig = 0) {
   const int r = lane & 31, h = lane >> 5;
   for (int ci = h; ci < a.n_comps; ci += 2) {
     const int c = a.comps[ci];
@@ -79,14 +90,24 @@ HN_DEV void hn_stage_sources(float* srcv, const HnMlpArgs& a, int p, int ray, in
     if (sid == 1) s = a.src[1];
     if (sid == 2) s = a.src[2];
     if (sid == 3) s = a.src[3];
-    if (s.ptr == nullptr) continue;
-    long long row = s.per_ray ? ray : p;
-    bool ok = true;
-    if (s.gather_idx != nullptr) {
-      row = s.gather_idx[ray];
-      ok = row >= 0 && row < s.gather_rows;
+    float x = 0.0f;      // a source without a pointer: published later by the program itself; until then its planes
+                         // read as 0 (padding features point at component 0, and 0 * stale-NaN would poison a tile)
+    if (s.ptr != nullptr) {
+      long long row = s.per_ray ? ray : p;
+      bool ok = true;
+      if (s.gather_idx != nullptr) {
+        row = s.gather_idx[ray];
+        ok = row >= 0 && row < s.gather_rows;
+      }
+      x = ok ? s.ptr[(size_t)row * s.ld + col] : __builtin_nanf("");
     }
-    srcv[ci * 32 + r] = ok ? s.ptr[(size_t)row * s.ld + col] : __builtin_nanf("");
+    srcv[ci * 32 + r] = x;
+    if (rev != nullptr && ci < n_trig) {
+      float hi, lo;
+      hn_rev_split(x, hi, lo);
+      rev[ci * 32 + r] = hi;
+      rev[(n_trig + ci) * 32 + r] = lo;
+    }
   }
 }
 
@@ -107,10 +128,17 @@ HN_DEV float hn_direct_source(const HnFeat e, const HnMlpArgs& a, int p, int ray
 HN_DEV float hn_sin_rev(float t) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t)); }
 #define HN_INV_2PI 0.15915494309189535f
 
-// Derived feature table of the bf16 kernels (built in LDS at kernel start from HnFeat): everything a feature needs
-// without decoding its kind — value = idmask ? x : sin_rev(scale * x + phase), x = *(srcv + off):
-//   SIN: scale = f/2pi, phase 0 ; COS / SINP: phase 1/4 ; ZERO: scale = phase = 0 (sin 0 = 0) ; ID: idmask = ~0.
-// d value / dx = idmask ? 1 : 2pi scale * sin_rev(scale * x + phase + 1/4).
+// Derived feature tables of the bf16 kernels (built in LDS at kernel start from HnFeat): everything a feature needs
+// without decoding its kind.
+// Backward (hn_derive_feat, derivative only, argument accuracy uncritical): x = *(srcv + off),
+//   d value / dx = idmask ? 1 : 2pi scale * sin_rev(scale * x + phase + 1/4), scale = f / 2pi, phase 0 | 1/4.
+// Forward (hn_derive_feat_fwd): value = idmask ? x : sin_rev(fract(f * hi) + (f * lo + phase)) with (hi, lo) = x / 2pi
+//   from the staging planes: `off` = byte offset of x | byte offset of hi << 16 (lo sits n_trig planes further), scale =
+//   f itself.  For the power-of-two frequencies of posenc_orig f * hi and its fract are EXACT, the remaining sum is
+//   below 1.3: the argument of the hardware sine is good to ~1e-7 revolutions at every octave, where the one-FMA form
+//   (scale * x + phase, |t| up to 82 revolutions at f = 512) is good to 8e-6.  That error, rounded to bf16 and carried
+//   through the ReLUs, was 2/3 of the bf16 mode's gradient error against the bf16-operand oracle (4.8e-2 -> 1.6e-2
+//   relative L2 with precise sines).  SIN: phase 0 ; COS / SINP: 1/4 ; ZERO: scale = phase = 0.
 struct HnDFeat { unsigned off; float scale, phase; unsigned idmask; };
 HN_DEV HnDFeat hn_derive_feat(const HnFeat e) {
   const int kind = (e.packed >> 12) & 15;
@@ -122,25 +150,44 @@ HN_DEV HnDFeat hn_derive_feat(const HnFeat e) {
   d.idmask = (kind == HN_FEAT_ID || kind == HN_FEAT_ID_DIRECT) ? 0xffffffffu : 0u;
   return d;
 }
+HN_DEV HnDFeat hn_derive_feat_fwd(const HnFeat e, int n_comps, int n_trig) {
+  const int kind = (e.packed >> 12) & 15, ci = e.packed & 255;
+  HnDFeat d;
+  const bool trig = (kind == HN_FEAT_SIN || kind == HN_FEAT_COS || kind == HN_FEAT_SINP) && ci < n_trig;
+  // two staged values per feature: (A, B) = (hi, lo) of x / 2pi for a trigonometric feature, (x, x) for the others
+  const unsigned oa = trig ? (unsigned)(n_comps + ci) * 128u : (unsigned)ci * 128u;
+  const unsigned ob = trig ? (unsigned)(n_comps + n_trig + ci) * 128u : oa;
+  d.off = oa | ob << 16;
+  d.scale = trig ? e.freq : 0.0f;
+  d.phase = (kind == HN_FEAT_COS || kind == HN_FEAT_SINP) ? 0.25f : 0.0f;
+  d.idmask = (kind == HN_FEAT_ID || kind == HN_FEAT_ID_DIRECT) ? 0xffffffffu : 0u;
+  return d;
+}
 HN_DEV float hn_bfi(unsigned m, float a, float b) {     // m ? a : b, bit-wise (one v_bfi_b32)
   return __uint_as_float((m & __float_as_uint(a)) | (~m & __float_as_uint(b)));
 }
-// values of 4 consecutive table entries for the lane's point: 4 x 16-byte table reads issued together, then the 4
-// source values (addresses from the entries) together, then 5 VALU per feature.  `srcv_r` = the wave's staged
-// components + 4 * point-in-block.
+// values of 4 consecutive forward-table entries for the lane's point: 4 x 16-byte table reads issued together, then
+// the 8 staged values (A, B; addresses from the entries) together, then 6 VALU per feature:
+//   value = idmask ? A : sin(fract(f * A) + (f * B + phase))        [revolutions; the sum stays below 1.3, inside the
+// hardware sine's domain, so no second fract].  `srcv_r` = the wave's staged components + 4 * point-in-block.
 HN_DEV void hn_features4(const HnDFeat* tp, const char* srcv_r, float* out) {
   u32x4 t[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) t[j] = reinterpret_cast<const u32x4*>(tp)[j];
   __builtin_amdgcn_sched_barrier(0);
-  float x[4];
+  float va[4], vb[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const float*>(srcv_r + t[j][0]);
+  for (int j = 0; j < 4; ++j) {
+    va[j] = *reinterpret_cast<const float*>(srcv_r + (t[j][0] & 0xffffu));
+    vb[j] = *reinterpret_cast<const float*>(srcv_r + (t[j][0] >> 16));
+  }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float sv = hn_sin_rev(__builtin_fmaf(__uint_as_float(t[j][1]), x[j], __uint_as_float(t[j][2])));
-    out[j] = hn_bfi(t[j][3], x[j], sv);
+    const float f = __uint_as_float(t[j][1]);
+    const float big = __builtin_amdgcn_fractf(__fmul_rn(f, va[j]));                      // exact for f = 2^k
+    const float sv = __builtin_amdgcn_sinf(__fadd_rn(big, __builtin_fmaf(f, vb[j], __uint_as_float(t[j][2]))));
+    out[j] = hn_bfi(t[j][3], va[j], sv);
   }
 }
 HN_DEV void hn_feature_grads4(const HnDFeat* tp, const char* srcv_r, float* out) {
@@ -471,13 +518,16 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * HN_CHUNK_UNITS * 1024);
   HnFeat* feat_lds = reinterpret_cast<HnFeat*>(bias_lds + ((a.n_bias + 3) & ~3));
   HnDFeat* dfeat_lds = reinterpret_cast<HnDFeat*>(feat_lds + ((a.n_feat + 1) & ~1));      // bf16 kernels only
+  // per wave: value plane (n_comps x 32 floats) and, bf16 only, the (hi, lo) planes of x / 2pi for the first n_trig
+  const int n_trig = BF16 ? a.n_trig_comps : 0;
   float* srcv = reinterpret_cast<float*>(BF16 ? reinterpret_cast<char*>(dfeat_lds + a.n_feat)
-                                              : reinterpret_cast<char*>(dfeat_lds)) + wave * (a.n_comps * 32);
+                                              : reinterpret_cast<char*>(dfeat_lds)) + wave * ((a.n_comps + 2 * n_trig) * 32);
+  float* rev = BF16 ? srcv + a.n_comps * 32 : nullptr;
   for (int i = threadIdx.x; i < a.n_bias; i += blockDim.x) bias_lds[i] = a.bias[i];
   for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) {
     const HnFeat e = a.feat[i];
     feat_lds[i] = e;
-    if constexpr (BF16) dfeat_lds[i] = hn_derive_feat(e);
+    if constexpr (BF16) dfeat_lds[i] = hn_derive_feat_fwd(e, a.n_comps, n_trig);
   }
   __syncthreads();
 
@@ -488,7 +538,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
     const int p = valid ? p0 : a.n_points - 1;
     const int ray = p / a.samples_per_ray;
     const bool wave_valid = blk * 32 < a.n_points;  // wave-uniform: the block holds at least one point
-    hn_stage_sources(srcv, a, p, ray, lane);
+    hn_stage_sources(srcv, a, p, ray, lane, rev, n_trig);
     ws.start();
 
     HnOpWords w_next = hn_load_op(a.ops, 0, a.n_ops);
@@ -590,7 +640,14 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
                     const HnSrc sr = a.src[out_w[5]];
                     y = __fadd_rn(sr.ptr[(size_t)(sr.per_ray ? ray : p) * sr.ld + out_w[6] + i], y);
                   }
-                  srcv[(out_w[7] - 1 + i) * 32 + r] = y;
+                  const int ci = out_w[7] - 1 + i;
+                  srcv[ci * 32 + r] = y;
+                  if (BF16 && ci < n_trig) {
+                    float hi, lo;
+                    hn_rev_split(y, hi, lo);
+                    rev[ci * 32 + r] = hi;
+                    rev[(n_trig + ci) * 32 + r] = lo;
+                  }
                 }
               }
             }
@@ -1396,10 +1453,12 @@ extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
   if (rc) return rc;
   hn_allow_big_lds();
   constexpr int WB = ModeT<true>::WAVES;
+  if (a->n_trig_comps < 0 || a->n_trig_comps > a->n_comps) return -5;
+  const size_t planes = a->mode == HN_MODE_BF16 ? (size_t)a->n_comps + 2 * (size_t)a->n_trig_comps : (size_t)a->n_comps;
   const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + (size_t)((a->n_bias + 3) & ~3) * 4 +
                      (size_t)((a->n_feat + 1) & ~1) * 8 + (a->mode == HN_MODE_BF16 ? (size_t)a->n_feat * 16 : 0) +
-                     (size_t)8 * a->n_comps * 32 * 4;
-  if (lds > 150 * 1024) return -6;
+                     (size_t)8 * planes * 32 * 4;
+  if (lds > 158 * 1024) return -6;
   if (a->mode == HN_MODE_BF16) {
     if (a->max_groups <= 2)
       hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 2>), dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,

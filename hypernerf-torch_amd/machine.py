@@ -328,6 +328,14 @@ class Program:
         return end
 
     @property
+    def n_trig_comps(self) -> int:
+        """Staged components 0 .. n-1 cover every component a trigonometric feature reads (they are assigned first,
+        `_link`): the bf16 forward stages x / 2pi as hi + lo for exactly those."""
+        idx = [self.comp_map[(f.src, f.comp)] for f in self.feat_table
+               if f.kind not in (L.HN_FEAT_ZERO, L.HN_FEAT_ID) and (f.src, f.comp) in self.comp_map]
+        return max(idx) + 1 if idx else 0
+
+    @property
     def n_dsrc(self):
         """Rows of the source-gradient accumulator in use (slot numbers may have gaps: reserved head rows)."""
         return max(self.dsrc_map.values()) + 1 if self.dsrc_map else 0
@@ -862,6 +870,7 @@ class MlpRunner:
         a.max_groups = max([ly.aux.groups for ly in self.prog.layers if ly.aux is not None], default=0)
         a.prof = L.PROF_BUFFER.data_ptr() if L.PROF_BUFFER is not None else 0
         a.comps, a.n_comps = d.comps.data_ptr(), len(self.prog.comp_map)
+        a.n_trig_comps = min(len(self.prog.comp_map), max(1, self.prog.n_trig_comps))
         a.stash = stash.data_ptr() if stash is not None else 0
         a.masks = masks.data_ptr() if masks is not None else 0
         a.dsrc = dsrc.data_ptr() if dsrc is not None else 0

@@ -164,6 +164,9 @@ typedef struct {
   const int64_t* embed_idx;
   int32_t embed_rows, embed_dim;
   int8_t embed_col[HN_DSRC_COMPS]; /* slot -> column of the table row, -1 = not an embedding component */
+  int32_t n_trig_comps;   /* forward, bf16: staged components 0 .. n_trig_comps-1 also get x / 2pi staged as hi + lo
+                             (every component a trigonometric feature reads must be among them; >= 1 if n_comps > 0) */
+  int32_t pad2;
 } HnMlpArgs;
 
 /* weight packing: one descriptor per 1-KiB unit of a stream */

@@ -308,8 +308,10 @@ def test_bf16_mode_vs_bf16_operand_oracle(case):
     Linear rounds its matmul operands to bf16, forward and backward, and accumulates in fp32; everything else fp32).
     What is left is summation order, the fast sin/cos of bf16 mode and the ReLUs / pdf bins that sit on a rounding
     boundary, so the bounds are ~10x tighter than against the fp32 oracle: forward 1e-3 of the tensor's scale
-    (measured <= 2.6e-4), the whole gradient to a relative L2 of 8e-2 (measured 4.8e-2 / 4.2e-2; against the fp32
-    oracle the same quantity is ~0.18), every gradient tensor that carries >= 1 % of it to 0.12."""
+    (measured <= 2.6e-4), the whole gradient to a relative L2 of 2.5e-2 (measured 1.13e-2 / 9.9e-3 since the encoders
+    take their sines on an exactly reduced argument — x / 2pi staged as hi + lo, hn_features4; 4.8e-2 / 4.2e-2 with the
+    one-FMA argument of rounds 1-2, 1.6e-2 / 1.8e-2 with libm sines; against the fp32 oracle the same quantity is
+    ~0.18), every gradient tensor that carries >= 1 % of it to 0.06."""
     HN.set_precision("bf16")
     try:
         kw = CASES[case]
@@ -347,10 +349,16 @@ def test_bf16_mode_vs_bf16_operand_oracle(case):
         ra = torch.cat([p[k].grad.double().reshape(-1) for k in ks])
         tot = float(ra.norm())
         rel = float((ga - ra).norm()) / tot
-        assert rel <= 8e-2, f"{case}: whole-gradient rel L2 {rel:.3e} against the bf16-operand oracle"
+        from gpu_common import _record
+        _record(f"bf16-contract {case}: whole gradient", "rel L2", rel, 2.5e-2)
+        per = {k: float((named[k].grad.detach().cpu().double() - p[k].grad.double()).norm() / (p[k].grad.double().norm() + 1e-30))
+               for k in ks if float(p[k].grad.norm()) >= 1e-2 * tot}
+        print(f"bf16-contract {case}: whole-gradient rel L2 {rel:.3e}; per tensor: " +
+              ", ".join(f"{k.replace('.weight', '.w').replace('.bias', '.b')}={v:.3f}" for k, v in sorted(per.items())))
+        assert rel <= 2.5e-2, f"{case}: whole-gradient rel L2 {rel:.3e} against the bf16-operand oracle"
         for k in ks:
             if float(p[k].grad.norm()) >= 1e-2 * tot:
-                assert_grad_close(named[k].grad, p[k].grad, 0.12, f"bf16-contract {case} d {k}", frobenius=True)
+                assert_grad_close(named[k].grad, p[k].grad, 0.06, f"bf16-contract {case} d {k}", frobenius=True)
     finally:
         HN.set_precision("bf16")
 

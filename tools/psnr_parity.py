@@ -94,11 +94,13 @@ def run(precision, seed=0):
 if __name__ == "__main__":
     res = {}
     seeds = [int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0"])]
-    for prec in ("fp32", "bf16"):
+    for prec in os.environ.get("HN_PSNR_MODES", "fp32,bf16").split(","):     # e.g. HN_PSNR_MODES=bf16: one mode only
         runs = [run(prec, sd) for sd in seeds]          # same init; the seed changes ray batches and draws
         res[prec] = {"test_psnr_db": [round(r[0], 3) for r in runs],
                      "mean_psnr_db": round(sum(r[0] for r in runs) / len(runs), 3),
                      "final_train_loss": [r[1] for r in runs], "train_seconds": round(sum(r[2] for r in runs), 2)}
-    res["psnr_gap_db"] = round(res["bf16"]["mean_psnr_db"] - res["fp32"]["mean_psnr_db"], 3)
+    if "bf16" in res and "fp32" in res:
+        res["psnr_gap_db"] = round(res["bf16"]["mean_psnr_db"] - res["fp32"]["mean_psnr_db"], 3)
+    res["seeds"] = seeds
     res["config"] = f"{steps} steps x {B} rays x (64+64) samples, Adam lr 1e-3 -> 1e-4, synthetic moving-sphere scene"
     print(json.dumps(res))
