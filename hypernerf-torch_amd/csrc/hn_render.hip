@@ -889,24 +889,43 @@ HN_DEV HnV3 hn_scale(float s, HnV3 a) { return hn_v3(s * a.x, s * a.y, s * a.z);
 HN_DEV HnV3 hn_load3(const float* p, size_t i) { return hn_v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 HN_DEV void hn_store3(float* p, size_t i, HnV3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
 
-__global__ void hn_se3_forward_kernel(const float* w, const float* v, const float* pts, int n, float* out) {
+HN_DEV HnV3 hn_load3s(const float* p, size_t i, int ld) { return hn_v3(p[i * ld], p[i * ld + 1], p[i * ld + 2]); }
+HN_DEV void hn_store3s(float* p, size_t i, int ld, HnV3 v) { p[i * ld] = v.x; p[i * ld + 1] = v.y; p[i * ld + 2] = v.z; }
+
+// every operand with its own row stride (w and v are the two halves of the field's (P, 6) head output: no slicing
+// copies); `rows_out` (optional, (P, 3 + H) with stride rows_ld) = [y | table[idx[ray]]]: the `warped_points` tensor of
+// an axis-aligned-plane level (models.py:533-534, 578) written by the same launch — no index_select, no cat
+__global__ void hn_se3_forward_kernel(const float* w, int w_ld, const float* v, int v_ld, const float* pts, int p_ld,
+                                      int n, float* out, float* rows_out, int rows_ld, const float* table,
+                                      const int64_t* idx, int H, int n_rows, int spr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const HnV3 wv = hn_load3(w, i), vv = hn_load3(v, i), p = hn_load3(pts, i);
+  const HnV3 wv = hn_load3s(w, i, w_ld), vv = hn_load3s(v, i, v_ld), p = hn_load3s(pts, i, p_ld);
   const float theta = sqrtf(hn_dot(wv, wv));
   const HnV3 a = hn_scale(1.0f / theta, wv), b = hn_scale(1.0f / theta, vv);
   const float s = sinf(theta), c = 1.0f - cosf(theta), d = theta - s;
   const HnV3 q = hn_cross(a, p), r = hn_cross(a, q), m = hn_cross(a, b), nn = hn_cross(a, m);
   HnV3 y = hn_add(p, hn_add(hn_scale(s, q), hn_scale(c, r)));
   y = hn_add(y, hn_add(hn_scale(theta, b), hn_add(hn_scale(c, m), hn_scale(d, nn))));
-  hn_store3(out, i, y);
+  if (out != nullptr) hn_store3(out, i, y);
+  if (rows_out != nullptr) {
+    float* dst = rows_out + (size_t)i * rows_ld;
+    dst[0] = y.x; dst[1] = y.y; dst[2] = y.z;
+    if (table != nullptr && H > 0) {
+      const long long row = idx[i / spr];
+      const bool ok = row >= 0 && row < n_rows;      // as the machine's own gather: an index outside the table is NaN
+      for (int k = 0; k < H; ++k) dst[3 + k] = ok ? table[(size_t)row * H + k] : __builtin_nanf("");
+    }
+  }
 }
 
-__global__ void hn_se3_backward_kernel(const float* w, const float* v, const float* pts, const float* gout, int n,
-                                       float* dw, float* dv, float* dp) {
+__global__ void hn_se3_backward_kernel(const float* w, int w_ld, const float* v, int v_ld, const float* pts, int p_ld,
+                                       const float* gout, int g_ld, int n, float* dw, int dw_ld, float* dv, int dv_ld,
+                                       float* dp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const HnV3 wv = hn_load3(w, i), vv = hn_load3(v, i), p = hn_load3(pts, i), g = hn_load3(gout, i);
+  const HnV3 wv = hn_load3s(w, i, w_ld), vv = hn_load3s(v, i, v_ld), p = hn_load3s(pts, i, p_ld);
+  const HnV3 g = hn_load3s(gout, i, g_ld);
   const float theta = sqrtf(hn_dot(wv, wv)), inv = 1.0f / theta;
   const HnV3 a = hn_scale(inv, wv), b = hn_scale(inv, vv);
   const float sn = sinf(theta), cs = cosf(theta), c = 1.0f - cs, d = theta - sn;
@@ -926,8 +945,8 @@ __global__ void hn_se3_backward_kernel(const float* w, const float* v, const flo
   g_theta -= inv * (hn_dot(g_a, a) + hn_dot(g_b, b));
   const HnV3 g_w = hn_add(hn_scale(inv, g_a), hn_scale(g_theta, a));   // d theta / d w = a
   const HnV3 g_v = hn_scale(inv, g_b);
-  if (dw != nullptr) hn_store3(dw, i, g_w);
-  if (dv != nullptr) hn_store3(dv, i, g_v);
+  if (dw != nullptr) hn_store3s(dw, i, dw_ld, g_w);
+  if (dv != nullptr) hn_store3s(dv, i, dv_ld, g_v);
   if (dp != nullptr) hn_store3(dp, i, g_p);
 }
 
@@ -935,8 +954,8 @@ extern "C" int hn_se3_apply_forward(const float* w, const float* v, const float*
                                     hnStream_t stream) {
   if (n_points <= 0) return -2;
   if (w == nullptr || v == nullptr || points == nullptr || out == nullptr) return -3;
-  hipLaunchKernelGGL(hn_se3_forward_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, v,
-                     points, n_points, out);
+  hipLaunchKernelGGL(hn_se3_forward_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, 3, v, 3,
+                     points, 3, n_points, out, (float*)nullptr, 0, (const float*)nullptr, (const int64_t*)nullptr, 0, 0, 1);
   HN_CHECK_LAUNCH();
   return 0;
 }
@@ -945,8 +964,36 @@ extern "C" int hn_se3_apply_backward(const float* w, const float* v, const float
                                      int n_points, float* d_w, float* d_v, float* d_points, hnStream_t stream) {
   if (n_points <= 0) return -2;
   if (w == nullptr || v == nullptr || points == nullptr || g_out == nullptr) return -3;
-  hipLaunchKernelGGL(hn_se3_backward_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, v,
-                     points, g_out, n_points, d_w, d_v, d_points);
+  hipLaunchKernelGGL(hn_se3_backward_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, 3, v, 3,
+                     points, 3, g_out, 3, n_points, d_w, 3, d_v, 3, d_points);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hn_se3_warp_forward(const float* w, int w_ld, const float* v, int v_ld, const float* points, int p_ld,
+                                   int n_points, float* out, float* rows_out, int rows_ld, const float* table,
+                                   const int64_t* idx, int H, int n_rows, int samples_per_ray, hnStream_t stream) {
+  if (n_points <= 0 || w_ld < 3 || v_ld < 3 || p_ld < 3) return -2;
+  if (w == nullptr || v == nullptr || points == nullptr || (out == nullptr && rows_out == nullptr)) return -3;
+  if (rows_out != nullptr) {
+    if (H < 0 || rows_ld < 3 + H || samples_per_ray <= 0) return -2;
+    if (H > 0 && (table == nullptr || idx == nullptr || n_rows <= 0)) return -3;
+  }
+  hipLaunchKernelGGL(hn_se3_forward_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, w_ld, v,
+                     v_ld, points, p_ld, n_points, out, rows_out, rows_ld, table, idx, H, n_rows,
+                     samples_per_ray > 0 ? samples_per_ray : 1);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hn_se3_warp_backward(const float* w, int w_ld, const float* v, int v_ld, const float* points, int p_ld,
+                                    const float* g_out, int g_ld, int n_points, float* d_w, int dw_ld, float* d_v,
+                                    int dv_ld, float* d_points, hnStream_t stream) {
+  if (n_points <= 0 || w_ld < 3 || v_ld < 3 || p_ld < 3 || g_ld < 3) return -2;
+  if (w == nullptr || v == nullptr || points == nullptr || g_out == nullptr) return -3;
+  if ((d_w != nullptr && dw_ld < 3) || (d_v != nullptr && dv_ld < 3)) return -2;
+  hipLaunchKernelGGL(hn_se3_backward_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, w_ld, v,
+                     v_ld, points, p_ld, g_out, g_ld, n_points, d_w, dw_ld, d_v, dv_ld, d_points);
   HN_CHECK_LAUNCH();
   return 0;
 }

@@ -209,10 +209,14 @@ class _ProgramFn(torch.autograd.Function):
                     mask = torch.tensor([1.0 if c in cols else 0.0 for c in range(width)], device=dsrc.device)
                     idx = (idx, None if all(c in cols for c in range(width)) else mask)
                     call.cache[key] = idx
-                g = dsrc.index_select(1, idx[0])          # one gather instead of a copy kernel per column
-                if idx[1] is not None:
-                    g = g * idx[1]
-            src_grads.append(g.view(shp))
+                slots = [cols.get(c, -1) for c in range(width)]
+                if all(sl == slots[0] + k for k, sl in enumerate(slots)) and slots[0] >= 0:
+                    g = dsrc.narrow(1, slots[0], width)   # consecutive rows of the accumulator tile: a view, no launch
+                else:
+                    g = dsrc.index_select(1, idx[0])      # one gather instead of a copy kernel per column
+                    if idx[1] is not None:
+                        g = g * idx[1]
+            src_grads.append(g.view(shp) if g.is_contiguous() else g)
         if flat is None:
             return (None, None, None, None, None, None, *src_grads, *([None] * len(prog.params)))
         pgrads = call.runner.split_grads(flat)
@@ -722,6 +726,73 @@ class _Se3Fn(torch.autograd.Function):
 def se3_apply(w: torch.Tensor, v: torch.Tensor, points: torch.Tensor) -> torch.Tensor:
     """y = exp([S] theta) . p with theta = |w|, S = (w, v) / theta, per point (reference: warping.py:226-238)."""
     return _Se3Fn.apply(w, v, points)
+
+
+class _Se3WarpFn(torch.autograd.Function):
+    """SE3Field's tail in one launch each way: wv (P, 6) = [w | v] straight from the field program (read with row
+    stride 6, no slicing copies), points (P, 3) -> xyz (P, 3) and, optionally, `warped` (P, 3 + H) = [xyz | table row
+    of the ray] (axis-aligned-plane levels; not differentiable: the template reads the hyper coordinates from the
+    gathered table itself).  The gradient arrives as columns of the template's source-gradient tensor (any row
+    stride) and leaves as one (P, 6) tensor."""
+
+    @staticmethod
+    def forward(ctx, wv, points, table, idx, samples_per_ray):
+        L.require_gpu(wv, points)
+        L.load()
+        wv_c = wv.detach()
+        if wv_c.dim() != 2 or wv_c.shape[1] != 6 or wv_c.stride(1) != 1:
+            wv_c = wv_c.reshape(-1, 6).contiguous()
+        p_c = points.detach().reshape(-1, 3)
+        if p_c.stride(1) != 1:
+            p_c = p_c.contiguous()
+        n = p_c.shape[0]
+        if wv_c.shape[0] != n:
+            raise L.HnError("se3_warp: wv and points must have the same number of rows")
+        xyz = torch.empty(n, 3, dtype=torch.float32, device=p_c.device)
+        warped, tab, gidx, h = None, None, None, 0
+        if table is not None:
+            tab = table.detach().contiguous()
+            gidx = idx.reshape(-1).to(torch.int64).contiguous()
+            h = tab.shape[1]
+            if gidx.numel() * int(samples_per_ray) != n:
+                raise L.HnError(f"se3_warp: {gidx.numel()} ray indices x {samples_per_ray} samples != {n} points")
+            warped = torch.empty(n, 3 + h, dtype=torch.float32, device=p_c.device)
+        L.launch("hn_se3_warp_forward", C.c_void_p(wv_c.data_ptr()), C.c_int(wv_c.stride(0)),
+                 C.c_void_p(wv_c.data_ptr() + 12), C.c_int(wv_c.stride(0)), L.ptr(p_c), C.c_int(p_c.stride(0)), C.c_int(n),
+                 L.ptr(xyz), L.ptr(warped), C.c_int(3 + h), L.ptr(tab), L.ptr(gidx), C.c_int(h),
+                 C.c_int(tab.shape[0] if tab is not None else 0), C.c_int(int(samples_per_ray)), L.stream_handle())
+        ctx.saved = (wv_c, p_c)
+        ctx.pshape = points.shape
+        ctx.set_materialize_grads(False)
+        if warped is None:
+            return xyz
+        ctx.mark_non_differentiable(warped)
+        return xyz, warped
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        L.load()
+        wv_c, p_c = ctx.saved
+        if g is None:
+            return None, None, None, None, None
+        if g.dim() != 2 or g.stride(1) != 1:
+            g = g.reshape(-1, 3).contiguous()
+        n = p_c.shape[0]
+        need_p = ctx.needs_input_grad[1]
+        d_wv = torch.empty(n, 6, dtype=torch.float32, device=p_c.device)
+        d_p = torch.empty(n, 3, dtype=torch.float32, device=p_c.device) if need_p else None
+        L.launch("hn_se3_warp_backward", C.c_void_p(wv_c.data_ptr()), C.c_int(wv_c.stride(0)),
+                 C.c_void_p(wv_c.data_ptr() + 12), C.c_int(wv_c.stride(0)), L.ptr(p_c), C.c_int(p_c.stride(0)),
+                 L.ptr(g), C.c_int(g.stride(0)), C.c_int(n), C.c_void_p(d_wv.data_ptr()), C.c_int(6),
+                 C.c_void_p(d_wv.data_ptr() + 12), C.c_int(6), L.ptr(d_p), L.stream_handle())
+        return d_wv, (d_p.view(ctx.pshape) if d_p is not None else None), None, None, None
+
+
+def se3_warp(wv: torch.Tensor, points: torch.Tensor, table: Optional[torch.Tensor] = None,
+             idx: Optional[torch.Tensor] = None, samples_per_ray: int = 1):
+    """xyz = exp([S] theta) . p from the field's (P, 6) head output [w | v]; with `table` / `idx` also the (P, 3 + H)
+    `warped_points` rows [xyz | table[idx[ray]]] (reference: warping.py:226-238, models.py:533-534, 578-581)."""
+    return _Se3WarpFn.apply(wv, points, table, idx, samples_per_ray)
 
 
 # --------------------------------------------------------------------------------------------

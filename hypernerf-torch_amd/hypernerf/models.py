@@ -486,18 +486,24 @@ class NerfModel(nn.Module):
             idx = metadata[key]
             if idx.shape[-1] == 1 and idx.dim() > 1:
                 idx = idx.squeeze(-1)
-            if use_warp:
+            from_table = use_warp and self.hyper_slice_method == 'axis_aligned_plane'
+            warped_rows = None
+            if use_warp and from_table and isinstance(self.warp_field, warping.SE3Field):
+                # config 5: the exp-map launch writes `warped_points` = [xyz | GLO row] itself (no index_select + cat)
+                xyz, warped_rows = self.warp_field.warp_with_rows(points, emb_mod.embed.weight, idx)
+            elif use_warp:
                 needs_rows = isinstance(self.warp_field, warping.TranslationField)
                 xyz = self.warp_field.warp(points, self.warp_embed(metadata[self.warp_embed_key]) if needs_rows else None,
                                            extra_params)
             else:
                 xyz = points
-            from_table = use_warp and self.hyper_slice_method == 'axis_aligned_plane'
             ge = torch.is_grad_enabled() and xyz.requires_grad
             call = self._template_gather_call(level, from_table, ge)
             rgb, alpha = F.run_program(call, [xyz.reshape(b * s, 3), viewdirs if self.use_viewdirs else None,
                                               emb_mod.embed.weight], s, self.precision, gather_idx=idx)
-            if from_table:
+            if warped_rows is not None:
+                warped = warped_rows
+            elif from_table:
                 with torch.no_grad():
                     flat = idx.reshape(-1)
                     safe = flat.clamp(0, emb_mod.embed.weight.shape[0] - 1)

@@ -165,7 +165,18 @@ class SE3Field(nn.Module):
         flat = points.reshape(-1, self.in_ch_pts)
         pg = bool(points.requires_grad and ge)
         (wv,) = F.run_program(self._field_call(pg), [flat], 1)
-        return F.se3_apply(wv[:, 0:3], wv[:, 3:6], flat if pg else flat.detach()).view(*lead, 3)
+        return F.se3_warp(wv, flat if pg else flat.detach()).view(*lead, 3)
+
+    def warp_with_rows(self, points: torch.Tensor, table: torch.Tensor, idx: torch.Tensor):
+        """points (B, S, 3) -> (xyz (B, S, 3), warped (B, S, 3 + H)) with warped = [xyz | table[idx[ray]]]: the
+        `warped_points` of an axis-aligned-plane level (models.py:533-534, 578-581) written by the exp-map launch
+        itself.  Gradients flow through xyz only."""
+        b, s = points.shape[0], points.shape[1]
+        flat = points.reshape(-1, self.in_ch_pts)
+        pg = bool(points.requires_grad and torch.is_grad_enabled())
+        (wv,) = F.run_program(self._field_call(pg), [flat], 1)
+        xyz, warped = F.se3_warp(wv, flat if pg else flat.detach(), table, idx, s)
+        return xyz.view(b, s, 3), warped.view(b, s, -1)
 
     def forward(self, points, metadata, extra_params, return_jacobian: bool = False):
         out = {'warped_points': self.warp(points, metadata, extra_params)}

@@ -387,6 +387,19 @@ int hn_se3_apply_forward(const float* w, const float* v, const float* points, in
 int hn_se3_apply_backward(const float* w, const float* v, const float* points, const float* g_out, int n_points,
                           float* d_w, float* d_v, float* d_points, hnStream_t stream);
 
+/* The same warp with a row stride per operand (w and v = the two halves of the field's (P, 6) head output, g_out =
+ * columns of the template's source-gradient tensor: no slicing copies on either side), and — forward — an optional
+ * second output rows_out (P, 3 + H), row stride rows_ld = [y | table[idx[p / samples_per_ray]]]: the `warped_points`
+ * tensor of an axis-aligned-plane level (hypernerf/models.py:533-534, 578-581) without index_select + cat; an index
+ * outside [0, n_rows) writes NaN, as the machine's own gather does.  out (P, 3) contiguous may be NULL if rows_out is
+ * given; d_w / d_v / d_points may each be NULL. */
+int hn_se3_warp_forward(const float* w, int w_ld, const float* v, int v_ld, const float* points, int p_ld,
+                        int n_points, float* out, float* rows_out, int rows_ld, const float* table,
+                        const int64_t* idx, int H, int n_rows, int samples_per_ray, hnStream_t stream);
+int hn_se3_warp_backward(const float* w, int w_ld, const float* v, int v_ld, const float* points, int p_ld,
+                         const float* g_out, int g_ld, int n_points, float* d_w, int dw_ld, float* d_v, int dv_ld,
+                         float* d_points, hnStream_t stream);
+
 /* Debug/probe: runs one MFMA of each kind on identifiable data (layout self-test on real hardware). */
 int hn_probe_mfma(float* out_bf16_acc, float* out_f32_acc, float* out_glds, hnStream_t stream);
 

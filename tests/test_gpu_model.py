@@ -1134,7 +1134,7 @@ def test_se3_field_warp_vs_oracle():
             f.warp(pts.to(DEV), None, {"warp_alpha": None})
         names = set(k.split("[")[0] for k in L.collect_kernel_times())
         L.KERNEL_TIMES = None
-        assert names <= {"hn_mlp_forward", "hn_se3_apply_forward", "hn_pack_units"}, names
+        assert names <= {"hn_mlp_forward", "hn_se3_warp_forward", "hn_pack_units"}, names
         assert set(f(pts.to(DEV), None, {"warp_alpha": None}).keys()) == {"warped_points"}
     finally:
         HN.set_precision("bf16")
