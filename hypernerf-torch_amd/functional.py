@@ -499,7 +499,12 @@ def seed_draws(seed: Optional[int] = None, device=None):
     set).  The state {seed, offset, ticket} lives in device memory and is advanced by the kernel itself."""
     L.load()
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    seed = torch.initial_seed() if seed is None else int(seed)
+    if seed is None:
+        # what torch.manual_seed set; data-parallel ranks seeded alike must still draw different numbers
+        seed = torch.initial_seed()
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            seed += 0x9E3779B97F4A7C15 * torch.distributed.get_rank()
+    seed = int(seed)
     st = torch.tensor([seed & 0x7fffffffffffffff, 0, 0], dtype=torch.int64, device=device)
     _DRAW_STATE[str(device)] = st
     return st
