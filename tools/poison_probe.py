@@ -22,7 +22,25 @@ CASES = {"bendy_cond": dict(hyper_slice_method="bendy_sheet", use_nerf_embed=Tru
                           use_alpha_cond=True)}
 
 
+_LDS = [None]
+
+
+def poison_lds(pattern):
+    """Fill every CU's LDS with `pattern` (tools/lds_poison.hip, built by __graft_entry__.build()); a no-op if the
+    helper library is not there."""
+    import ctypes
+    if _LDS[0] is None:
+        path = os.path.join(ROOT, "tools", "liblds_poison.so")
+        _LDS[0] = ctypes.CDLL(path) if os.path.exists(path) else False
+    if _LDS[0]:
+        rc = _LDS[0].lds_poison(ctypes.c_uint32(pattern), 2, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+    return bool(_LDS[0])
+
+
 def poison(pattern):
+    poison_lds(pattern)
     bufs = []
     for mb in (2048, 1024, 512, 256, 128, 64, 64, 32, 32, 16, 16, 8, 8, 4, 4, 2, 2, 1, 1):
         t = torch.empty(mb << 18, dtype=torch.int32, device=DEV)
