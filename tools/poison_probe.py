@@ -31,6 +31,13 @@ def poison_lds(pattern):
     import ctypes
     if _LDS[0] is None:
         path = os.path.join(ROOT, "tools", "liblds_poison.so")
+        if not os.path.exists(path):        # not shipped with this snapshot: hipcc is on every GPU box
+            import subprocess
+            try:
+                subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-o", path,
+                                os.path.join(ROOT, "tools", "lds_poison.hip")], check=True, capture_output=True, timeout=300)
+            except (OSError, subprocess.SubprocessError):
+                pass
         _LDS[0] = ctypes.CDLL(path) if os.path.exists(path) else False
     if _LDS[0]:
         rc = _LDS[0].lds_poison(ctypes.c_uint32(pattern), 2, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
