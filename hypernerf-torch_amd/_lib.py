@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libhn_hip.so")
 SOURCES = ["hn_mlp.hip", "hn_render.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hn_kernels.h")
-BUILD_MACROS = ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX", "HN_PIPE256", "HN_EXP")     # build-time tuning knobs (A/B experiments)
+BUILD_MACROS = ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX")     # build-time tuning knobs (A/B experiments)
 
 HN_MODE_F32, HN_MODE_BF16 = 0, 1
 HN_MAX_SRC, HN_MAX_DST, HN_MAX_SLOTS = 8, 4, 128

@@ -77,21 +77,10 @@ HN_DEV void hn_mma_block32(f32x16& acc, const char* lds, const float* in, int la
   }
 }
 
-// Z = X^T through the matrix core: fr = the fragments of one 32-feature tile in the points-on-lanes
-// layout (they are, unchanged, the A operand of X^T); B = a permuted identity.  Result: lane (c,h)
-// holds feature c of the tile at the 16 points rho(q,h) — the operand layout of the dW product.
-HN_DEV f32x16 hn_transpose_tile(const bf16x8* fr, int lane) {
-  const int c = lane & 31, h = lane >> 5;
-  f32x16 z = {0};
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    bf16x8 id;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) id[j] = (c == 16 * u + hn_pi16(h, j)) ? (__bf16)1.0f : (__bf16)0.0f;
-    z = hn_mfma_bf16(fr[u], id, z);
-  }
-  return z;
-}
+// fp32 mode only (the bf16 stash keeps the operand layout and is transposed by the weight-gradient kernel's LDS read):
+// Z = X^T through the matrix core: fr = the 16 steps of one 32-feature tile in the points-on-lanes layout (they are,
+// unchanged, the A operand of X^T); B = a permuted identity.  Result: lane (c,h) holds feature c of the tile at the 16
+// points rho(q,h) — the operand layout of the dW product.
 HN_DEV f32x16 hn_transpose_tile(const float* fr, int lane) {
   const int c = lane & 31, h = lane >> 5;
   f32x16 z = {0};
@@ -99,17 +88,7 @@ HN_DEV f32x16 hn_transpose_tile(const float* fr, int lane) {
   for (int q = 0; q < 16; ++q) z = hn_mfma_f32(fr[q], (c == hn_rho(q, h)) ? 1.0f : 0.0f, z);
   return z;
 }
-
-// store a transposed tile (TILE_UNITS KiB at dst) : bf16 [v][lane][8] / fp32 [g][lane][4]
-HN_DEV void hn_store_tile(const f32x16& z, char* dst, int lane, bf16x8*) {
-#pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (__bf16)z[8 * v + j];
-    __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(&o), reinterpret_cast<u32x4*>(dst + v * 1024 + lane * 16));
-  }
-}
+// store a transposed fp32 tile (4 KiB at dst): [g][lane][4]
 HN_DEV void hn_store_tile(const f32x16& z, char* dst, int lane, float*) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {

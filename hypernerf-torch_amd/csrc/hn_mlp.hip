@@ -303,8 +303,12 @@ HN_DEV void hn_init_acc(f32x16& acc, const float* bias, int t, int h) {
 
 // acc += W[tile][32*K32 features] . in   (K32 consecutive blocks of the stream)
 // bf16: the A fragments (one ds_read_b128 per MFMA) are read HN_PF units ahead of the MFMA that consumes them, so
-// the LDS latency hides behind the two or three MFMAs in between instead of being paid before every pair.
-constexpr int HN_PF = 4;
+// the LDS latency hides behind the MFMAs in between instead of being paid before every pair.  3, not 4: with four
+// fragment buffers the forward kernel is 4 VGPRs short in its 16-MFMA tile product, spills two register pairs around it
+// and reloads them at its end — and the next tile's first LDS read into those registers then waits (vmcnt(0), WAW) for
+// the reload AND every stash store in front of it.  Same speed either way (measured on one box), no scratch traffic
+// in any MFMA block this way (tools/scratch_report.py).
+constexpr int HN_PF = 3;
 template <bool BF16, int K32>
 HN_DEV void hn_gemm_blocks(f32x16& acc, const typename ModeT<BF16>::Frag* in, WStream<ModeT<BF16>::WAVES>& ws) {
   using M = ModeT<BF16>;
@@ -352,7 +356,8 @@ HN_DEV char* hn_slot_base(const HnMlpArgs& a, int off_kib, int nt, int blk) {
 }
 // mask words of a block: `off256` = the slot's byte offset / 256 (resolved by the host), nt words per lane and block
 HN_DEV uint32_t* hn_mask_base(const HnMlpArgs& a, int off256, int nt, int blk, int lane) {
-  return a.masks + (size_t)(unsigned)off256 * 64 + (size_t)blk * nt * 64 + lane;
+  (void)lane;      // added at the access: the base stays wave-uniform (scalar registers, no VGPR pair per slot)
+  return a.masks + (size_t)(unsigned)off256 * 64 + (size_t)blk * nt * 64;
 }
 // Store one 32-feature tile of a block as tile t of a stash slot.
 // bf16: the operand fragments AS THEY ARE (points on lanes) — no transposing MFMAs, no second conversion: unit u of the
@@ -433,7 +438,7 @@ HN_DEV void hn_epilogue_share(int k, int tp, f32x16& a, bf16x8* frag, unsigned& 
   } else if (TRAIN && k == 8) {
     hn_stash<true>(frag, out_base, tp, lane);
     if ((tp & 1) || tp == NT - 1) {
-      mask_base[(tp >> 1) * 64] = (tp & 1) ? bits : bits << 16;
+      mask_base[(tp >> 1) * 64 + lane] = (tp & 1) ? bits : bits << 16;
       bits = 0;
     }
   }
@@ -586,13 +591,6 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             else hn_layer_pipelined<4, 4, false>(cur, nxt, bias, ws, out_base, mask_base, lane);
             continue;
           }
-#ifdef HN_PIPE256
-          if (plain && K32 == 8 && NT == 8) {
-            if (do_stash) hn_layer_pipelined<8, 8, true>(cur, nxt, bias, ws, out_base, mask_base, lane);
-            else hn_layer_pipelined<8, 8, false>(cur, nxt, bias, ws, out_base, mask_base, lane);
-            continue;
-          }
-#endif
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -662,7 +660,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             if ((t & 1) || t == NT - 1) {
               // a plain (cached) store: the backward machine stalls on these words at the top of every layer, and
               // unlike the once-streamed stash they are small enough (70 MB per step) to survive in L2 / MALL
-              if (do_mask) mask_base[(t >> 1) * 64] = (t & 1) ? bits : bits << 16;
+              if (do_mask) mask_base[(t >> 1) * 64 + lane] = (t & 1) ? bits : bits << 16;
               bits = 0;
             }
             if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, out_base, t, lane);
@@ -716,7 +714,7 @@ HN_DEV bool hn_prefetch_masks(const HnMlpArgs& a, const HnOpWords& wn, int blk, 
   const uint32_t* mb = hn_mask_base(a, wn[4], (NT + 1) >> 1, blk, lane);
 #pragma unroll
   for (int dd = 0; dd < 4; ++dd)
-    out[dd] = (2 * dd < NT) ? (wave_valid ? mb[dd * 64] : 0xffffffffu) : 0u;
+    out[dd] = (2 * dd < NT) ? (wave_valid ? mb[dd * 64 + lane] : 0xffffffffu) : 0u;
   return true;
 }
 
@@ -838,7 +836,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         for (int t = 0; t < 8; ++t) {
           if (t < NT) {
             if (w[5] >= 0 && !(t & 1)) {  // output activation was relu: dZ = dY * relu'
-              nbits = wave_valid ? ~hn_mask_base(a, w[5], (NT + 1) >> 1, blk, lane)[(t >> 1) * 64] : 0u;
+              nbits = wave_valid ? ~hn_mask_base(a, w[5], (NT + 1) >> 1, blk, lane)[(t >> 1) * 64 + lane] : 0u;
             }
             f32x16 v;
 #pragma unroll
@@ -867,7 +865,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd)
               if (2 * dd < NT)
-                mbits[dd] = wave_valid ? ~mb[dd * 64] : 0u;
+                mbits[dd] = wave_valid ? ~mb[dd * 64 + lane] : 0u;
           }
         }
         mnext_ready = false;
