@@ -478,7 +478,8 @@ def _pmc_traffic(a):
             t = json.load(open(h))
         except (OSError, ValueError):
             continue
-        if not (t.get("rays") == a.rays and t.get("nc") == a.nc and t.get("nf") == a.nf):
+        if not (t.get("rays") == a.rays and t.get("nc") == a.nc and t.get("nf") == a.nf
+                and t.get("dtype", "bf16") == a.precision):      # the fp32 mode moves 3x the bytes of the bf16 mode
             continue
         theirs = (t.get("build") or {}).get("kernel_src_sha256")
         if theirs == mine:

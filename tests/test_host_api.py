@@ -320,7 +320,7 @@ def test_pmc_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
 
     class A:
-        config, rays, nc, nf = 2, 1024, 64, 64
+        config, rays, nc, nf, precision = 2, 1024, 64, 64, "bf16"
     mine = L.build_id()["kernel_src_sha256"]
     base = {"config": 2, "rays": 1024, "nc": 64, "nf": 64, "bytes_per_step": 1.0, "per_kernel_launch": {}}
     (prof / "r02_traffic_config2.json").write_text(json.dumps(base))                       # unstamped: never quoted
@@ -332,6 +332,8 @@ def test_pmc_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
     (prof / "r04_traffic_config2.json").write_text(json.dumps(dict(base, build={"kernel_src_sha256": mine})))
     t, note = bench._pmc_traffic(A)
     assert t is not None and note is None and t["source"].endswith("r04_traffic_config2.json")
+    A.precision = "fp32"          # a bf16 collection says nothing about the fp32 mode's bytes
+    assert bench._pmc_traffic(A)[0] is None
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/utils"), reason="build container only: needs /root/reference")

@@ -60,7 +60,8 @@ with open(os.path.join(dst, f"{tag}_pmc_per_kernel{sfx}.csv"), "w") as f:
                 f",{share}\n")
 line = json.load(open(os.path.join(src, "bench_line.json")))
 traffic = {"config": cfg, "rays": line["config"]["rays_per_gpu"], "nc": line["config"]["n_samples"],
-           "nf": line["config"]["n_importance"], "pmc_steps": PMC_STEPS, "bytes_per_step": step_bytes,
+           "nf": line["config"]["n_importance"], "dtype": line.get("dtype", "bf16"), "pmc_steps": PMC_STEPS,
+           "bytes_per_step": step_bytes,
            # the kernels these counters were collected on (bench.py refuses to quote the file for any other build)
            "build": dict(line.get("build") or {}, git_sha=GIT_SHA),
            "per_kernel_launch": {k: per_kernel_bytes[k] / per_kernel_n[k] for k in per_kernel_bytes if k.startswith("hn_")},
