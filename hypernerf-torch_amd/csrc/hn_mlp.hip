@@ -80,8 +80,10 @@ HN_DEV void hn_rev_split(float x, float& hi, float& lo) {
 }
 // `rev` (bf16 forward only, else nullptr): planes [hi | lo] of n_trig x 32 floats behind the wave's value plane, for
 // the first n_trig staged components (the host orders components so that every encoded one comes first).
+// `with_lo` false (a program whose planes would not fit into LDS otherwise): only hi is staged, the features read a
+// shared all-zero plane as lo — the accuracy of the one-FMA form (hi alone carries x / 2pi to 2^-24 relative).
 HN_DEV void hn_stage_sources(float* srcv, const HnMlpArgs& a, int p, int ray, int lane, float* rev = nullptr,
-                             int n_trig = 0) {
+                             int n_trig = 0, bool with_lo = true) {
   const int r = lane & 31, h = lane >> 5;
   for (int ci = h; ci < a.n_comps; ci += 2) {
     const int c = a.comps[ci];
@@ -106,9 +108,10 @@ HN_DEV void hn_stage_sources(float* srcv, const HnMlpArgs& a, int p, int ray, in
       float hi, lo;
       hn_rev_split(x, hi, lo);
       rev[ci * 32 + r] = hi;
-      rev[(n_trig + ci) * 32 + r] = lo;
+      if (with_lo) rev[(n_trig + ci) * 32 + r] = lo;
     }
   }
+  if (rev != nullptr && !with_lo && h == 0) rev[n_trig * 32 + r] = 0.0f;      // the shared zero plane
 }
 
 // (Never a gathered source: machine.Program refuses to leave identity features of a source in `no_direct` unstaged.
@@ -150,13 +153,13 @@ HN_DEV HnDFeat hn_derive_feat(const HnFeat e) {
   d.idmask = (kind == HN_FEAT_ID || kind == HN_FEAT_ID_DIRECT) ? 0xffffffffu : 0u;
   return d;
 }
-HN_DEV HnDFeat hn_derive_feat_fwd(const HnFeat e, int n_comps, int n_trig) {
+HN_DEV HnDFeat hn_derive_feat_fwd(const HnFeat e, int n_comps, int n_trig, bool with_lo) {
   const int kind = (e.packed >> 12) & 15, ci = e.packed & 255;
   HnDFeat d;
   const bool trig = (kind == HN_FEAT_SIN || kind == HN_FEAT_COS || kind == HN_FEAT_SINP) && ci < n_trig;
   // two staged values per feature: (A, B) = (hi, lo) of x / 2pi for a trigonometric feature, (x, x) for the others
   const unsigned oa = trig ? (unsigned)(n_comps + ci) * 128u : (unsigned)ci * 128u;
-  const unsigned ob = trig ? (unsigned)(n_comps + n_trig + ci) * 128u : oa;
+  const unsigned ob = trig ? (unsigned)(n_comps + n_trig + (with_lo ? ci : 0)) * 128u : oa;
   d.off = oa | ob << 16;
   d.scale = trig ? e.freq : 0.0f;
   d.phase = (kind == HN_FEAT_COS || kind == HN_FEAT_SINP) ? 0.25f : 0.0f;
@@ -525,14 +528,16 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   HnDFeat* dfeat_lds = reinterpret_cast<HnDFeat*>(feat_lds + ((a.n_feat + 1) & ~1));      // bf16 kernels only
   // per wave: value plane (n_comps x 32 floats) and, bf16 only, the (hi, lo) planes of x / 2pi for the first n_trig
   const int n_trig = BF16 ? a.n_trig_comps : 0;
+  const bool with_lo = a.trig_lo_planes != 0;
+  const int n_planes = BF16 ? a.n_comps + n_trig + (with_lo ? n_trig : 1) : a.n_comps;
   float* srcv = reinterpret_cast<float*>(BF16 ? reinterpret_cast<char*>(dfeat_lds + a.n_feat)
-                                              : reinterpret_cast<char*>(dfeat_lds)) + wave * ((a.n_comps + 2 * n_trig) * 32);
+                                              : reinterpret_cast<char*>(dfeat_lds)) + wave * (n_planes * 32);
   float* rev = BF16 ? srcv + a.n_comps * 32 : nullptr;
   for (int i = threadIdx.x; i < a.n_bias; i += blockDim.x) bias_lds[i] = a.bias[i];
   for (int i = threadIdx.x; i < a.n_feat; i += blockDim.x) {
     const HnFeat e = a.feat[i];
     feat_lds[i] = e;
-    if constexpr (BF16) dfeat_lds[i] = hn_derive_feat_fwd(e, a.n_comps, n_trig);
+    if constexpr (BF16) dfeat_lds[i] = hn_derive_feat_fwd(e, a.n_comps, n_trig, with_lo);
   }
   __syncthreads();
 
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
     const int p = valid ? p0 : a.n_points - 1;
     const int ray = p / a.samples_per_ray;
     const bool wave_valid = blk * 32 < a.n_points;  // wave-uniform: the block holds at least one point
-    hn_stage_sources(srcv, a, p, ray, lane, rev, n_trig);
+    hn_stage_sources(srcv, a, p, ray, lane, rev, n_trig, with_lo);
     ws.start();
 
     HnOpWords w_next = hn_load_op(a.ops, 0, a.n_ops);
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
                     float hi, lo;
                     hn_rev_split(y, hi, lo);
                     rev[ci * 32 + r] = hi;
-                    rev[(n_trig + ci) * 32 + r] = lo;
+                    if (with_lo) rev[(n_trig + ci) * 32 + r] = lo;
                   }
                 }
               }
@@ -1452,7 +1457,9 @@ extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
   hn_allow_big_lds();
   constexpr int WB = ModeT<true>::WAVES;
   if (a->n_trig_comps < 0 || a->n_trig_comps > a->n_comps) return -5;
-  const size_t planes = a->mode == HN_MODE_BF16 ? (size_t)a->n_comps + 2 * (size_t)a->n_trig_comps : (size_t)a->n_comps;
+  const size_t planes = a->mode == HN_MODE_BF16
+                            ? (size_t)a->n_comps + (size_t)a->n_trig_comps + (a->trig_lo_planes ? (size_t)a->n_trig_comps : 1)
+                            : (size_t)a->n_comps;
   const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + (size_t)((a->n_bias + 3) & ~3) * 4 +
                      (size_t)((a->n_feat + 1) & ~1) * 8 + (a->mode == HN_MODE_BF16 ? (size_t)a->n_feat * 16 : 0) +
                      (size_t)8 * planes * 32 * 4;

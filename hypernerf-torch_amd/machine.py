@@ -871,6 +871,12 @@ class MlpRunner:
         a.prof = L.PROF_BUFFER.data_ptr() if L.PROF_BUFFER is not None else 0
         a.comps, a.n_comps = d.comps.data_ptr(), len(self.prog.comp_map)
         a.n_trig_comps = min(len(self.prog.comp_map), max(1, self.prog.n_trig_comps))
+        # hi + lo planes of x / 2pi for the encoded components when the forward's LDS budget allows (158 KiB: ring +
+        # bias / feature tables + 8 waves x planes x 128 B), else hi alone (the one-FMA accuracy of rounds 1-2)
+        n_feat, n_bias = max(1, len(self.prog.feat_table)), max(32, self.prog.bias_len)
+        fixed = 2 * CHUNK * 1024 + ((n_bias + 3) & ~3) * 4 + ((n_feat + 1) & ~1) * 8 + n_feat * 16
+        full = fixed + 8 * (a.n_comps + 2 * a.n_trig_comps) * 128
+        a.trig_lo_planes = 1 if full <= 158 * 1024 else 0
         a.stash = stash.data_ptr() if stash is not None else 0
         a.masks = masks.data_ptr() if masks is not None else 0
         a.dsrc = dsrc.data_ptr() if dsrc is not None else 0

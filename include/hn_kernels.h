@@ -52,8 +52,10 @@ typedef void* hnStream_t; /* hipStream_t */
  * GENERATED features (feature table)].  For every 32-row output tile t < NT, one at a time:
  *     acc = bias[32t..] + W[32t.., main] . cur + W[32t.., aux] . generated ;  nxt[t] = act(acc)
  * then cur <- nxt (unless NO_COMMIT).  Weight-stream order per tile: K32 main blocks, then 2*nG
- * aux blocks (a "block" = 32 out x 32 in).  Training: relu bit mask -> mask_slot, transposed
- * activation -> stash_out (X of the next layer's dW), transposed generated features -> stash_aux. */
+ * aux blocks (a "block" = 32 out x 32 in).  Training: relu bit mask -> mask_slot, activation ->
+ * stash_out (X of the next layer's dW), generated features -> stash_aux.  The stash is a workspace of the three
+ * machine kernels, opaque to the host: bf16 mode stores the operand fragments as they are (the weight-gradient kernel
+ * transposes on its LDS read), fp32 mode stores tiles transposed through the matrix core. */
 #define HN_OP_LAYER 1    /* w1 = K32 | nG<<8 | NT<<16 | act<<24 | flags<<28 ; w2=bias_off w3=feat_off
                             w4=mask|-1 w5=stash_out|-1 w6=stash_aux|-1 — RESOLVED for the launch: the byte offset
                             of block 0 of that stash region in KiB (masks: in units of 256 B); a region holds, per
@@ -166,7 +168,9 @@ typedef struct {
   int8_t embed_col[HN_DSRC_COMPS]; /* slot -> column of the table row, -1 = not an embedding component */
   int32_t n_trig_comps;   /* forward, bf16: staged components 0 .. n_trig_comps-1 also get x / 2pi staged as hi + lo
                              (every component a trigonometric feature reads must be among them; >= 1 if n_comps > 0) */
-  int32_t pad2;
+  int32_t trig_lo_planes; /* 1: the lo planes are staged (exactly reduced sine arguments); 0: hi only + one shared zero
+                             plane (programs whose staging would not fit into LDS otherwise: hn_mlp_forward returns -6
+                             when ring + tables + 8 waves x (n_comps + n_trig + (lo ? n_trig : 1)) x 128 B > 158 KiB) */
 } HnMlpArgs;
 
 /* weight packing: one descriptor per 1-KiB unit of a stream */

@@ -363,6 +363,48 @@ def test_bf16_mode_vs_bf16_operand_oracle(case):
         HN.set_precision("bf16")
 
 
+def test_hi_only_staging_when_the_planes_do_not_fit_into_lds():
+    """A program with 30 ENCODED source components: hi + lo planes of x / 2pi for all of them do not fit into LDS
+    beside the weight ring, so the bf16 forward stages hi alone (HnMlpArgs.trig_lo_planes = 0, one shared zero plane).
+    No model of the render path gets there (its encoders read <= 15 components); built directly on the machine and
+    checked against torch under the bf16-operand contract, forward and gradients."""
+    from hypernerf_torch_amd import functional as HF
+    from hypernerf_torch_amd.machine import AuxSpec, GradIn, Layer, OutSpec, Program, posenc_features
+    HN.set_precision("bf16")
+    n, c = 777, 30
+    x = H.uniform(23, "wide_x", (n, c), -1.0, 1.0)
+    l0, l1 = torch.nn.Linear(c * 5, 64), torch.nn.Linear(64, 3)
+    with torch.no_grad():
+        for i, prm in enumerate(list(l0.parameters()) + list(l1.parameters())):
+            prm.copy_(H.uniform(23, f"wide_p{i}", tuple(prm.shape), -0.3, 0.3))
+    feats = posenc_features(0, range(c), 2, need_grad=False)
+    layers = [Layer("l0", l0.weight, l0.bias, aux=AuxSpec(feats), act="relu"),
+              Layer("l1", l1.weight, l1.bias, main=(0, 64), act="none", out=OutSpec(0, 0, "none"), grad_in=GradIn(4, 0))]
+    l0.to(DEV), l1.to(DEV)
+    call = HF.ProgramCall(Program(layers, n_src=1, name="wide_encoder"), [False], [3], [("g", 0)])
+    assert call.program.n_trig_comps == c
+    (y,) = HF.run_program(call, [x.to(DEV)], 1)
+    g = H.normal(23, "wide_g", (n, 3))
+    (y * g.to(DEV)).sum().backward()
+    # reference: posenc_orig order [x, sin(1x), cos(1x), sin(2x), cos(2x)], every Linear with bf16-rounded operands
+    r16 = lambda t: t.to(torch.bfloat16).float()
+    w0, b0, w1, b1 = (t.detach().cpu().clone().requires_grad_(True) for t in (l0.weight, l0.bias, l1.weight, l1.bias))
+    f = torch.cat([x, torch.sin(x), torch.cos(x), torch.sin(2 * x), torch.cos(2 * x)], -1)
+    with O.bf16_operands():
+        hcpu = torch.relu(O._linear({"a.weight": w0, "a.bias": b0}, "a", f))
+        ref = O._linear({"b.weight": w1, "b.bias": b1}, "b", hcpu)
+    (ref * g).sum().backward()
+    assert_close(y, ref, 2e-3, "hi-only staging: forward", elementwise=False)
+    for name, got, want in (("l0.weight", l0.weight.grad, w0.grad), ("l0.bias", l0.bias.grad, b0.grad),
+                            ("l1.weight", l1.weight.grad, w1.grad), ("l1.bias", l1.bias.grad, b1.grad)):
+        assert_grad_close(got, want, 3e-2, f"hi-only staging d {name}", frobenius=True)
+    # and the launch really ran in the compact mode
+    a = call.runner._args(call.runner._tables(torch.device(DEV), 1), 1, n, 1, False, call.runner._ops(torch.device(DEV), 1, n)[0],
+                          len(call.program.fwd_ops), 0, 1, [(x.to(DEV), False)], [y.detach()], None, None, None)
+    assert a.n_trig_comps == c and a.trig_lo_planes == 0
+    HN.set_precision("bf16")
+
+
 OPTION_CASES = {
     # call-time use_warp=False on a model built without a warp field (models.py:695, 723: `self.use_warp and use_warp`)
     "call_nowarp": (dict(use_warp=False, hyper_slice_method=None, use_nerf_embed=True, use_alpha_cond=True), dict(use_warp=False)),
