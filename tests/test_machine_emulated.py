@@ -411,3 +411,39 @@ def test_legacy_nerf_aux_first_skip_emulated(bf16):
     _, gtot = prog.grad_offsets()
     flat = E.run_wgrad(prog, mode, jobs, stash, gtot)
     check_grads(prog, flat, tp, dict(m.named_parameters()))
+
+
+def test_exact_argument_reduction_of_the_bf16_encoders():
+    """The arithmetic behind hn_rev_split / hn_features4 (hn_mlp.hip), replayed in float32 numpy: x / 2pi staged as
+    hi + lo (hi = fl(x c), lo = the FMA residual of that product + x (1/2pi - c)), feature argument =
+    fract(f hi) + (f lo + phase).  For the power-of-two frequencies of posenc_orig the argument must agree with the
+    exact f x / 2pi (mod 1) to ~1e-7 revolutions at EVERY octave, where the one-FMA form of rounds 1-2,
+    fract(fl(f / 2pi) x + phase), is off by up to ~1e-5 at f = 512 — the error that carried 2/3 of the bf16 mode's
+    gradient error."""
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1.0, 1.0, 200000).astype(np.float32)
+    c_hi = np.float32(0.15915494309189535)
+    c_lo = np.float32(0.15915494309189535 - float(c_hi))
+    f32 = np.float32
+
+    def fma(a, b, c):       # one rounding: the float32 product is exact in float64
+        return (a.astype(np.float64) * np.float64(b) + c.astype(np.float64)).astype(np.float32)
+
+    hi = (x * c_hi).astype(np.float32)
+    lo = fma(x, c_lo, fma(x, c_hi, -hi))
+    exact_rev = x.astype(np.float64) / (2.0 * np.pi)
+    worst_new, worst_old = 0.0, 0.0
+    for k in range(10):
+        f = f32(2.0 ** k)
+        big = (f * hi).astype(np.float32)                  # exact: a power of two times a float32
+        assert np.array_equal(big.astype(np.float64), np.float64(f) * hi.astype(np.float64))
+        arg_new = (big - np.floor(big)).astype(np.float32) + fma(lo, f, np.zeros_like(lo))
+        want = np.float64(f) * exact_rev
+        err_new = np.abs(((arg_new.astype(np.float64) - want + 0.5) % 1.0) - 0.5)
+        scale = f32(float(f) * 0.15915494309189535)
+        t_old = fma(x, scale, np.zeros_like(x))
+        arg_old = (t_old - np.floor(t_old)).astype(np.float32)
+        err_old = np.abs(((arg_old.astype(np.float64) - want + 0.5) % 1.0) - 0.5)
+        worst_new, worst_old = max(worst_new, err_new.max()), max(worst_old, err_old.max())
+        assert err_new.max() < 1.3e-7, (k, err_new.max())
+    assert worst_old > 3e-6 and worst_old / worst_new > 25, (worst_old, worst_new)
