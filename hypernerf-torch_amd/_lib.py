@@ -56,7 +56,7 @@ class HnMlpArgs(C.Structure):
         ("src", HnSrc * HN_MAX_SRC), ("dst", HnDst * HN_MAX_DST), ("slots", HnSlot * HN_MAX_SLOTS),
         ("prof", C.c_void_p), ("comps", C.c_void_p), ("n_comps", C.c_int32), ("embed_reg_mask", C.c_int32),
         ("embed_grad", C.c_void_p), ("embed_idx", C.c_void_p), ("embed_rows", C.c_int32), ("embed_dim", C.c_int32),
-        ("embed_col", C.c_int8 * 32), ("n_trig_comps", C.c_int32), ("trig_lo_planes", C.c_int32),
+        ("embed_col", C.c_int8 * 32), ("n_trig_comps", C.c_int32), ("wide_ops", C.c_int32), ("pad3", C.c_int32), ("trig_lo_planes", C.c_int32),
     ]
 
 

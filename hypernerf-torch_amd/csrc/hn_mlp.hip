@@ -726,7 +726,10 @@ HN_DEV bool hn_prefetch_masks(const HnMlpArgs& a, const HnOpWords& wn, int blk, 
 // ------------------------------------------------------------------------------------------------
 // backward-data machine
 // ------------------------------------------------------------------------------------------------
-template <bool BF16>
+// WIDE: the program holds HN_BOP_LOAD_WIDE ops (stand-alone modules with > 4 output columns; never a render-level
+// program).  Compiled out, the bf16 kernel needs no scratch at all (188 B/lane with it: the wide load's 16-value gather
+// per tile pushes the allocator over 256 registers in the prologue).
+template <bool BF16, bool WIDE>
 __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_bwd_kernel(const HnMlpArgs a) {
   using M = ModeT<BF16>;
   using Frag = typename M::Frag;
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
           if (to2) cur2[s] = tmp[s];
           else cur[s] = tmp[s];
         }
-      } else if (code == HN_BOP_LOAD_WIDE) {
+      } else if (WIDE && code == HN_BOP_LOAD_WIDE) {
         const int n = w[3], NT = w[4];
         const HnSrc s = a.src[w[1]];
         unsigned nbits = 0xffffffffu;  // complement of the mask word: set = keep
@@ -1368,8 +1371,9 @@ static void hn_allow_big_lds() {
   (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
 }
@@ -1488,11 +1492,15 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
   if (a->mode == HN_MODE_BF16) {
     constexpr int WB = ModeT<true>::WAVES;
     const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + (size_t)a->n_feat * 16 + (size_t)WB * a->n_comps * 32 * 4;
-    hipLaunchKernelGGL(hn_mlp_bwd_kernel<true>, dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
-                       (hipStream_t)stream, *a);
+    if (a->wide_ops)
+      hipLaunchKernelGGL((hn_mlp_bwd_kernel<true, true>), dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
+                         (hipStream_t)stream, *a);
+    else
+      hipLaunchKernelGGL((hn_mlp_bwd_kernel<true, false>), dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
+                         (hipStream_t)stream, *a);
   } else {
     const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + (size_t)4 * a->n_comps * 32 * 4;
-    hipLaunchKernelGGL(hn_mlp_bwd_kernel<false>, dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
+    hipLaunchKernelGGL((hn_mlp_bwd_kernel<false, true>), dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
                        (hipStream_t)stream, *a);
   }
   HN_CHECK_LAUNCH();

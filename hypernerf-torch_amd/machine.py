@@ -28,6 +28,7 @@ import torch
 from . import _lib as L
 
 CHUNK = L.HN_CHUNK_UNITS
+_FORCE_WIDE = os.environ.get("HN_FORCE_WIDE", "0") == "1"
 
 
 def pow2ceil(n: int) -> int:
@@ -870,6 +871,8 @@ class MlpRunner:
         a.max_groups = max([ly.aux.groups for ly in self.prog.layers if ly.aux is not None], default=0)
         a.prof = L.PROF_BUFFER.data_ptr() if L.PROF_BUFFER is not None else 0
         a.comps, a.n_comps = d.comps.data_ptr(), len(self.prog.comp_map)
+        # (HN_FORCE_WIDE=1: A/B knob — take the kernel build that carries the wide ops although the program has none)
+        a.wide_ops = int(any(ly.out is not None and ly.out.wide for ly in self.prog.layers) or _FORCE_WIDE)
         a.n_trig_comps = min(len(self.prog.comp_map), max(1, self.prog.n_trig_comps))
         # hi + lo planes of x / 2pi for the encoded components when the forward's LDS budget allows (158 KiB: ring +
         # bias / feature tables + 8 waves x planes x 128 B), else hi alone (the one-FMA accuracy of rounds 1-2)
