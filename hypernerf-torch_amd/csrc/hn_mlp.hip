@@ -496,7 +496,10 @@ HN_DEV void hn_layer_pipelined(bf16x8* cur, bf16x8* nxt, const float* bias, WStr
 // ------------------------------------------------------------------------------------------------
 // AUXG: generated-feature groups (64 features each) a layer may have.  Their fragments stay in registers across the
 // layer's tile loop, so the common programs (<= 2 groups) get a build that does not pay for the third.
-template <bool BF16, int AUXG>
+// EXTRA: the program holds identity features read directly from global memory (HN_LAYER_DIRECT) or HN_OP_OUT_WIDE ops
+// — stand-alone modules with wide raw inputs / outputs; never a render-level program.  Compiled out, the bf16 kernels
+// need 237 (AUXG 2) / 253 (AUXG 3) registers and no scratch (12 / 72 B/lane with them).
+template <bool BF16, int AUXG, bool EXTRA>
 __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_fwd_kernel(const HnMlpArgs a) {
   using M = ModeT<BF16>;
   using Frag = typename M::Frag;
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
         for (int g = 0; g < AUXG; ++g) {
           if (g < nG) {
-            if (flags & HN_LAYER_DIRECT)
+            if (EXTRA && (flags & HN_LAYER_DIRECT))
               hn_make_group<true>(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, dfeat_lds + w[3] + 64 * g, srcv,
                                   lane, a, p, ray);
             else
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         }
       } else if (code == HN_OP_OUT) {
         // handled inside the LAYER op it follows (the raw accumulator is only alive there)
-      } else if (code == HN_OP_OUT_WIDE) {
+      } else if (EXTRA && code == HN_OP_OUT_WIDE) {
         const int n = w[3], NT = w[4];
         if (valid) {
           const HnDst d = a.dst[w[1]];
@@ -1368,9 +1371,11 @@ static void hn_allow_big_lds() {
   if (done) return;
   done = true;
   const int big = 160 * 1024;
-  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -1468,15 +1473,18 @@ extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
                      (size_t)((a->n_feat + 1) & ~1) * 8 + (a->mode == HN_MODE_BF16 ? (size_t)a->n_feat * 16 : 0) +
                      (size_t)8 * planes * 32 * 4;
   if (lds > 158 * 1024) return -6;
+  const dim3 grid_b(hn_grid_for(a->n_points, WB * 32)), blk_b(WB * 64);
   if (a->mode == HN_MODE_BF16) {
-    if (a->max_groups <= 2)
-      hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 2>), dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
-                         (hipStream_t)stream, *a);
-    else
-      hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 3>), dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
-                         (hipStream_t)stream, *a);
+    const bool extra = a->wide_ops != 0;
+    if (a->max_groups <= 2) {
+      if (extra) hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 2, true>), grid_b, blk_b, lds, (hipStream_t)stream, *a);
+      else hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 2, false>), grid_b, blk_b, lds, (hipStream_t)stream, *a);
+    } else {
+      if (extra) hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 3, true>), grid_b, blk_b, lds, (hipStream_t)stream, *a);
+      else hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 3, false>), grid_b, blk_b, lds, (hipStream_t)stream, *a);
+    }
   } else {
-    hipLaunchKernelGGL((hn_mlp_fwd_kernel<false, 3>), dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
+    hipLaunchKernelGGL((hn_mlp_fwd_kernel<false, 3, true>), dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
                        (hipStream_t)stream, *a);
   }
   HN_CHECK_LAUNCH();
@@ -1492,7 +1500,7 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
   if (a->mode == HN_MODE_BF16) {
     constexpr int WB = ModeT<true>::WAVES;
     const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + (size_t)a->n_feat * 16 + (size_t)WB * a->n_comps * 32 * 4;
-    if (a->wide_ops)
+    if (a->wide_ops & 1)
       hipLaunchKernelGGL((hn_mlp_bwd_kernel<true, true>), dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
                          (hipStream_t)stream, *a);
     else

@@ -872,7 +872,9 @@ class MlpRunner:
         a.prof = L.PROF_BUFFER.data_ptr() if L.PROF_BUFFER is not None else 0
         a.comps, a.n_comps = d.comps.data_ptr(), len(self.prog.comp_map)
         # (HN_FORCE_WIDE=1: A/B knob — take the kernel build that carries the wide ops although the program has none)
-        a.wide_ops = int(any(ly.out is not None and ly.out.wide for ly in self.prog.layers) or _FORCE_WIDE)
+        wide = any(ly.out is not None and ly.out.wide for ly in self.prog.layers) or _FORCE_WIDE
+        direct = any(f.kind != L.HN_FEAT_ZERO and (f.src, f.comp) not in self.prog.comp_map for f in self.prog.feat_table)
+        a.wide_ops = (1 if wide else 0) | (2 if (direct or _FORCE_WIDE) else 0)
         a.n_trig_comps = min(len(self.prog.comp_map), max(1, self.prog.n_trig_comps))
         # hi + lo planes of x / 2pi for the encoded components when the forward's LDS budget allows (158 KiB: ring +
         # bias / feature tables + 8 waves x planes x 128 B), else hi alone (the one-FMA accuracy of rounds 1-2)

@@ -168,8 +168,10 @@ typedef struct {
   int8_t embed_col[HN_DSRC_COMPS]; /* slot -> column of the table row, -1 = not an embedding component */
   int32_t n_trig_comps;   /* forward, bf16: staged components 0 .. n_trig_comps-1 also get x / 2pi staged as hi + lo
                              (every component a trigonometric feature reads must be among them; >= 1 if n_comps > 0) */
-  int32_t wide_ops;       /* 1: the op program holds HN_OP_OUT_WIDE / HN_BOP_LOAD_WIDE ops (the backward launch then
-                             takes the kernel build that carries them; 0 selects the build without — no scratch) */
+  int32_t wide_ops;       /* bit 0: the op program holds HN_OP_OUT_WIDE / HN_BOP_LOAD_WIDE ops; bit 1: its feature table
+                             holds HN_FEAT_ID_DIRECT entries (layers flagged HN_LAYER_DIRECT).  Forward launches take
+                             the kernel build that carries those paths if either bit is set, backward launches if bit 0
+                             is; 0 selects the builds without them (what every render-level program runs: no scratch) */
   int32_t pad3;
   int32_t trig_lo_planes; /* 1: the lo planes are staged (exactly reduced sine arguments); 0: hi only + one shared zero
                              plane (programs whose staging would not fit into LDS otherwise: hn_mlp_forward returns -6
