@@ -499,7 +499,8 @@ HN_DEV void hn_layer_pipelined(bf16x8* cur, bf16x8* nxt, const float* bias, WStr
 // EXTRA: the program holds identity features read directly from global memory (HN_LAYER_DIRECT) or HN_OP_OUT_WIDE ops
 // — stand-alone modules with wide raw inputs / outputs; never a render-level program.  Compiled out, the bf16 kernels
 // need 237 (AUXG 2) / 253 (AUXG 3) registers and no scratch (12 / 72 B/lane with them).
-template <bool BF16, int AUXG, bool EXTRA>
+// TRAIN: masks and stashes are written (HnMlpArgs.training); the inference build carries none of that code.
+template <bool BF16, int AUXG, bool EXTRA, bool TRAIN>
 __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_fwd_kernel(const HnMlpArgs a) {
   using M = ModeT<BF16>;
   using Frag = typename M::Frag;
@@ -564,10 +565,10 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const int K32 = w[1] & 255, nG = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
         const int act = (w[1] >> 24) & 15, flags = (w[1] >> 28) & 15;
         const float* bias = bias_lds + w[2];
-        const bool do_mask = a.training && w[4] >= 0 && wave_valid;
-        const bool do_stash = a.training && w[5] >= 0 && wave_valid;
+        const bool do_mask = TRAIN && w[4] >= 0 && wave_valid;
+        const bool do_stash = TRAIN && w[5] >= 0 && wave_valid;
         char* out_base = do_stash ? hn_slot_base<BF16>(a, w[5], NT, blk) : nullptr;
-        char* aux_base = (a.training && wave_valid) ? hn_slot_base<BF16>(a, w[6], 2 * nG, blk) : nullptr;
+        char* aux_base = (TRAIN && wave_valid) ? hn_slot_base<BF16>(a, w[6], 2 * nG, blk) : nullptr;
         uint32_t* mask_base = do_mask ? hn_mask_base(a, w[4], (NT + 1) >> 1, blk, lane) : nullptr;
         const bool has_out = w_next[0] == HN_OP_OUT;    // head layer: its <=4 outputs leave from the accumulator
         const HnOpWords out_w = w_next;
@@ -1371,11 +1372,13 @@ static void hn_allow_big_lds() {
   if (done) return;
   done = true;
   const int big = 160 * 1024;
-  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute((const void*)hn_mlp_fwd_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+#define HN_BIG(k) (void)hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, big)
+  HN_BIG((hn_mlp_fwd_kernel<true, 2, false, true>)); HN_BIG((hn_mlp_fwd_kernel<true, 2, false, false>));
+  HN_BIG((hn_mlp_fwd_kernel<true, 2, true, true>)); HN_BIG((hn_mlp_fwd_kernel<true, 2, true, false>));
+  HN_BIG((hn_mlp_fwd_kernel<true, 3, false, true>)); HN_BIG((hn_mlp_fwd_kernel<true, 3, false, false>));
+  HN_BIG((hn_mlp_fwd_kernel<true, 3, true, true>)); HN_BIG((hn_mlp_fwd_kernel<true, 3, true, false>));
+  HN_BIG((hn_mlp_fwd_kernel<false, 3, true, true>)); HN_BIG((hn_mlp_fwd_kernel<false, 3, true, false>));
+#undef HN_BIG
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -1474,19 +1477,23 @@ extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
                      (size_t)8 * planes * 32 * 4;
   if (lds > 158 * 1024) return -6;
   const dim3 grid_b(hn_grid_for(a->n_points, WB * 32)), blk_b(WB * 64);
+  const hipStream_t st = (hipStream_t)stream;
+#define HN_FWD(G, E, T) hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, G, E, T>), grid_b, blk_b, lds, st, *a)
   if (a->mode == HN_MODE_BF16) {
-    const bool extra = a->wide_ops != 0;
+    const bool extra = a->wide_ops != 0, train = a->training != 0;
     if (a->max_groups <= 2) {
-      if (extra) hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 2, true>), grid_b, blk_b, lds, (hipStream_t)stream, *a);
-      else hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 2, false>), grid_b, blk_b, lds, (hipStream_t)stream, *a);
+      if (extra) { if (train) HN_FWD(2, true, true); else HN_FWD(2, true, false); }
+      else { if (train) HN_FWD(2, false, true); else HN_FWD(2, false, false); }
     } else {
-      if (extra) hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 3, true>), grid_b, blk_b, lds, (hipStream_t)stream, *a);
-      else hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 3, false>), grid_b, blk_b, lds, (hipStream_t)stream, *a);
+      if (extra) { if (train) HN_FWD(3, true, true); else HN_FWD(3, true, false); }
+      else { if (train) HN_FWD(3, false, true); else HN_FWD(3, false, false); }
     }
   } else {
-    hipLaunchKernelGGL((hn_mlp_fwd_kernel<false, 3, true>), dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
-                       (hipStream_t)stream, *a);
+    const dim3 grid_f(hn_grid_for(a->n_points, 128)), blk_f(256);
+    if (a->training) hipLaunchKernelGGL((hn_mlp_fwd_kernel<false, 3, true, true>), grid_f, blk_f, lds, st, *a);
+    else hipLaunchKernelGGL((hn_mlp_fwd_kernel<false, 3, true, false>), grid_f, blk_f, lds, st, *a);
   }
+#undef HN_FWD
   HN_CHECK_LAUNCH();
   return 0;
 }
