@@ -573,3 +573,45 @@ def test_checkpoint_into_the_hip_model_renders_like_the_oracle(tmp_path):
     for lvl in ("coarse", "fine"):
         for key in ("rgb", "depth", "weights"):
             assert torch.equal(again[lvl][key], trained[lvl][key]), f"reloaded model renders differently: {lvl}/{key}"
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_forked_weight_gradient_schedule_matches_serial(use_graph):
+    """functional.set_wgrad_overlap(True) (bench.py --fork-wgrad): each program's weight-gradient launch on a side
+    stream behind its own backward-data kernel, joined at the end of backward — eagerly and as parallel branches of a
+    captured HIP graph.  Off by default (measured slower), but it must compute the same
+    gradients as the one batched launch: to 1e-5 of the buffer's scale (float atomics in a different order)."""
+    from hypernerf_torch_amd.graphs import GraphedStep
+    from hypernerf_torch_amd.hypernerf import model_utils
+    from hypernerf_torch_amd.losses import MSELoss
+    m, _ = small_model(71, 16, 16, noise_std=None, precision="bf16")
+    arena = HN.ParamArena(m.parameters())
+    _, _, _, rays = ray_rows(71, 64)
+    rays = rays.to(DEV)
+    gt = H.uniform(71, "gt", (64, 3), 0, 1).to(DEV)
+    rng = {"t_rand": H.uniform(71, "t", (64, 16), 0, 1).to(DEV), "u": H.uniform(71, "u", (64, 16), 0, 1).to(DEV)}
+    loss_fn = MSELoss()
+
+    def fwd_bwd():
+        out = m(model_utils.prepare_ray_dict(rays), {}, rng=rng)
+        F.backward(loss_fn(out, gt))
+
+    grads = {}
+    try:
+        for forked in (False, True):
+            F.set_wgrad_overlap(forked)
+            arena.zero_grad()
+            if use_graph:
+                g = GraphedStep(fwd_bwd, warmup=2, mutates_params=False)
+                arena.zero_grad()
+                g()
+            else:
+                fwd_bwd()
+            torch.cuda.synchronize()
+            assert not F._FORKED and not F._PENDING
+            grads[forked] = arena.grad.clone()
+    finally:
+        F.set_wgrad_overlap(False)
+    scale = float(grads[False].abs().max())
+    assert scale > 0
+    assert float((grads[True] - grads[False]).abs().max()) <= 1e-5 * scale
