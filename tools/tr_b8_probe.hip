@@ -1,5 +1,10 @@
 // Diagnostic: lane layout of ds_read_b64_tr_b8 on gfx950 (no local documentation).  Lane L supplies LDS address 8 L
 // (64 lanes x 8 bytes = 512 contiguous bytes); every byte of the result is printed as the LDS byte offset it came from.
+// Measured (gpurun_out/tr_b8_probe.txt, round 3): per group of 16 lanes the 16 x 8 supplied bytes form 8 rows of 16
+// bytes, row k = the 8 bytes of lane 2k followed by the 8 bytes of lane 2k+1; lane i of the group receives column i:
+// result byte b = byte (i & 7) of the piece supplied by lane 2b + (i >> 3).  I.e. an 8 x 16 byte transposition — one
+// read hands a lane its MFMA K-run of 8 consecutive rows (points) for its column (feature), the 8-bit analogue of what
+// DwFrag<true> does with four ds_read_b64_tr_b16.
 // Build: hipcc -O2 --offload-arch=gfx950 -o tools/tr_b8_probe tools/tr_b8_probe.hip ; run: tools/tr_b8_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
