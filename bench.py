@@ -54,7 +54,9 @@ def parse():
     ap.add_argument("--rays", type=int, default=None)
     ap.add_argument("--nc", type=int, default=None)
     ap.add_argument("--nf", type=int, default=None)
-    ap.add_argument("--precision", default=None, choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32", "bf16s8"],
+                    help="bf16s8: OPT-IN variant of bf16 with the training stash in 8 bits (HN_MODE_BF16_S8) — never the default, "
+                         "reported as dtype 'bf16 (8-bit stash: e4m3 X, e5m2 dZ)'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
@@ -347,7 +349,7 @@ def main():
         "metric": "ray-samples/sec (fwd+bwd+Adam), whole job; per-GPU = value/n_gpus",
         "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": a.precision, "data": "synthetic",
+        "dtype": "bf16 (8-bit stash: e4m3 X, e5m2 dZ; opt-in)" if a.precision == "bf16s8" else a.precision, "data": "synthetic",
         "config": {"workload": workload, "baseline_config": a.config, "rays_per_gpu": b, "n_samples": a.nc,
                    "n_importance": a.nf, "parallelism": f"dp{world}", "hip_graph": use_graph, "wgrad_schedule": wgrad_schedule, "dp_code_path": dp, "grad_sync": None if sync is None else ("one all-reduce" if sync.split is None else f"two buckets split at float {sync.split} of {arena.numel}, overlapped"),
                    "ranks_seen_by_collective": ranks_seen},
@@ -395,8 +397,10 @@ def roofline(a, L, fwd_bwd, opt, progs, step_s, b):
     L.KERNEL_TIMES = None
     tot = {k: sum(v) for k, v in times.items()}
     flops_pass = sum(2.0 * macs_per_point(p) * pts for p, pts in progs.values())      # one of fwd / bwd / wgrad
-    mode = 1 if a.precision == "bf16" else 0
-    tile_bytes = 2048 if a.precision == "bf16" else 4096
+    prec_key = "bf16" if a.precision == "bf16s8" else a.precision      # the 8-bit MFMA of the opt-in mode runs at the bf16 rate
+    from hypernerf_torch_amd import machine as HM
+    mode = HF.mode_of(a.precision)
+    tile_bytes = HM.mode_consts(mode)[1]
     stash_read = 0.0
     for prog, pts_list in _points_by_program(progs):
         for pts in pts_list:
@@ -415,8 +419,8 @@ def roofline(a, L, fwd_bwd, opt, progs, step_s, b):
         kern[g] = (ms_step, launches)
         mf = flops_pass / (ms_step * 1e-3)
         per_kernel[sym[g]] = {"ms_per_step": ms_step, "launches_per_step": launches,
-                              "mfma": {"achieved": mf / 1e12, "peak": PEAK[a.precision] / 1e12, "unit": "TFLOP/s",
-                                       "frac": mf / PEAK[a.precision], "algorithmic_flops_per_step": flops_pass}}
+                              "mfma": {"achieved": mf / 1e12, "peak": PEAK[prec_key] / 1e12, "unit": "TFLOP/s",
+                                       "frac": mf / PEAK[prec_key], "algorithmic_flops_per_step": flops_pass}}
     out = {}
     if kern:
         dom = max(kern, key=lambda k: kern[k][0])
@@ -427,8 +431,8 @@ def roofline(a, L, fwd_bwd, opt, progs, step_s, b):
         # in the operand dtype; fp32 gradients written once
         uniq = {id(p): p for p, _ in progs.values()}
         n_params = sum(sum(q.numel() for q in p.params) for p in uniq.values())
-        alg_bytes = b * 68.0 + 2.0 * n_params * (2 if a.precision == "bf16" else 4) + 4.0 * n_params
-        rl = {"bound": "mfma", "kernel": sym[dom] + ("<true>" if a.precision == "bf16" else "<false>"),
+        alg_bytes = b * 68.0 + 2.0 * n_params * (2 if prec_key == "bf16" else 4) + 4.0 * n_params
+        rl = {"bound": "mfma", "kernel": sym[dom] + ("<true>" if prec_key == "bf16" else "<false>"),
               "achieved": pk["achieved"], "peak": pk["peak"], "unit": "TFLOP/s", "frac": pk["frac"],
               "traffic": None, "avg_launch_ms": ms_step / launches, "launches_per_step": launches,
               "algorithmic_flops_per_launch": flops_pass / launches,
@@ -452,7 +456,7 @@ def roofline(a, L, fwd_bwd, opt, progs, step_s, b):
         out["roofline"] = rl
         out["hbm"] = hbm
     out["step_tflops"] = 3.0 * flops_pass / step_s / 1e12
-    out["step_mfma_frac"] = 3.0 * flops_pass / step_s / PEAK[a.precision]
+    out["step_mfma_frac"] = 3.0 * flops_pass / step_s / PEAK[prec_key]
     return out
 
 

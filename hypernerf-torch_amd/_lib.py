@@ -20,7 +20,7 @@ SOURCES = ["hn_mlp.hip", "hn_render.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hn_kernels.h")
 BUILD_MACROS = ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX")     # build-time tuning knobs (A/B experiments)
 
-HN_MODE_F32, HN_MODE_BF16 = 0, 1
+HN_MODE_F32, HN_MODE_BF16, HN_MODE_BF16_S8 = 0, 1, 2
 HN_MAX_SRC, HN_MAX_DST, HN_MAX_SLOTS = 8, 4, 128
 HN_OP_WORDS, HN_CHUNK_UNITS, HN_DSRC_COMPS = 8, int(os.environ.get("HN_CHUNK_UNITS", 32)), 32
 HN_AUXG_MAX = 3
@@ -56,7 +56,7 @@ class HnMlpArgs(C.Structure):
         ("src", HnSrc * HN_MAX_SRC), ("dst", HnDst * HN_MAX_DST), ("slots", HnSlot * HN_MAX_SLOTS),
         ("prof", C.c_void_p), ("comps", C.c_void_p), ("n_comps", C.c_int32), ("embed_reg_mask", C.c_int32),
         ("embed_grad", C.c_void_p), ("embed_idx", C.c_void_p), ("embed_rows", C.c_int32), ("embed_dim", C.c_int32),
-        ("embed_col", C.c_int8 * 32), ("n_trig_comps", C.c_int32), ("wide_ops", C.c_int32), ("pad3", C.c_int32), ("trig_lo_planes", C.c_int32),
+        ("embed_col", C.c_int8 * 32), ("n_trig_comps", C.c_int32), ("wide_ops", C.c_int32), ("dz_scale_log2", C.c_int32), ("trig_lo_planes", C.c_int32),
     ]
 
 

@@ -350,12 +350,13 @@ HN_DEV void hn_gemm_k(f32x16& acc, const typename ModeT<BF16>::Frag* in, int K32
 
 // address of tile 0 of a stash slot for one 32-point block (looked up once per op, outside the tile loops: the slot
 // table sits in the kernel arguments and a lookup is two dependent scalar loads)
-template <bool BF16>
+template <bool BF16, int S8 = 0>
 HN_DEV char* hn_slot_base(const HnMlpArgs& a, int off_kib, int nt, int blk) {
   // `off_kib`: the slot's offset for block 0 in KiB, resolved by the host for this launch's point count (the op
   // word itself: no table lookup — a kernel-argument lookup is two dependent scalar loads per slot and layer)
   if (off_kib < 0) return nullptr;
-  return reinterpret_cast<char*>(a.stash) + (size_t)(unsigned)off_kib * 1024 + (size_t)blk * nt * (ModeT<BF16>::TILE_UNITS * 1024);
+  constexpr int TU = S8 ? 1 : ModeT<BF16>::TILE_UNITS;
+  return reinterpret_cast<char*>(a.stash) + (size_t)(unsigned)off_kib * 1024 + (size_t)blk * nt * (TU * 1024);
 }
 // mask words of a block: `off256` = the slot's byte offset / 256 (resolved by the host), nt words per lane and block
 HN_DEV uint32_t* hn_mask_base(const HnMlpArgs& a, int off256, int nt, int blk, int lane) {
@@ -369,9 +370,42 @@ HN_DEV uint32_t* hn_mask_base(const HnMlpArgs& a, int off256, int nt, int blk, i
 // slot permutation is what makes those reads bank-conflict free.  The 64 lanes still fill exactly one 1-KiB unit.
 // fp32 (parity mode; no 32-bit transposing read exists): transposed through the matrix core as before.
 HN_DEV int hn_stash_slot(int r, int h, int u) { return 32 * h + (r ^ (4 * h + 8 * u)); }
-template <bool BF16>
+// HN_MODE_BF16_S8: a tile is ONE 1-KiB unit, lane (r, h) owns 16 bytes of it — byte i = element i of its accumulator
+// column (feature rho(i, h) of point r), i.e. the two fragments back to back — at 16-byte slot hn_stash8_slot(r, h).
+// The weight-gradient kernel's ds_read_b64_tr_b8 takes, per group of 16 lanes, 8 rows (points) x 16 bytes, a row being
+// the 8-byte halves supplied by a lane pair: with this slot order the 32 halves of a 32-lane access tile one 256-byte
+// window (64 distinct banks), and 4 consecutive lanes still store 64 contiguous bytes.
+HN_DEV int hn_stash8_slot(int r, int h) { return (r & 3) + 4 * h + 8 * ((r >> 2) & 1) + 16 * (r >> 3); }
+// two bf16 of one register -> the two 8-bit values in half `hi` of `old` (S8 = 1: e4m3, 2: e5m2); out-of-range values
+// clamp to the largest finite code (MODE.FP16_OVFL is set at the top of the S8 kernels), never to NaN / inf
+template <int S8>
+HN_DEV int hn_cvt2_f8(unsigned w, int old, bool hi) {
+  const float lo_f = __uint_as_float(w << 16), hi_f = __uint_as_float(w & 0xffff0000u);
+  if constexpr (S8 == 1) return hi ? __builtin_amdgcn_cvt_pk_fp8_f32(lo_f, hi_f, old, true)
+                                   : __builtin_amdgcn_cvt_pk_fp8_f32(lo_f, hi_f, old, false);
+  else return hi ? __builtin_amdgcn_cvt_pk_bf8_f32(lo_f, hi_f, old, true)
+                 : __builtin_amdgcn_cvt_pk_bf8_f32(lo_f, hi_f, old, false);
+}
+template <bool BF16, int S8 = 0>
 HN_DEV void hn_stash(const typename ModeT<BF16>::Frag* fr, char* slot_base, int t, int lane) {
   using M = ModeT<BF16>;
+  if constexpr (BF16 && S8 != 0) {
+    const u32x4 f0 = *reinterpret_cast<const u32x4*>(&fr[0]), f1 = *reinterpret_cast<const u32x4*>(&fr[1]);
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      int lo = 0, hi = 0;
+      lo = hn_cvt2_f8<S8>(f0[2 * k], lo, false);
+      lo = hn_cvt2_f8<S8>(f0[2 * k + 1], lo, true);
+      hi = hn_cvt2_f8<S8>(f1[2 * k], hi, false);
+      hi = hn_cvt2_f8<S8>(f1[2 * k + 1], hi, true);
+      o[k] = (unsigned)lo;
+      o[2 + k] = (unsigned)hi;
+    }
+    char* dst8 = slot_base + (size_t)t * 1024 + hn_stash8_slot(lane & 31, lane >> 5) * 16;
+    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst8));
+    return;
+  }
   char* dst = slot_base + (size_t)t * (M::TILE_UNITS * 1024);
   if constexpr (BF16) {
     const int off0 = hn_stash_slot(lane & 31, lane >> 5, 0) * 16;        // unit 1: the same slot with bit 3 flipped
@@ -428,7 +462,7 @@ HN_DEV HnOpWords hn_load_op(const int* ops, int op, int n_ops) {
 // one share of the previous tile's epilogue + stash, written so that share k only needs shares < k:
 //   k = 0..7   elements 2k, 2k+1: mask bit, ReLU, pack to bf16 (fragment k>>2 complete after k = 3 / 7)
 //   k = 8      the two 16-byte stash stores of the finished fragments (+ the mask word of a finished tile pair)
-template <bool TRAIN, int NT>
+template <bool TRAIN, int NT, int S8>
 HN_DEV void hn_epilogue_share(int k, int tp, f32x16& a, bf16x8* frag, unsigned& bits, char* out_base,
                               uint32_t* mask_base, int lane) {
   if (k < 8) {
@@ -439,7 +473,7 @@ HN_DEV void hn_epilogue_share(int k, int tp, f32x16& a, bf16x8* frag, unsigned& 
       frag[i >> 3][i & 7] = (__bf16)__int_as_float(max(__float_as_int(a[i]), 0));
     }
   } else if (TRAIN && k == 8) {
-    hn_stash<true>(frag, out_base, tp, lane);
+    hn_stash<true, S8>(frag, out_base, tp, lane);
     if ((tp & 1) || tp == NT - 1) {
       mask_base[(tp >> 1) * 64 + lane] = (tp & 1) ? bits : bits << 16;
       bits = 0;
@@ -447,7 +481,7 @@ HN_DEV void hn_epilogue_share(int k, int tp, f32x16& a, bf16x8* frag, unsigned& 
   }
 }
 
-template <int K32, int NT, bool TRAIN>
+template <int K32, int NT, bool TRAIN, int S8>
 HN_DEV void hn_layer_pipelined(bf16x8* cur, bf16x8* nxt, const float* bias, WStream<ModeT<true>::WAVES>& ws,
                                char* out_base, uint32_t* mask_base, int lane) {
   constexpr int N = 2 * K32;            // MFMAs (= issue slots) per tile
@@ -481,7 +515,7 @@ HN_DEV void hn_layer_pipelined(bf16x8* cur, bf16x8* nxt, const float* bias, WStr
         for (int e = 0; e < PER_SLOT; ++e) {
           const int k = u * PER_SLOT + e;
           if (k < SHARES)
-            hn_epilogue_share<TRAIN, NT>(k, tp, acc[tp & 1], nxt + tp * 2, bits, out_base, mask_base, lane);
+            hn_epilogue_share<TRAIN, NT, S8>(k, tp, acc[tp & 1], nxt + tp * 2, bits, out_base, mask_base, lane);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -500,9 +534,13 @@ HN_DEV void hn_layer_pipelined(bf16x8* cur, bf16x8* nxt, const float* bias, WStr
 // — stand-alone modules with wide raw inputs / outputs; never a render-level program.  Compiled out, the bf16 kernels
 // need 237 (AUXG 2) / 253 (AUXG 3) registers and no scratch (12 / 72 B/lane with them).
 // TRAIN: masks and stashes are written (HnMlpArgs.training); the inference build carries none of that code.
-template <bool BF16, int AUXG, bool EXTRA, bool TRAIN>
+// S8: HN_MODE_BF16_S8 — the stash is written as e4m3, 1 KiB per tile (hn_stash); nothing else changes.
+template <bool BF16, int AUXG, bool EXTRA, bool TRAIN, bool S8 = false>
 __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_fwd_kernel(const HnMlpArgs a) {
   using M = ModeT<BF16>;
+  constexpr int SX = S8 ? 1 : 0;
+  static_assert(!(S8 && (EXTRA || !TRAIN || !BF16)), "the 8-bit stash exists for the render-level bf16 training builds only");
+  if constexpr (S8) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");     // FP16_OVFL: 8-bit conversions clamp
   using Frag = typename M::Frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -567,8 +605,8 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const float* bias = bias_lds + w[2];
         const bool do_mask = TRAIN && w[4] >= 0 && wave_valid;
         const bool do_stash = TRAIN && w[5] >= 0 && wave_valid;
-        char* out_base = do_stash ? hn_slot_base<BF16>(a, w[5], NT, blk) : nullptr;
-        char* aux_base = (TRAIN && wave_valid) ? hn_slot_base<BF16>(a, w[6], 2 * nG, blk) : nullptr;
+        char* out_base = do_stash ? hn_slot_base<BF16, SX>(a, w[5], NT, blk) : nullptr;
+        char* aux_base = (TRAIN && wave_valid) ? hn_slot_base<BF16, SX>(a, w[6], 2 * nG, blk) : nullptr;
         uint32_t* mask_base = do_mask ? hn_mask_base(a, w[4], (NT + 1) >> 1, blk, lane) : nullptr;
         const bool has_out = w_next[0] == HN_OP_OUT;    // head layer: its <=4 outputs leave from the accumulator
         const HnOpWords out_w = w_next;
@@ -583,8 +621,8 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
               hn_make_group<false>(aux + g * 2 * M::STEPS32, feat_lds + w[3] + 64 * g, dfeat_lds + w[3] + 64 * g, srcv,
                                    lane, a, p, ray);
             if (aux_base != nullptr) {
-              hn_stash<BF16>(aux + g * 2 * M::STEPS32, aux_base, 2 * g, lane);
-              hn_stash<BF16>(aux + (g * 2 + 1) * M::STEPS32, aux_base, 2 * g + 1, lane);
+              hn_stash<BF16, SX>(aux + g * 2 * M::STEPS32, aux_base, 2 * g, lane);
+              hn_stash<BF16, SX>(aux + (g * 2 + 1) * M::STEPS32, aux_base, 2 * g + 1, lane);
             }
           }
         }
@@ -596,8 +634,8 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
           const bool plain = nG == 0 && act == HN_ACT_RELU && !(flags & HN_LAYER_NO_COMMIT) && !has_out &&
                              wave_valid && do_stash == do_mask;
           if (plain && K32 == 4 && NT == 4) {
-            if (do_stash) hn_layer_pipelined<4, 4, true>(cur, nxt, bias, ws, out_base, mask_base, lane);
-            else hn_layer_pipelined<4, 4, false>(cur, nxt, bias, ws, out_base, mask_base, lane);
+            if (do_stash) hn_layer_pipelined<4, 4, true, SX>(cur, nxt, bias, ws, out_base, mask_base, lane);
+            else hn_layer_pipelined<4, 4, false, SX>(cur, nxt, bias, ws, out_base, mask_base, lane);
             continue;
           }
         }
@@ -672,7 +710,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
               if (do_mask) mask_base[(t >> 1) * 64 + lane] = (t & 1) ? bits : bits << 16;
               bits = 0;
             }
-            if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, out_base, t, lane);
+            if (do_stash) hn_stash<BF16, SX>(nxt + t * M::STEPS32, out_base, t, lane);
             HN_STAMP(4);
           }
         }
@@ -733,9 +771,16 @@ HN_DEV bool hn_prefetch_masks(const HnMlpArgs& a, const HnOpWords& wn, int blk, 
 // WIDE: the program holds HN_BOP_LOAD_WIDE ops (stand-alone modules with > 4 output columns; never a render-level
 // program).  Compiled out, the bf16 kernel needs no scratch at all (188 B/lane with it: the wide load's 16-value gather
 // per tile pushes the allocator over 256 registers in the prologue).
-template <bool BF16, bool WIDE>
+// S8: HN_MODE_BF16_S8 — the machine carries 2^dz_scale_log2 * dZ (exact) and stashes it as e5m2, 1 KiB per tile; source
+// and embedding gradients are scaled back on their way out.
+template <bool BF16, bool WIDE, bool S8 = false>
 __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_bwd_kernel(const HnMlpArgs a) {
   using M = ModeT<BF16>;
+  constexpr int SZ = S8 ? 2 : 0;
+  static_assert(!(S8 && WIDE) && !(S8 && !BF16), "the 8-bit stash exists for the render-level bf16 builds only");
+  if constexpr (S8) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");     // FP16_OVFL: 8-bit conversions clamp
+  const float dz_scale = S8 ? ldexpf(1.0f, a.dz_scale_log2) : 1.0f;
+  const float dz_unscale = S8 ? ldexpf(1.0f, -a.dz_scale_log2) : 1.0f;
   using Frag = typename M::Frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -810,6 +855,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
           for (int i = 0; i < 4; ++i)
             if (i < n) {
               float g = (w[1] >= 0 && s.ptr != nullptr) ? s.ptr[(size_t)p * s.ld + w[2] + i] : 0.0f;
+              if constexpr (S8) g *= dz_scale;
               if ((w[3] >> 9) & 1) g += d[i];
               if (w[4] == 1) {
                 const HnSrc ys = a.src[w[5]];
@@ -833,7 +879,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
           for (int i = 0; i < 4; ++i) tmp[i] = d[i];             // step q, h==0 <-> feature q
         }
-        if (a.training && w[7] >= 0 && wave_valid) hn_stash<BF16>(tmp, hn_slot_base<BF16>(a, w[7], 1, blk), 0, lane);
+        if (a.training && w[7] >= 0 && wave_valid) hn_stash<BF16, SZ>(tmp, hn_slot_base<BF16, SZ>(a, w[7], 1, blk), 0, lane);
 #pragma unroll
         for (int s = 0; s < M::STEPS32; ++s) {
           if (to2) cur2[s] = tmp[s];
@@ -865,7 +911,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
         const int K32 = w[1] & 255, K32b = (w[1] >> 8) & 255, NT = (w[1] >> 16) & 255;
         const bool has_mask = w[4] >= 0;
         const bool do_stash = a.training && w[5] >= 0 && wave_valid;
-        char* dz_base = do_stash ? hn_slot_base<BF16>(a, w[5], NT, blk) : nullptr;
+        char* dz_base = do_stash ? hn_slot_base<BF16, SZ>(a, w[5], NT, blk) : nullptr;
         unsigned nbits = 0xffffffffu;
         unsigned mbits[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // complemented words: set = keep
         if (has_mask) {
@@ -898,7 +944,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             for (int i = 0; i < 16; ++i)
               acc[i] = __int_as_float(__float_as_int(acc[i]) & hn_keep_mask(nbits, t & 1, i));
             hn_acc_to_frags(acc, nxt + t * M::STEPS32);
-            if (do_stash) hn_stash<BF16>(nxt + t * M::STEPS32, dz_base, t, lane);
+            if (do_stash) hn_stash<BF16, SZ>(nxt + t * M::STEPS32, dz_base, t, lane);
             HN_STAMP(4);
           }
         }
@@ -948,7 +994,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int slot = hn_rho(i, h);
-        if (slot < a.n_dsrc) a.dsrc[(size_t)p0 * a.n_dsrc + slot] = dacc[i];
+        if (slot < a.n_dsrc) a.dsrc[(size_t)p0 * a.n_dsrc + slot] = S8 ? dacc[i] * dz_unscale : dacc[i];
       }
     }
     // GLOEmbed backward (modules.py:155-167 under autograd): the block's 32 points belong to one ray, so the
@@ -958,7 +1004,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if (a.embed_reg_mask & (1 << i)) {
-          float v = valid ? dacc[i] : 0.0f;
+          float v = valid ? (S8 ? dacc[i] * dz_unscale : dacc[i]) : 0.0f;
 #pragma unroll
           for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
           const int col = a.embed_col[hn_rho(i, h)];
@@ -1099,6 +1145,44 @@ struct DwFrag<false> {
   }
 };
 
+// HN_MODE_BF16_S8: one ds_read_b64_tr_b8 per 16-point operand.  Per group of 16 lanes it gathers 8 rows x 16 bytes, row b =
+// the 8-byte pieces supplied by lanes 2b and 2b+1, and hands lane i column i (tools/tr_b8_probe.hip).  Lane 2b + hh of
+// group G supplies the half (fragment G & 1) of forward lane (point 16 mm + 8 (G >> 1) + b, half hh) for read mm; it
+// receives, for those 8 points, accumulator element 8 (G & 1) + (i & 7) of half i >> 3 — feature hn_dw8_feature(c) of
+// the tile, c = lane & 31: a fixed permutation, the same for both operands, undone in the epilogue's addresses.
+HN_DEV int hn_dw8_offset(int lane) {
+  const int G = lane >> 4, i = lane & 15;
+  return hn_stash8_slot(8 * (G >> 1) + (i >> 1), i & 1) * 16 + 8 * (G & 1);
+}
+HN_DEV int hn_dw8_feature(int c) { return hn_rho(8 * (c >> 4) + (c & 7), (c >> 3) & 1); }
+struct DwFrag8 {
+  long v[2];
+  template <int OFF>
+  HN_DEV void load_tr(unsigned a0, unsigned) {
+    u32x2 l0, l1;
+    asm volatile(
+        "ds_read_b64_tr_b8 %0, %2 offset:%3\n\t"
+        "ds_read_b64_tr_b8 %1, %2 offset:%4\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(l0), "=&v"(l1)
+        : "v"(a0), "n"(OFF), "n"(OFF + 512)
+        : "memory");
+    v[0] = __builtin_bit_cast(long, l0);
+    v[1] = __builtin_bit_cast(long, l1);
+  }
+  HN_DEV void load(const char*, int, int, int) {}
+  // a: dZ (e5m2), b: X (e4m3)
+  HN_DEV static void mma(f32x16& acc, const DwFrag8& a, const DwFrag8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a.v[0], b.v[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a.v[1], b.v[1], acc, 0, 0, 0);
+  }
+  HN_DEV static void mma_ones(f32x16& acc, const DwFrag8& a) {
+    const long one = 0x3838383838383838L;       // e4m3 1.0 in every byte
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a.v[0], one, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a.v[1], one, acc, 0, 0, 0);
+  }
+};
+
 HN_DEV void hn_wait_vmcnt(int n) {
   // s_waitcnt needs an immediate: wait until at most n of this wave's vector-memory ops are outstanding
   switch (n) {
@@ -1127,11 +1211,12 @@ HN_DEV void hn_wait_vmcnt(int n) {
 // rectangles.  HBM-bound by construction: every stash byte is read exactly once.
 struct HnDwBatchTable {
   HnDwBatch b[HN_MAX_WGRAD_BATCH];
+  float unscale;          // HN_MODE_BF16_S8: 2^-dz_scale_log2, applied to every sum before it is added to the gradient
   const int32_t* order;   // optional: workgroup g runs job order[g] & 0xffffff of batch order[g] >> 24
   int n;
 };
 
-template <bool BF16>
+template <bool BF16, bool S8 = false>
 __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable tab) {
   // which batch holds this workgroup's job (<= 8 scalar compares on kernel-argument data)
   int job_id = blockIdx.x, which = 0;
@@ -1152,8 +1237,10 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
     if (which == i) { jobs = tab.b[i].jobs; stash = reinterpret_cast<const char*>(tab.b[i].stash); grads = tab.b[i].grads; n_jobs = tab.b[i].n_jobs; }
   using M = ModeT<BF16>;
-  constexpr int TU = M::TILE_UNITS;
-  constexpr size_t TB = TU * 1024;
+  using Fr = std::conditional_t<S8, DwFrag8, DwFrag<BF16>>;
+  constexpr int TU = S8 ? 1 : M::TILE_UNITS;
+  constexpr int TBc = TU * 1024;
+  constexpr size_t TB = TBc;
   constexpr int STAGES = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -1251,7 +1338,8 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
 #define HN_TS(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
 #endif
   int tro0 = 0, tro1 = 0;       // bf16: this lane's transposed-read offsets inside a stash tile
-  hn_dw_tr_offsets(lane, tro0, tro1);
+  if constexpr (S8) tro0 = hn_dw8_offset(lane);
+  else hn_dw_tr_offsets(lane, tro0, tro1);
   for (int s0 = 0; s0 < STAGES - 1 && s0 < nstage; ++s0) issue(s0);
   for (int s = 0; s < nstage; ++s) {
     const int younger = min(STAGES - 2, nstage - 1 - s);     // stages issued after stage s that may stay in flight
@@ -1280,13 +1368,13 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     const int nblk_s = min(bps, nb - s * bps);
     for (int bi = 0; bi < nblk_s; ++bi) {
       const char* sb = st + (size_t)bi * UB * 1024;
-      DwFrag<BF16> xb[2];
+      Fr xb[2];
       // bf16: LDS byte addresses of this lane's transposed reads in the block's first dZ tile / first X tile of the wave
       const unsigned a_blk = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)sb;
       const unsigned ax = a_blk + (unsigned)((jb.n_nt + k0) * TB), az = a_blk + (unsigned)(n0 * TB);
       if constexpr (BF16) {
         if (0 < my_k) xb[0].template load_tr<0>(ax + tro0, ax + tro1);
-        if (1 < my_k) xb[1].template load_tr<2048>(ax + tro0, ax + tro1);
+        if (1 < my_k) xb[1].template load_tr<TBc>(ax + tro0, ax + tro1);
       } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -1295,13 +1383,13 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
       static_for4([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         if (i < my_n) {
-          DwFrag<BF16> za;
-          if constexpr (BF16) za.template load_tr<2048 * i>(az + tro0, az + tro1);
+          Fr za;
+          if constexpr (BF16) za.template load_tr<TBc * i>(az + tro0, az + tro1);
           else za.load(sb + (size_t)(n0 + i) * TB, lane, 0, 0);
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            if (j < my_k) DwFrag<BF16>::mma(acc[i][j], za, xb[j]);
-          if (bias_mask & (1u << i)) DwFrag<BF16>::mma_ones(accb[i], za);
+            if (j < my_k) Fr::mma(acc[i][j], za, xb[j]);
+          if (bias_mask & (1u << i)) Fr::mma_ones(accb[i], za);
         }
       });
     }
@@ -1327,10 +1415,10 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
           if (j < my_k)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-              const int row = jb.r0 + 32 * (n0 + i) + hn_rho(q, h);
-              const int col = jb.c0 + 32 * (k0 + j) + c;
+              const int row = jb.r0 + 32 * (n0 + i) + (S8 ? hn_dw8_feature(hn_rho(q, h)) : hn_rho(q, h));
+              const int col = jb.c0 + 32 * (k0 + j) + (S8 ? hn_dw8_feature(c) : c);
               if (row >= 0 && col >= 0 && row < jb.r_end && col < jb.c_end)
-                atomicAdd(G + (size_t)row * jb.ld + col, acc[i][j][q]);
+                atomicAdd(G + (size_t)row * jb.ld + col, S8 ? acc[i][j][q] * tab.unscale : acc[i][j][q]);
             }
   }
   if (bias_mask != 0 && c == 0) {
@@ -1340,8 +1428,8 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
       if (bias_mask & (1u << i))
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int row = jb.r0 + 32 * (n0 + i) + hn_rho(q, h);
-          if (row >= 0 && row < jb.r_end) atomicAdd(gb + row, accb[i][q]);
+          const int row = jb.r0 + 32 * (n0 + i) + (S8 ? hn_dw8_feature(hn_rho(q, h)) : hn_rho(q, h));
+          if (row >= 0 && row < jb.r_end) atomicAdd(gb + row, S8 ? accb[i][q] * tab.unscale : accb[i][q]);
         }
   }
 }
@@ -1378,6 +1466,8 @@ static void hn_allow_big_lds() {
   HN_BIG((hn_mlp_fwd_kernel<true, 3, false, true>)); HN_BIG((hn_mlp_fwd_kernel<true, 3, false, false>));
   HN_BIG((hn_mlp_fwd_kernel<true, 3, true, true>)); HN_BIG((hn_mlp_fwd_kernel<true, 3, true, false>));
   HN_BIG((hn_mlp_fwd_kernel<false, 3, true, true>)); HN_BIG((hn_mlp_fwd_kernel<false, 3, true, false>));
+  HN_BIG((hn_mlp_fwd_kernel<true, 2, false, true, true>)); HN_BIG((hn_mlp_fwd_kernel<true, 3, false, true, true>));
+  HN_BIG((hn_mlp_bwd_kernel<true, false, true>)); HN_BIG((hn_wgrad_kernel<true, true>));
 #undef HN_BIG
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)hn_mlp_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -1392,7 +1482,7 @@ extern "C" int hn_pack_units(int mode, const HnPackUnit* units, int n_units, con
   const int total = n_units + n_bias;
   if (total == 0) return 0;
   const int grid = (total + 3) / 4;
-  if (mode == HN_MODE_BF16)
+  if (mode == HN_MODE_BF16 || mode == HN_MODE_BF16_S8)
     hipLaunchKernelGGL(hn_pack_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, units, n_units, ptrs,
                        (char*)wstream, bias, n_bias, bias_out);
   else if (mode == HN_MODE_F32)
@@ -1408,7 +1498,10 @@ static int hn_check_args(const HnMlpArgs* a) {
   if (a == nullptr) return -1;
   if (a->n_points <= 0 || a->samples_per_ray <= 0 || a->n_ops <= 0 || a->n_chunks <= 0) return -2;
   if (a->ops == nullptr || a->wstream == nullptr) return -3;
-  if (a->mode != HN_MODE_BF16 && a->mode != HN_MODE_F32) return -4;
+  if (a->mode != HN_MODE_BF16 && a->mode != HN_MODE_F32 && a->mode != HN_MODE_BF16_S8) return -4;
+  // the 8-bit stash exists in the render-level training builds only (no stand-alone-module paths)
+  if (a->mode == HN_MODE_BF16_S8 && a->training && a->wide_ops != 0) return -4;
+  if (a->mode == HN_MODE_BF16_S8 && (a->dz_scale_log2 < -60 || a->dz_scale_log2 > 60)) return -5;
   if (a->n_dsrc < 0 || a->n_dsrc > HN_DSRC_COMPS) return -5;
   if (a->n_bias < 0 || a->n_feat < 0 || a->n_comps < 0 || a->n_comps > HN_MAX_COMPS) return -5;
   if (a->max_groups < 0 || a->max_groups > 3) return -5;
@@ -1422,9 +1515,9 @@ extern "C" int hn_mlp_workspace_bytes(const int32_t* ops_host, int n_ops, int ba
                                       int64_t* stash_bytes, int64_t* mask_bytes) {
   if (ops_host == nullptr || stash_bytes == nullptr || mask_bytes == nullptr) return -1;
   if (n_ops <= 0 || n_points <= 0) return -2;
-  if (mode != HN_MODE_BF16 && mode != HN_MODE_F32) return -4;
+  if (mode != HN_MODE_BF16 && mode != HN_MODE_F32 && mode != HN_MODE_BF16_S8) return -4;
   const int64_t nblk = (n_points + 31) / 32;
-  const int64_t tile = (mode == HN_MODE_BF16 ? ModeT<true>::TILE_UNITS : ModeT<false>::TILE_UNITS) * 1024;
+  const int64_t tile = (mode == HN_MODE_BF16_S8 ? 1 : mode == HN_MODE_BF16 ? ModeT<true>::TILE_UNITS : ModeT<false>::TILE_UNITS) * 1024;
   int64_t sb = 0, mb = 0;
   auto stash = [&](int off_kib, int nt) {
     if (off_kib >= 0) sb = std::max<int64_t>(sb, (int64_t)(unsigned)off_kib * 1024 + nblk * nt * tile);
@@ -1469,17 +1562,21 @@ extern "C" int hn_mlp_forward(const HnMlpArgs* a, hnStream_t stream) {
   hn_allow_big_lds();
   constexpr int WB = ModeT<true>::WAVES;
   if (a->n_trig_comps < 0 || a->n_trig_comps > a->n_comps) return -5;
-  const size_t planes = a->mode == HN_MODE_BF16
+  const bool bf = a->mode == HN_MODE_BF16 || a->mode == HN_MODE_BF16_S8;
+  const size_t planes = bf
                             ? (size_t)a->n_comps + (size_t)a->n_trig_comps + (a->trig_lo_planes ? (size_t)a->n_trig_comps : 1)
                             : (size_t)a->n_comps;
   const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + (size_t)((a->n_bias + 3) & ~3) * 4 +
-                     (size_t)((a->n_feat + 1) & ~1) * 8 + (a->mode == HN_MODE_BF16 ? (size_t)a->n_feat * 16 : 0) +
+                     (size_t)((a->n_feat + 1) & ~1) * 8 + (bf ? (size_t)a->n_feat * 16 : 0) +
                      (size_t)8 * planes * 32 * 4;
   if (lds > 158 * 1024) return -6;
   const dim3 grid_b(hn_grid_for(a->n_points, WB * 32)), blk_b(WB * 64);
   const hipStream_t st = (hipStream_t)stream;
 #define HN_FWD(G, E, T) hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, G, E, T>), grid_b, blk_b, lds, st, *a)
-  if (a->mode == HN_MODE_BF16) {
+  if (a->mode == HN_MODE_BF16_S8 && a->training) {
+    if (a->max_groups <= 2) hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 2, false, true, true>), grid_b, blk_b, lds, st, *a);
+    else hipLaunchKernelGGL((hn_mlp_fwd_kernel<true, 3, false, true, true>), grid_b, blk_b, lds, st, *a);
+  } else if (bf) {
     const bool extra = a->wide_ops != 0, train = a->training != 0;
     if (a->max_groups <= 2) {
       if (extra) { if (train) HN_FWD(2, true, true); else HN_FWD(2, true, false); }
@@ -1504,10 +1601,13 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
   hn_allow_big_lds();
   const size_t flds = (size_t)((a->n_feat + 1) & ~1) * 8;
   if (flds > 64 * 1024) return -6;
-  if (a->mode == HN_MODE_BF16) {
+  if (a->mode == HN_MODE_BF16 || a->mode == HN_MODE_BF16_S8) {
     constexpr int WB = ModeT<true>::WAVES;
     const size_t lds = 2 * HN_CHUNK_UNITS * 1024 + flds + (size_t)a->n_feat * 16 + (size_t)WB * a->n_comps * 32 * 4;
-    if (a->wide_ops & 1)
+    if (a->mode == HN_MODE_BF16_S8 && a->training)
+      hipLaunchKernelGGL((hn_mlp_bwd_kernel<true, false, true>), dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
+                         (hipStream_t)stream, *a);
+    else if (a->wide_ops & 1)
       hipLaunchKernelGGL((hn_mlp_bwd_kernel<true, true>), dim3(hn_grid_for(a->n_points, WB * 32)), dim3(WB * 64), lds,
                          (hipStream_t)stream, *a);
     else
@@ -1526,11 +1626,17 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
 static void* hn_wgrad_prof = nullptr;
 extern "C" void hn_set_wgrad_prof(void* p) { hn_wgrad_prof = p; }     // diagnostic builds only: (64, 8) int64 buffer
 #endif
-static int hn_launch_wgrad(int mode, const HnDwBatchTable& tab, int total, hnStream_t stream) {
+static int hn_launch_wgrad(int mode_word, HnDwBatchTable& tab, int total, hnStream_t stream) {
   hn_allow_big_lds();
-  // 4 stages x (<= 16 tiles) : bf16 16 x 2 KiB, fp32 8 x 4 KiB  => 128 KiB
+  // 4 stages x 32 KiB : bf16 16 tiles of 2 KiB, fp32 8 of 4 KiB, 8-bit stash 32 of 1 KiB  => 128 KiB
   const size_t lds = 4 * 32 * 1024;
-  if (mode == HN_MODE_BF16)
+  const int mode = mode_word & 255, dz_log2 = mode_word >> 8;     // HN_MODE_BF16_S8 | dz_scale_log2 << 8
+  tab.unscale = 1.0f;
+  if (mode == HN_MODE_BF16_S8) {
+    if (dz_log2 < -60 || dz_log2 > 60) return -2;
+    tab.unscale = ldexpf(1.0f, -dz_log2);
+    hipLaunchKernelGGL((hn_wgrad_kernel<true, true>), dim3(total), dim3(512), lds, (hipStream_t)stream, tab);
+  } else if (mode == HN_MODE_BF16)
     hipLaunchKernelGGL(hn_wgrad_kernel<true>, dim3(total), dim3(512), lds, (hipStream_t)stream, tab);
   else if (mode == HN_MODE_F32)
     hipLaunchKernelGGL(hn_wgrad_kernel<false>, dim3(total), dim3(512), lds, (hipStream_t)stream, tab);

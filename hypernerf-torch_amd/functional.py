@@ -19,9 +19,11 @@ _PRECISION = os.environ.get("HN_PRECISION", "bf16")
 
 
 def set_precision(p: str):
-    """'bf16' (bf16 MFMA operands, fp32 accumulate; throughput mode) or 'fp32' (fp32 MFMA; parity mode)."""
+    """'bf16' (bf16 MFMA operands, fp32 accumulate; throughput mode), 'fp32' (fp32 MFMA; parity mode) or — opt-in —
+    'bf16s8': 'bf16' with the training stash (what only the weight gradient reads) kept in 8 bits, include/hn_kernels.h
+    HN_MODE_BF16_S8: same forward, same input gradients, rounding noise in the weight gradients, half the stash bytes."""
     global _PRECISION
-    if p not in ("bf16", "fp32"):
+    if p not in ("bf16", "fp32", "bf16s8"):
         raise ValueError(p)
     _PRECISION = p
 
@@ -31,7 +33,8 @@ def get_precision() -> str:
 
 
 def mode_of(precision: Optional[str] = None) -> int:
-    return L.HN_MODE_BF16 if (precision or _PRECISION) == "bf16" else L.HN_MODE_F32
+    p = precision or _PRECISION
+    return L.HN_MODE_BF16 if p == "bf16" else L.HN_MODE_BF16_S8 if p == "bf16s8" else L.HN_MODE_F32
 
 
 # --------------------------------------------------------------------------------------------

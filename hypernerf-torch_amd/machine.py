@@ -38,9 +38,22 @@ def pow2ceil(n: int) -> int:
     return p
 
 
+def bf16_like(mode: int) -> bool:
+    """bf16 weight streams and matrix products (HN_MODE_BF16, and HN_MODE_BF16_S8 which differs in the stash only)."""
+    return mode in (L.HN_MODE_BF16, L.HN_MODE_BF16_S8)
+
+
 def mode_consts(mode: int):
     """(units per 32x32 weight block, bytes per stashed 32x32 tile)."""
+    if mode == L.HN_MODE_BF16_S8:
+        return 2, 1024
     return (2, 2048) if mode == L.HN_MODE_BF16 else (4, 4096)
+
+
+# HN_MODE_BF16_S8: the backward machine carries 2^DZ_SCALE_LOG2 * dZ so that its e5m2 stash (normal range 6.1e-5 ..
+# 57344) keeps gradients between 2^-30 and 0.87 (mean-reduced losses put them around 1e-7 .. 1e-3); the weight-gradient
+# kernel divides the sums by it again.  A power of two: exact everywhere but in the 8-bit rounding itself.
+DZ_SCALE_LOG2 = int(os.environ.get("HN_DZ_SCALE_LOG2", 16))
 
 
 # --------------------------------------------------------------------------------------------
@@ -470,7 +483,7 @@ class Program:
 
         def put(pos, w_id, ld, r0, c0, r_end, c_end, transposed):
             for u in range(u32):
-                k0 = 16 * u if mode == L.HN_MODE_BF16 else 4 * u
+                k0 = 16 * u if bf16_like(mode) else 4 * u
                 units[pos + u] = (w_id, ld, r0, c0, r_end, c_end, k0, transposed)
 
         for ly in self.layers:
@@ -498,7 +511,7 @@ class Program:
         def put(pos, ly: Layer, r0, c0, c_end):
             w_id, _b, row0, rows = ly.part_of_row(r0)
             for u in range(u32):
-                k0 = 16 * u if mode == L.HN_MODE_BF16 else 4 * u
+                k0 = 16 * u if bf16_like(mode) else 4 * u
                 units[pos + u] = (w_id, ly.in_features, r0 - row0, c0, rows, c_end, k0, 1)
 
         for step in self.bwd_plan:
@@ -526,7 +539,7 @@ class Program:
                     pos, ctr = self._take(ctr, u32)
                     f0 = ly.aux.feat_off + 64 * g + 32 * tt
                     for u in range(u32):
-                        k0 = 16 * u if mode == L.HN_MODE_BF16 else 4 * u
+                        k0 = 16 * u if bf16_like(mode) else 4 * u
                         units[pos + u] = (self.sel_w_id, len(self.feat_table), 0, f0, self.n_dsrc,
                                           len(self.feat_table), k0, 0)
         return units, ctr
@@ -650,8 +663,8 @@ class Program:
         offs, _, _ = self.layout(mode, n_points)
         goffs = list(grad_offsets) if grad_offsets is not None else self.grad_offsets()[0]
         nblk = (n_points + 31) // 32
-        tmax = 8 if mode == L.HN_MODE_BF16 else 4
-        stage_tiles = 16 if mode == L.HN_MODE_BF16 else 8         # 32 KiB per LDS stage
+        tmax = 8 if bf16_like(mode) else 4
+        stage_tiles = 32 * 1024 // mode_consts(mode)[1]           # 32 KiB per LDS stage
         rects = []
         for ly in self.layers:
             segs = []
@@ -679,7 +692,7 @@ class Program:
             bps = max(1, stage_tiles // (n_nt + n_kt))
             nstage = -(-nblk // bps)
             if job_bytes is not None:
-                tile_bytes = 2048 if mode == L.HN_MODE_BF16 else 4096
+                tile_bytes = mode_consts(mode)[1]
                 share = max(1, min(nstage, round((n_nt + n_kt) * nblk * tile_bytes / job_bytes)))
             else:
                 share = max(1, min(nstage, round(target_jobs * (n_nt + n_kt) / total_tiles)))
@@ -720,6 +733,11 @@ class Program:
 # --------------------------------------------------------------------------------------------
 class _DevTables:
     pass
+
+
+def wgrad_mode_word(mode: int) -> int:
+    """The `mode` argument of hn_mlp_wgrad*: HN_MODE_BF16_S8 carries the dZ scale in bits 8.. (include/hn_kernels.h)."""
+    return mode | (DZ_SCALE_LOG2 << 8) if mode == L.HN_MODE_BF16_S8 else mode
 
 
 WGRAD_TAIL_FRAC = float(os.environ.get("HN_WGRAD_TAIL_FRAC", 0.4))   # lightest 40 % of the jobs are halved: -1.8 % step time at config 2
@@ -771,7 +789,7 @@ def launch_pending_wgrads(pending: Sequence[PendingWgrad]):
                 ids = np.concatenate([(k << 24) | np.arange(p.n_jobs, dtype=np.int64) for k, p in enumerate(grp)])
                 order = torch.from_numpy(ids[np.argsort(-w, kind="stable")].astype(np.int32)).to(grp[0].stash.device)
                 _ORDER_CACHE[key] = order
-            L.launch("hn_mlp_wgrad_batched", C.c_int(mode), arr, C.c_int(len(grp)), L.ptr(order), L.stream_handle(),
+            L.launch("hn_mlp_wgrad_batched", C.c_int(wgrad_mode_word(mode)), arr, C.c_int(len(grp)), L.ptr(order), L.stream_handle(),
                      tag="batched")
 
 
@@ -875,6 +893,7 @@ class MlpRunner:
         wide = any(ly.out is not None and ly.out.wide for ly in self.prog.layers) or _FORCE_WIDE
         direct = any(f.kind != L.HN_FEAT_ZERO and (f.src, f.comp) not in self.prog.comp_map for f in self.prog.feat_table)
         a.wide_ops = (1 if wide else 0) | (2 if (direct or _FORCE_WIDE) else 0)
+        a.dz_scale_log2 = DZ_SCALE_LOG2 if mode == L.HN_MODE_BF16_S8 else 0
         a.n_trig_comps = min(len(self.prog.comp_map), max(1, self.prog.n_trig_comps))
         # hi + lo planes of x / 2pi for the encoded components when the forward's LDS budget allows (158 KiB: ring +
         # bias / feature tables + 8 waves x planes x 128 B), else hi alone (the one-FMA accuracy of rounds 1-2)
@@ -923,8 +942,26 @@ class MlpRunner:
             self._jobs[key] = hit
         return hit
 
+    @staticmethod
+    def _job_bytes(mode: int) -> int:
+        """WGRAD_JOB_BYTES is quoted for 2-KiB tiles; a job of the 8-bit stash covers the same point blocks (same
+        number of jobs per launch, same products and atomics per job) in half the bytes."""
+        return WGRAD_JOB_BYTES // 2 if mode == L.HN_MODE_BF16_S8 else WGRAD_JOB_BYTES
+
+    def effective_mode(self, mode: int) -> int:
+        """HN_MODE_BF16_S8 exists in the render-level kernel builds only: a program with stand-alone-module paths (wide
+        outputs, directly read identity features) runs, stash included, in plain HN_MODE_BF16."""
+        if mode == L.HN_MODE_BF16_S8:
+            wide = any(ly.out is not None and ly.out.wide for ly in self.prog.layers) or _FORCE_WIDE
+            direct = any(f.kind != L.HN_FEAT_ZERO and (f.src, f.comp) not in self.prog.comp_map
+                         for f in self.prog.feat_table)
+            if wide or direct:
+                return L.HN_MODE_BF16
+        return mode
+
     def forward(self, mode, n_points, samples_per_ray, srcs, dsts, training: bool):
         """Launch the forward machine.  Returns (stash, masks) (None, None when not training)."""
+        mode = self.effective_mode(mode)
         device = dsts[0].device if dsts and dsts[0] is not None else srcs[0][0].device
         d = self.pack(device, mode, force=training)
         stash = masks = None
@@ -949,6 +986,7 @@ class MlpRunner:
         samples_per_ray % 32 == 0).  want_dsrc=False skips the per-point source-gradient tensor altogether.
         Returns (dsrc [P, n_dsrc] or None, flat fp32 gradient buffer or None when grad_target was given)."""
         device = stash.device
+        mode = self.effective_mode(mode)
         BACKWARD_SERIAL[0] += 1
         d = self._tables(device, mode)       # the streams its forward packed
         dsrc = None
@@ -966,12 +1004,12 @@ class MlpRunner:
         jkey = (str(device), mode, n_points, goffs, deferred, split)
         if jkey not in self._jobs:
             jobs = self.prog.wgrad_jobs(mode, n_points, grad_offsets=goffs,
-                                        job_bytes=WGRAD_JOB_BYTES if deferred else None)
+                                        job_bytes=self._job_bytes(mode) if deferred else None)
             parts = [jobs]
             if split is not None:
                 # the held bucket runs as a launch of its own, next to the all-reduce of the first: it holds ~1/6 of
                 # the stash bytes, so its jobs are cut finer to still give every CU a few of them
-                fine = self.prog.wgrad_jobs(mode, n_points, grad_offsets=goffs, job_bytes=WGRAD_JOB_BYTES // HELD_JOB_DIV)
+                fine = self.prog.wgrad_jobs(mode, n_points, grad_offsets=goffs, job_bytes=self._job_bytes(mode) // HELD_JOB_DIV)
                 parts = [jobs[jobs["w_off"] >= split], fine[fine["w_off"] < split]]
             entry = []
             for part in parts:
@@ -990,7 +1028,7 @@ class MlpRunner:
         else:
             _, gtot = self.prog.grad_offsets()
             grads = ret = torch.zeros(gtot, dtype=torch.float32, device=device)
-        L.launch("hn_mlp_wgrad", C.c_int(mode), L.ptr(jobs_dev), C.c_int(n_jobs), L.ptr(stash), L.ptr(grads),
+        L.launch("hn_mlp_wgrad", C.c_int(wgrad_mode_word(mode)), L.ptr(jobs_dev), C.c_int(n_jobs), L.ptr(stash), L.ptr(grads),
                  L.stream_handle(), tag=self.prog.name)
         return dsrc, ret
 

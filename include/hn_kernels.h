@@ -29,11 +29,18 @@ extern "C" {
 
 typedef void* hnStream_t; /* hipStream_t */
 
-#define HN_VERSION 300
+#define HN_VERSION 310
 
 /* numeric modes of the MLP machine */
 #define HN_MODE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode (<=1e-4 vs oracle) */
 #define HN_MODE_BF16 1 /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate, throughput mode   */
+/* OPT-IN, not the mode the bench line is quoted on: HN_MODE_BF16 in every product of the forward and backward-data
+ * machines and in every output, but the training stash (layer inputs X, layer gradients dZ — what ONLY the weight
+ * gradient reads) is kept in 8 bits: X as OCP e4m3, dZ as OCP e5m2 of 2^dz_scale_log2 * dZ, 1 KiB per 32x32 tile
+ * instead of 2; the weight-gradient kernel multiplies them with v_mfma_f32_32x32x16_bf8_fp8 (fp32 accumulate) and
+ * undoes the scale.  Halves the stash traffic that bounds a training step; costs rounding noise in dW only
+ * (DESIGN.md section 8).  hn_mlp_wgrad* take the scale in their mode argument: HN_MODE_BF16_S8 | dz_scale_log2 << 8. */
+#define HN_MODE_BF16_S8 2
 
 #define HN_MAX_SRC 8 /* forward: feature sources 0-3 ; backward: 0-3 same, 4-7 gradient inputs */
 #define HN_MAX_DST 4
@@ -172,7 +179,8 @@ typedef struct {
                              holds HN_FEAT_ID_DIRECT entries (layers flagged HN_LAYER_DIRECT).  Forward launches take
                              the kernel build that carries those paths if either bit is set, backward launches if bit 0
                              is; 0 selects the builds without them (what every render-level program runs: no scratch) */
-  int32_t pad3;
+  int32_t dz_scale_log2;  /* HN_MODE_BF16_S8, backward: the machine carries 2^dz_scale_log2 * dZ (exact: a power of two)
+                             so that the e5m2 stash keeps small gradients; source / embedding gradients leave unscaled */
   int32_t trig_lo_planes; /* 1: the lo planes are staged (exactly reduced sine arguments); 0: hi only + one shared zero
                              plane (programs whose staging would not fit into LDS otherwise: hn_mlp_forward returns -6
                              when ring + tables + 8 waves x (n_comps + n_trig + (lo ? n_trig : 1)) x 128 B > 158 KiB) */
