@@ -386,6 +386,25 @@ HN_DEV int hn_cvt2_f8(unsigned w, int old, bool hi) {
   else return hi ? __builtin_amdgcn_cvt_pk_bf8_f32(lo_f, hi_f, old, true)
                  : __builtin_amdgcn_cvt_pk_bf8_f32(lo_f, hi_f, old, false);
 }
+// the same tile straight from the fp32 accumulator (8 conversions instead of 16 shifts / masks + 8 conversions)
+template <int S8>
+HN_DEV void hn_stash8_acc(const f32x16& a, char* slot_base, int t, int lane) {
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int w = 0;
+    if constexpr (S8 == 1) {
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(a[4 * k], a[4 * k + 1], w, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(a[4 * k + 2], a[4 * k + 3], w, true);
+    } else {
+      w = __builtin_amdgcn_cvt_pk_bf8_f32(a[4 * k], a[4 * k + 1], w, false);
+      w = __builtin_amdgcn_cvt_pk_bf8_f32(a[4 * k + 2], a[4 * k + 3], w, true);
+    }
+    o[k] = (unsigned)w;
+  }
+  char* dst8 = slot_base + (size_t)t * 1024 + hn_stash8_slot(lane & 31, lane >> 5) * 16;
+  __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst8));
+}
 template <bool BF16, int S8 = 0>
 HN_DEV void hn_stash(const typename ModeT<BF16>::Frag* fr, char* slot_base, int t, int lane) {
   using M = ModeT<BF16>;
@@ -710,7 +729,10 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
               if (do_mask) mask_base[(t >> 1) * 64 + lane] = (t & 1) ? bits : bits << 16;
               bits = 0;
             }
-            if (do_stash) hn_stash<BF16, SX>(nxt + t * M::STEPS32, out_base, t, lane);
+            if (do_stash) {
+              if constexpr (SX != 0) hn_stash8_acc<SX>(acc, out_base, t, lane);
+              else hn_stash<BF16, SX>(nxt + t * M::STEPS32, out_base, t, lane);
+            }
             HN_STAMP(4);
           }
         }
@@ -944,7 +966,10 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
             for (int i = 0; i < 16; ++i)
               acc[i] = __int_as_float(__float_as_int(acc[i]) & hn_keep_mask(nbits, t & 1, i));
             hn_acc_to_frags(acc, nxt + t * M::STEPS32);
-            if (do_stash) hn_stash<BF16, SZ>(nxt + t * M::STEPS32, dz_base, t, lane);
+            if (do_stash) {
+              if constexpr (SZ != 0) hn_stash8_acc<SZ>(acc, dz_base, t, lane);
+              else hn_stash<BF16, SZ>(nxt + t * M::STEPS32, dz_base, t, lane);
+            }
             HN_STAMP(4);
           }
         }
@@ -1114,7 +1139,7 @@ struct DwFrag<true> {
     acc = hn_mfma_bf16(a.v[0], b.v[0], acc);
     acc = hn_mfma_bf16(a.v[1], b.v[1], acc);
   }
-  HN_DEV static void mma_ones(f32x16& acc, const DwFrag& a) {
+  HN_DEV static void mma_ones(f32x16& acc, const DwFrag& a, int, int) {      // one accumulator per tile, every column
     bf16x8 one;
 #pragma unroll
     for (int j = 0; j < 8; ++j) one[j] = (__bf16)1.0f;
@@ -1137,7 +1162,7 @@ struct DwFrag<false> {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = hn_mfma_f32(a.v[g][e], b.v[g][e], acc);
   }
-  HN_DEV static void mma_ones(f32x16& acc, const DwFrag& a) {
+  HN_DEV static void mma_ones(f32x16& acc, const DwFrag& a, int, int) {     // fp32: one accumulator per tile, every column
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1176,12 +1201,46 @@ struct DwFrag8 {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a.v[0], b.v[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a.v[1], b.v[1], acc, 0, 0, 0);
   }
-  HN_DEV static void mma_ones(f32x16& acc, const DwFrag8& a) {
-    const long one = 0x3838383838383838L;       // e4m3 1.0 in every byte
+  // bias gradient of tile `col` (0..3) into COLUMN `col` of the one shared accumulator: the B operand is all ones on the
+  // lanes of that column and zero elsewhere, so four tiles' row sums live side by side in 16 registers instead of 64
+  HN_DEV static void mma_ones(f32x16& acc, const DwFrag8& a, int col, int lane) {
+    const long one = ((lane & 31) == col) ? 0x3838383838383838L : 0L;       // e4m3 1.0 in every byte of column `col`
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a.v[0], one, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a.v[1], one, acc, 0, 0, 0);
   }
 };
+
+// All operands of one 32-point block of a wave's rectangle (2 X tiles, 4 dZ tiles of 1 KiB) with ONE wait: 12 reads in
+// flight together instead of a read-wait-multiply round trip per tile (the 8-bit fragments are half the registers of
+// the bf16 ones, which is what makes room for all six).  Tiles the wave does not own are read all the same (their
+// values are never used; reads past the end of LDS return zero).
+HN_DEV void hn_tr8_block(DwFrag8* xb, DwFrag8* za, unsigned ax, unsigned az) {
+  u32x2 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11;
+  asm volatile(
+      "ds_read_b64_tr_b8 %0, %12\n\t"
+      "ds_read_b64_tr_b8 %1, %12 offset:512\n\t"
+      "ds_read_b64_tr_b8 %2, %12 offset:1024\n\t"
+      "ds_read_b64_tr_b8 %3, %12 offset:1536\n\t"
+      "ds_read_b64_tr_b8 %4, %13\n\t"
+      "ds_read_b64_tr_b8 %5, %13 offset:512\n\t"
+      "ds_read_b64_tr_b8 %6, %13 offset:1024\n\t"
+      "ds_read_b64_tr_b8 %7, %13 offset:1536\n\t"
+      "ds_read_b64_tr_b8 %8, %13 offset:2048\n\t"
+      "ds_read_b64_tr_b8 %9, %13 offset:2560\n\t"
+      "ds_read_b64_tr_b8 %10, %13 offset:3072\n\t"
+      "ds_read_b64_tr_b8 %11, %13 offset:3584\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8), "=&v"(r9),
+        "=&v"(r10), "=&v"(r11)
+      : "v"(ax), "v"(az)
+      : "memory");
+  xb[0].v[0] = __builtin_bit_cast(long, r0); xb[0].v[1] = __builtin_bit_cast(long, r1);
+  xb[1].v[0] = __builtin_bit_cast(long, r2); xb[1].v[1] = __builtin_bit_cast(long, r3);
+  za[0].v[0] = __builtin_bit_cast(long, r4); za[0].v[1] = __builtin_bit_cast(long, r5);
+  za[1].v[0] = __builtin_bit_cast(long, r6); za[1].v[1] = __builtin_bit_cast(long, r7);
+  za[2].v[0] = __builtin_bit_cast(long, r8); za[2].v[1] = __builtin_bit_cast(long, r9);
+  za[3].v[0] = __builtin_bit_cast(long, r10); za[3].v[1] = __builtin_bit_cast(long, r11);
+}
 
 HN_DEV void hn_wait_vmcnt(int n) {
   // s_waitcnt needs an immediate: wait until at most n of this wave's vector-memory ops are outstanding
@@ -1260,11 +1319,12 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   const int nstage = (nb + bps - 1) / bps;
 
   f32x16 acc[4][2];
-  f32x16 accb[4];
+  constexpr int NB = S8 ? 1 : 4;        // 8-bit stash: ONE bias accumulator, tile i in its column i (DwFrag8::mma_ones)
+  f32x16 accb[NB];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) accb[i][e] = 0.0f;
+    for (int e = 0; e < 16; ++e) accb[i % NB][e] = 0.0f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1372,6 +1432,20 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
       // bf16: LDS byte addresses of this lane's transposed reads in the block's first dZ tile / first X tile of the wave
       const unsigned a_blk = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)sb;
       const unsigned ax = a_blk + (unsigned)((jb.n_nt + k0) * TB), az = a_blk + (unsigned)(n0 * TB);
+      if constexpr (S8) {
+        DwFrag8 za8[4];
+        hn_tr8_block(xb, za8, ax + tro0, az + tro0);
+        static_for4([&](auto I) __attribute__((always_inline)) {
+          constexpr int i = decltype(I)::value;
+          if (i < my_n) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (j < my_k) DwFrag8::mma(acc[i][j], za8[i], xb[j]);
+            if (bias_mask & (1u << i)) DwFrag8::mma_ones(accb[0], za8[i], i, lane);
+          }
+        });
+        continue;
+      }
       if constexpr (BF16) {
         if (0 < my_k) xb[0].template load_tr<0>(ax + tro0, ax + tro1);
         if (1 < my_k) xb[1].template load_tr<TBc>(ax + tro0, ax + tro1);
@@ -1389,7 +1463,7 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             if (j < my_k) Fr::mma(acc[i][j], za, xb[j]);
-          if (bias_mask & (1u << i)) Fr::mma_ones(accb[i], za);
+          if (bias_mask & (1u << i)) Fr::mma_ones(accb[i % NB], za, i, lane);
         }
       });
     }
@@ -1421,15 +1495,15 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
                 atomicAdd(G + (size_t)row * jb.ld + col, S8 ? acc[i][j][q] * tab.unscale : acc[i][j][q]);
             }
   }
-  if (bias_mask != 0 && c == 0) {
+  if (bias_mask != 0 && c < 4) {
     float* gb = grads + jb.b_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (bias_mask & (1u << i))
+      if ((bias_mask & (1u << i)) && c == (S8 ? i : 0))
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int row = jb.r0 + 32 * (n0 + i) + (S8 ? hn_dw8_feature(hn_rho(q, h)) : hn_rho(q, h));
-          if (row >= 0 && row < jb.r_end) atomicAdd(gb + row, S8 ? accb[i][q] * tab.unscale : accb[i][q]);
+          if (row >= 0 && row < jb.r_end) atomicAdd(gb + row, S8 ? accb[i % NB][q] * tab.unscale : accb[i % NB][q]);
         }
   }
 }

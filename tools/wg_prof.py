@@ -7,7 +7,7 @@ import hypernerf_torch_amd as HN
 from hypernerf_torch_amd import _lib as L
 from hypernerf_torch_amd.hypernerf.models import NerfModel
 from gpu_common import EMB, rays_for
-HN.set_precision("bf16")
+HN.set_precision(os.environ.get("HN_PRECISION", "bf16"))
 m = NerfModel(EMB, n_samples_coarse=64, n_samples_fine=64, noise_std=1.0, hyper_slice_method="bendy_sheet", use_nerf_embed=True, use_alpha_cond=True, view_fourier_dim=6).cuda()
 arena = HN.ParamArena(m.parameters())
 o, d, idx = rays_for(1, 1024)
