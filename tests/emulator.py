@@ -185,6 +185,39 @@ def ds_read_b64_tr_b16(img, addr):
     return out
 
 
+# ---- HN_MODE_BF16_S8: 1-KiB tiles of 8-bit elements (csrc/hn_mlp.hip: hn_stash8_slot, hn_dw8_offset, hn_dw8_feature) ----
+def stash8_slot(r, h):
+    return (r & 3) + 4 * h + 8 * ((r >> 2) & 1) + 16 * (r >> 3)
+
+
+def dw8_offset(lane):
+    G, i = lane >> 4, lane & 15
+    return stash8_slot(8 * (G >> 1) + (i >> 1), i & 1) * 16 + 8 * (G & 1)
+
+
+def dw8_feature(c):
+    return rho(8 * (c >> 4) + (c & 7), (c >> 3) & 1)
+
+
+def ds_read_b64_tr_b8(img, addr):
+    """gfx950 semantics as measured by tools/tr_b8_probe.hip: per group of 16 lanes, 8 rows x 16 bytes, row b = the 8 bytes
+    at the address of lane 2b followed by the 8 bytes at the address of lane 2b+1; lane i receives column i (byte b of
+    its result = row b).  img: one entry per byte.  Same bank rule as the 16-bit form: the 32 lanes of a half must touch
+    64 distinct banks."""
+    out = np.zeros((64, 8))
+    for half in range(2):
+        banks = set()
+        for l in range(32 * half, 32 * half + 32):
+            assert addr[l] % 8 == 0
+            banks.update({(addr[l] // 4) % 64, (addr[l] // 4 + 1) % 64})
+        assert len(banks) == 64, "transposed 8-bit stash read is not bank-conflict free"
+    for G in range(4):
+        for i in range(16):
+            for b in range(8):
+                out[16 * G + i, b] = img[addr[16 * G + 2 * b + (i >> 3)] + (i & 7)]
+    return out
+
+
 def store_tile(mode, z):
     """-> (TILE_UNITS, 64, elems) as written to the stash."""
     if mode.bf16:

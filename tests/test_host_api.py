@@ -12,6 +12,7 @@ import torch
 
 import hypernerf_torch_amd as HN
 from hypernerf_torch_amd import _lib as L
+from hypernerf_torch_amd import machine
 from hypernerf_torch_amd.hypernerf import model_utils, models, modules, warping
 from hypernerf_torch_amd.models import nerf as legacy_nerf
 from hypernerf_torch_amd.models import rendering as legacy_rendering
@@ -63,7 +64,7 @@ def test_workspace_query_matches_the_host_compiler():
     progs = [m._level_call("fine").program, warping.SE3Field(in_ch=3)._field_call(True).program,
              legacy_nerf.NeRF().fused_call(legacy_nerf.Embedding(3, 10), legacy_nerf.Embedding(3, 4), False).program]
     for prog in progs:
-        for mode in (L.HN_MODE_BF16, L.HN_MODE_F32):
+        for mode in (L.HN_MODE_BF16, L.HN_MODE_F32, L.HN_MODE_BF16_S8):
             for n in (1, 32, 1000, 196608):
                 fwd, bwd = prog.resolved_ops(mode, n)
                 _, sb, mb = prog.layout(mode, n)
@@ -77,6 +78,19 @@ def test_workspace_query_matches_the_host_compiler():
                     assert 0 <= s_out.value <= sb and 0 <= m_out.value <= mb
                     got.append((s_out.value, m_out.value))
                 assert max(g[0] for g in got) == sb and max(g[1] for g in got) == mb, (prog.name, mode, n, got, sb, mb)
+        # the opt-in 8-bit stash: half the stash of the bf16 mode, the same masks, the same weight-gradient job grid
+        # (same rectangles over the same point blocks; half the bytes per job)
+        _, sb16, mb16 = prog.layout(L.HN_MODE_BF16, 196608)
+        _, sb8, mb8 = prog.layout(L.HN_MODE_BF16_S8, 196608)
+        assert sb8 * 2 == sb16 and mb8 == mb16
+        j16 = prog.wgrad_jobs(L.HN_MODE_BF16, 196608, job_bytes=machine.WGRAD_JOB_BYTES)
+        j8 = prog.wgrad_jobs(L.HN_MODE_BF16_S8, 196608, job_bytes=machine.WGRAD_JOB_BYTES // 2)
+        cover = lambda j: sorted(zip(j["w_off"].tolist(), j["r0"].tolist(), j["c0"].tolist(), j["n_nt"].tolist(), j["n_kt"].tolist()))
+        assert len(j8) > 0 and set(cover(j8)) == set(cover(j16))
+        assert int(((j8["n_nt"] + j8["n_kt"]).astype(np.int64) * (j8["blk1"] - j8["blk0"])).sum()) == \
+            int(((j16["n_nt"] + j16["n_kt"]).astype(np.int64) * (j16["blk1"] - j16["blk0"])).sum())
+    assert machine.wgrad_mode_word(L.HN_MODE_BF16) == 1 and machine.wgrad_mode_word(L.HN_MODE_F32) == 0
+    assert machine.wgrad_mode_word(L.HN_MODE_BF16_S8) == 2 | machine.DZ_SCALE_LOG2 << 8
     bad = np.zeros((1, 8), dtype=np.int32); bad[0, 0] = 99
     s_out, m_out = ctypes.c_int64(), ctypes.c_int64()
     assert lib.hn_mlp_workspace_bytes(bad.ctypes.data_as(ctypes.c_void_p), 1, 0, L.HN_MODE_BF16, ctypes.c_int64(32),

@@ -447,3 +447,30 @@ def test_exact_argument_reduction_of_the_bf16_encoders():
         worst_new, worst_old = max(worst_new, err_new.max()), max(worst_old, err_old.max())
         assert err_new.max() < 1.3e-7, (k, err_new.max())
     assert worst_old > 3e-6 and worst_old / worst_new > 25, (worst_old, worst_new)
+
+
+def test_eight_bit_stash_layout_and_transposed_read():
+    """HN_MODE_BF16_S8 (opt-in): a 32 x 32 tile is one 1-KiB unit; forward lane (point r, half h) stores its 16
+    accumulator elements (features rho(i, h)) as 16 bytes at slot hn_stash8_slot(r, h).  The weight-gradient kernel's two
+    ds_read_b64_tr_b8 per tile (offsets hn_dw8_offset, +512 for points 16..31) must hand lane (c, kg) — c = lane & 31,
+    kg = lane >> 5 — the 8 consecutive points 16 mm + 8 kg .. + 7 of ONE feature, hn_dw8_feature(c), i.e. a valid MFMA
+    operand up to a fixed feature permutation; that permutation is a bijection of the tile's 32 features (the epilogue
+    undoes it in its addresses), and the reads are bank-conflict free (asserted inside the emulated instruction)."""
+    assert sorted(E.stash8_slot(r, h) for r in range(32) for h in range(2)) == list(range(64))
+    assert sorted(E.dw8_feature(c) for c in range(32)) == list(range(32))
+    # tile[p][f] = a code of (point, feature) that fits 8 bits is not possible (1024 values): check in two passes
+    for part in ("point", "feature"):
+        img = np.zeros(1024)
+        for r in range(32):
+            for h in range(2):
+                for i in range(16):
+                    img[E.stash8_slot(r, h) * 16 + i] = r if part == "point" else E.rho(i, h)
+        off = np.array([E.dw8_offset(l) for l in range(64)])
+        for mm in range(2):
+            got = E.ds_read_b64_tr_b8(img, off + 512 * mm)
+            for lane in range(64):
+                c, kg = lane & 31, lane >> 5
+                if part == "point":
+                    assert got[lane].tolist() == [16 * mm + 8 * kg + b for b in range(8)], (mm, lane, got[lane])
+                else:
+                    assert set(got[lane].tolist()) == {E.dw8_feature(c)}, (mm, lane, got[lane])
