@@ -24,7 +24,10 @@ for line in res.stderr.splitlines():
             cur[key] = int(m2.group(1))
 for name in ("_Z17hn_mlp_fwd_kernelILb1ELi2ELb0ELb1ELb0EEv9HnMlpArgs", "_Z17hn_mlp_fwd_kernelILb1ELi2ELb0ELb0ELb0EEv9HnMlpArgs",
              "_Z17hn_mlp_fwd_kernelILb1ELi2ELb1ELb1ELb0EEv9HnMlpArgs", "_Z17hn_mlp_bwd_kernelILb1ELb0ELb0EEv9HnMlpArgs", "_Z17hn_mlp_bwd_kernelILb1ELb1ELb0EEv9HnMlpArgs",
-             "_Z15hn_wgrad_kernelILb1ELb0EEv14HnDwBatchTable"):
+             "_Z15hn_wgrad_kernelILb1ELb0EEv14HnDwBatchTable",
+             # the opt-in 8-bit-stash builds
+             "_Z17hn_mlp_fwd_kernelILb1ELi2ELb0ELb1ELb1EEv9HnMlpArgs", "_Z17hn_mlp_bwd_kernelILb1ELb0ELb1EEv9HnMlpArgs",
+             "_Z15hn_wgrad_kernelILb1ELb1EEv14HnDwBatchTable"):
     start = next(i for i, l in enumerate(asm) if l.startswith(name + ":"))
     end = next(i for i in range(start, len(asm)) if "s_endpgm" in asm[i])
     blocks, blk = [], ["entry", 0, 0, 0]
