@@ -634,17 +634,18 @@ def _fwd_bwd_in(precision, seed=83, b=64, nc=16, nf=16):
     return {k: out["fine"][k].detach().clone() for k in ("rgb", "depth", "weights")}, arena.grad.clone(), grads
 
 
-def test_eight_bit_stash_changes_nothing_but_the_weight_gradients():
+@pytest.mark.parametrize("b,nc,nf", [(64, 16, 16), (50, 24, 20)])       # the second: ragged last block and last tile
+def test_eight_bit_stash_changes_nothing_but_the_weight_gradients(b, nc, nf):
     """precision 'bf16s8' (HN_MODE_BF16_S8, include/hn_kernels.h — OPT-IN, never what bench.py's headline runs): the
     training stash, which only the weight-gradient kernel reads, is kept as e4m3 (layer inputs) / e5m2 (2^16-scaled
     layer gradients).  The forward machine and the backward-data machine compute what they compute in 'bf16' mode:
     outputs bit-identical, embedding gradients (reduced inside the backward machine: they carry the power-of-two scale
     and lose it again, exactly) equal up to the order of their float atomics.  The weight gradients carry the 8-bit
-    rounding of every (point, feature) term as zero-mean noise: finite, within 15 % relative L2 of the bf16 mode's
+    rounding of every (point, feature) term as (nearly) zero-mean noise: finite, within 15 % relative L2 of the bf16 mode's
     over the whole buffer at 64 rays (measured 7.6 %; 3.9 % at 1024 rays x 128 samples — tools/s8_check.py), and not
     identical (the mode must actually be in effect)."""
-    out16, g16, by16 = _fwd_bwd_in("bf16")
-    out8, g8, by8 = _fwd_bwd_in("bf16s8")
+    out16, g16, by16 = _fwd_bwd_in("bf16", b=b, nc=nc, nf=nf)
+    out8, g8, by8 = _fwd_bwd_in("bf16s8", b=b, nc=nc, nf=nf)
     for k in out16:
         assert torch.equal(out16[k], out8[k]), k
     assert bool(torch.isfinite(g8).all())
@@ -658,8 +659,9 @@ def test_eight_bit_stash_changes_nothing_but_the_weight_gradients():
     b_ = torch.cat([by8[n].flatten() for n in mlp])
     rel = float((b_ - a).norm() / a.norm())
     assert 1e-4 < rel < 0.15, rel
-    # no bias: the signed error, summed over every weight, is small against the sum of its magnitudes
-    assert abs(float((b_ - a).sum())) < 0.02 * float((b_ - a).abs().sum())
+    # no bias to speak of: the error's component ALONG the gradient — what would act like a change of the learning
+    # rate — stays within a few per cent of it (measured -2.7 % / -0.5 % here, -0.4 % at 1024 rays x 128 samples)
+    assert abs(float(((b_ - a) * a).sum() / (a * a).sum())) < 0.06
 
 
 def test_eight_bit_stash_trains_and_stand_alone_modules_fall_back():

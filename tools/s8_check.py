@@ -40,6 +40,9 @@ print("loss", a[3], b[3], "rgb max diff", float((a[0] - b[0]).abs().max()))
 g0, g1 = a[1], b[1]
 print("finite", bool(torch.isfinite(g1).all()), "rel L2 of the gradient buffer", float((g1 - g0).norm() / g0.norm()),
       "max abs", float((g1 - g0).abs().max()), "scale", float(g0.abs().max()))
+e = g1 - g0
+print("projection of the error on the gradient  <e, g> / <g, g> =", float((e * g0).sum() / (g0 * g0).sum()),
+      "  signed / absolute error sum", float(e.sum() / e.abs().sum()))
 worst = sorted(((float((b[2][n] - a[2][n]).norm() / (a[2][n].norm() + 1e-30)), n) for n in a[2]), reverse=True)
 for r, n in worst[:12]:
     print(f"  {r:.4f}  {n}  |g| {float(a[2][n].norm()):.3e}")
