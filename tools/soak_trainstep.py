@@ -20,7 +20,7 @@ import psnr_parity                                                # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 dev = "cuda:0"
-HN.set_precision("bf16")
+HN.set_precision(os.environ.get("HN_PRECISION", "bf16"))      # HN_PRECISION=bf16s8: soak the opt-in 8-bit-stash mode
 torch.manual_seed(0)
 m = NerfModel(EMB, near=0.2, far=2.0, n_samples_coarse=64, n_samples_fine=64, noise_std=1.0,
               hyper_slice_method="bendy_sheet", use_warp=True, use_nerf_embed=True, use_alpha_cond=True,
