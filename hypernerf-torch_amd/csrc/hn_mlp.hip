@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   constexpr int TU = S8 ? 1 : M::TILE_UNITS;
   constexpr int TBc = TU * 1024;
   constexpr size_t TB = TBc;
-  constexpr int STAGES = 4;
+  constexpr int STAGES = S8 ? 3 : 4;      // 8-bit stash: 3 x 48 KiB (a third fewer stage barriers), else 4 x 32 KiB
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1703,12 +1703,13 @@ extern "C" void hn_set_wgrad_prof(void* p) { hn_wgrad_prof = p; }     // diagnos
 static int hn_launch_wgrad(int mode_word, HnDwBatchTable& tab, int total, hnStream_t stream) {
   hn_allow_big_lds();
   // 4 stages x 32 KiB : bf16 16 tiles of 2 KiB, fp32 8 of 4 KiB, 8-bit stash 32 of 1 KiB  => 128 KiB
-  const size_t lds = 4 * 32 * 1024;
+  size_t lds = 4 * 32 * 1024;
   const int mode = mode_word & 255, dz_log2 = mode_word >> 8;     // HN_MODE_BF16_S8 | dz_scale_log2 << 8
   tab.unscale = 1.0f;
   if (mode == HN_MODE_BF16_S8) {
     if (dz_log2 < -60 || dz_log2 > 60) return -2;
     tab.unscale = ldexpf(1.0f, -dz_log2);
+    lds = 3 * 48 * 1024;
     hipLaunchKernelGGL((hn_wgrad_kernel<true, true>), dim3(total), dim3(512), lds, (hipStream_t)stream, tab);
   } else if (mode == HN_MODE_BF16)
     hipLaunchKernelGGL(hn_wgrad_kernel<true>, dim3(total), dim3(512), lds, (hipStream_t)stream, tab);

@@ -664,7 +664,8 @@ class Program:
         goffs = list(grad_offsets) if grad_offsets is not None else self.grad_offsets()[0]
         nblk = (n_points + 31) // 32
         tmax = 8 if bf16_like(mode) else 4
-        stage_tiles = 32 * 1024 // mode_consts(mode)[1]           # 32 KiB per LDS stage
+        # tiles per LDS stage of hn_wgrad_kernel: 32 KiB (4-stage ring), 8-bit stash 48 KiB (3-stage ring)
+        stage_tiles = 48 if mode == L.HN_MODE_BF16_S8 else 32 * 1024 // mode_consts(mode)[1]
         rects = []
         for ly in self.layers:
             segs = []
