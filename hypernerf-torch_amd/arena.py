@@ -100,10 +100,11 @@ class ParamArena:
     def zero_grad(self):
         self.grad.zero_()
 
-    def all_reduce_sum(self, group=None):
+    def all_reduce_sum(self, group=None, force: bool = False):
         """SUM the gradient buffer across ranks: one all-reduce, in place.  The 1/world of the mean is applied by the
-        consumer (ArenaAdam's grad_scale: no separate division launch)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        consumer (ArenaAdam's grad_scale: no separate division launch).  `force`: issue the collective even in a
+        one-rank group (RCCL runs it as a copy) — what lets a one-GPU box exercise the captured all-reduce."""
+        if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
     def all_reduce_mean(self, group=None):

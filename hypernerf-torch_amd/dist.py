@@ -138,13 +138,14 @@ class GradSync:
         finally:
             machine.WGRAD_SPLIT_OFFSET = old
 
-    def reduce(self, run_held=None):
+    def reduce(self, run_held=None, force: bool = False):
         """Call after forward+backward.  `run_held` launches the held weight-gradient jobs (eagerly or as a graph
-        replay); it is called even when there is nothing to overlap with, so the gradients are always complete."""
+        replay); it is called even when there is nothing to overlap with, so the gradients are always complete.
+        `force`: issue the all-reduce in a one-rank group too (ParamArena.all_reduce_sum)."""
         if self.split is None:
             if run_held is not None:
                 run_held()
-            self.arena.all_reduce_sum(self.group)
+            self.arena.all_reduce_sum(self.group, force=force)
             return
         if run_held is None:
             from . import functional
@@ -158,3 +159,12 @@ class GradSync:
         h1 = dist.all_reduce(g[:self.split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         h0.wait()
         h1.wait()
+
+
+def collective_capturable(group=None) -> bool:
+    """True when a collective on `group` can be recorded into a HIP graph: RCCL ("nccl") enqueues a kernel on the
+    current stream, which torch captures like any other launch; gloo stages through host memory (a device-to-host copy
+    and a host wait: illegal inside a capture)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return str(dist.get_backend(group)).lower() == "nccl"

@@ -219,7 +219,12 @@ class _ProgramFn(torch.autograd.Function):
                     g = dsrc.index_select(1, idx[0])      # one gather instead of a copy kernel per column
                     if idx[1] is not None:
                         g = g * idx[1]
-            src_grads.append(g.view(shp) if g.is_contiguous() else g)
+            # always the source's own shape (autograd checks it): splitting dim 0 of the row-strided view `narrow`
+            # returns is a legal view; anything view() cannot express is copied
+            try:
+                src_grads.append(g.view(shp))
+            except RuntimeError:
+                src_grads.append(g.reshape(shp))
         if flat is None:
             return (None, None, None, None, None, None, *src_grads, *([None] * len(prog.params)))
         pgrads = call.runner.split_grads(flat)
@@ -739,9 +744,12 @@ def se3_apply(w: torch.Tensor, v: torch.Tensor, points: torch.Tensor) -> torch.T
 class _Se3WarpFn(torch.autograd.Function):
     """SE3Field's tail in one launch each way: wv (P, 6) = [w | v] straight from the field program (read with row
     stride 6, no slicing copies), points (P, 3) -> xyz (P, 3) and, optionally, `warped` (P, 3 + H) = [xyz | table row
-    of the ray] (axis-aligned-plane levels; not differentiable: the template reads the hyper coordinates from the
-    gathered table itself).  The gradient arrives as columns of the template's source-gradient tensor (any row
-    stride) and leaves as one (P, 6) tensor."""
+    of the ray] (axis-aligned-plane levels).  The template reads the hyper coordinates from the gathered table itself,
+    so in a training step no gradient arrives through `warped`; a loss the CALLER puts on results['warped_points']
+    (differentiable w.r.t. both parts in the reference: models.py:578-581) does — its xyz columns join the gradient
+    of `xyz`, its hyper columns are summed over the ray's samples into the table rows (rare path, torch ops).  The
+    gradient of `xyz` arrives as columns of the template's source-gradient tensor (any row stride) and leaves as
+    one (P, 6) tensor."""
 
     @staticmethod
     def forward(ctx, wv, points, table, idx, samples_per_ray):
@@ -771,18 +779,28 @@ class _Se3WarpFn(torch.autograd.Function):
                  C.c_int(tab.shape[0] if tab is not None else 0), C.c_int(int(samples_per_ray)), L.stream_handle())
         ctx.saved = (wv_c, p_c)
         ctx.pshape = points.shape
+        ctx.rows = None if table is None else (gidx, tuple(table.shape), int(samples_per_ray))
         ctx.set_materialize_grads(False)
         if warped is None:
             return xyz
-        ctx.mark_non_differentiable(warped)
         return xyz, warped
 
     @staticmethod
-    def backward(ctx, g, *unused):
+    def backward(ctx, g, g_warped=None):
         L.load()
         wv_c, p_c = ctx.saved
+        d_table = None
+        if g_warped is not None:        # a loss on warped_points itself
+            gw = g_warped.reshape(p_c.shape[0], -1)
+            g = gw[:, :3] if g is None else g.reshape(-1, 3) + gw[:, :3]
+            if ctx.needs_input_grad[2]:
+                gidx, tshape, spr = ctx.rows
+                d_table = torch.zeros(tshape, dtype=torch.float32, device=p_c.device)
+                ok = (gidx >= 0) & (gidx < tshape[0])
+                d_table.index_add_(0, gidx.clamp(0, tshape[0] - 1),
+                                   gw[:, 3:].reshape(gidx.numel(), spr, -1).sum(1) * ok.unsqueeze(1))
         if g is None:
-            return None, None, None, None, None
+            return None, None, d_table, None, None
         if g.dim() != 2 or g.stride(1) != 1:
             g = g.reshape(-1, 3).contiguous()
         n = p_c.shape[0]
@@ -793,7 +811,7 @@ class _Se3WarpFn(torch.autograd.Function):
                  C.c_void_p(wv_c.data_ptr() + 12), C.c_int(wv_c.stride(0)), L.ptr(p_c), C.c_int(p_c.stride(0)),
                  L.ptr(g), C.c_int(g.stride(0)), C.c_int(n), C.c_void_p(d_wv.data_ptr()), C.c_int(6),
                  C.c_void_p(d_wv.data_ptr() + 12), C.c_int(6), L.ptr(d_p), L.stream_handle())
-        return d_wv, (d_p.view(ctx.pshape) if d_p is not None else None), None, None, None
+        return d_wv, (d_p.view(ctx.pshape) if d_p is not None else None), d_table, None, None
 
 
 def se3_warp(wv: torch.Tensor, points: torch.Tensor, table: Optional[torch.Tensor] = None,

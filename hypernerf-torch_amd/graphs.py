@@ -31,8 +31,17 @@ class GraphedStep:
             torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, pool=pool):
-            self.out = fn()
+        try:
+            with torch.cuda.graph(self.graph, pool=pool):
+                self.out = fn()
+        except BaseException:
+            # an operation that cannot be captured (a host-staged collective, a synchronising copy) invalidates the
+            # capture; torch has ended it on the way out — leave the device idle for whoever falls back to eager work
+            try:
+                torch.cuda.synchronize()
+            except RuntimeError:
+                pass
+            raise
 
     def __call__(self):
         self.graph.replay()

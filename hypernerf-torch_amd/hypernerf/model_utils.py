@@ -81,14 +81,32 @@ def sample_pdf(bins, weights, origins, directions, z_vals, num_coarse_samples, u
     return z_all, pts
 
 
+_BANDS = {}
+
+
+def _bands(key, device):
+    """Frequency bands of the two encoders, computed ONCE per (arguments, device) with the reference's ATen ops on the
+    CPU (the values the CPU reference — and the golden fixtures — use, bit for bit) and kept on the device: no
+    pageable host-to-device copy (a sync point, and an error inside HIP-graph capture) per call."""
+    k = (key, str(device))
+    t = _BANDS.get(k)
+    if t is None:
+        if key[0] == "orig":
+            n = key[1]
+            t = 2 ** torch.linspace(0, n - 1, n) if key[2] else torch.linspace(0, n - 1, n)
+        else:
+            t = 2. ** torch.linspace(key[1], key[2], steps=key[2] - key[1])
+        t = _BANDS[k] = t.to(device)
+    return t
+
+
 def posenc_orig(x, N_freqs, log_scale=True):
     """[x, sin(2^0 x), cos(2^0 x), ..., sin(2^(N-1) x), cos(2^(N-1) x)] in blocks of C channels — the
     "SinusoidalEncoder" (reference: hypernerf/model_utils.py:234-246).  `log_scale=False` takes the reference's
     linspace(0, N-1, N) bands (frequency 0 included).  One HIP launch (hn_posenc), differentiable w.r.t. x."""
     L.require_gpu(x)
     n = int(N_freqs)
-    bands = 2 ** torch.linspace(0, n - 1, n) if log_scale else torch.linspace(0, n - 1, n)      # the reference's ATen ops
-    return F.posenc(x, bands.to(x.device), identity=True, jax_cos=False)
+    return F.posenc(x, _bands(("orig", n, bool(log_scale)), x.device), identity=True, jax_cos=False)
 
 
 def posenc(x, min_deg, max_deg, use_identity=False, alpha=None):
@@ -96,8 +114,7 @@ def posenc(x, min_deg, max_deg, use_identity=False, alpha=None):
     2**linspace(min_deg, max_deg, steps=max_deg-min_deg) (non-integer exponents), cos as sin(x + 0.5*3.1415926),
     layout (*, F, 2, C) flattened; `alpha` windowing is disabled upstream (:264-266) and ignored here too."""
     L.require_gpu(x)
-    scales = 2. ** torch.linspace(min_deg, max_deg, steps=max_deg - min_deg)
-    return F.posenc(x, scales.to(x.device), identity=bool(use_identity), jax_cos=True)
+    return F.posenc(x, _bands(("jax", int(min_deg), int(max_deg)), x.device), identity=bool(use_identity), jax_cos=True)
 
 
 def _depth_index(weights, z_vals, depth_threshold, want_index, want_depth, want_mask):
@@ -130,7 +147,12 @@ def compute_depth_index(weights, depth_threshold=0.5):
 
 def compute_depth_map(weights, z_vals, depth_threshold=0.5):
     """Depth by median accumulation = z at compute_depth_index, 0 where the threshold is never reached
-    (reference: model_utils.py:347-362)."""
+    (reference: model_utils.py:347-362).  The reference's sum(mask * z_vals) is differentiable w.r.t. z_vals (never
+    w.r.t. the weights: the mask is a comparison); when z_vals asks for a gradient the same product is taken in torch
+    on the kernel's mask, otherwise the kernel returns the depth itself."""
+    if z_vals is not None and z_vals.requires_grad and torch.is_grad_enabled():
+        mask = _depth_index(weights, None, depth_threshold, False, False, True)[2]
+        return torch.sum(mask * z_vals, dim=-1)
     return _depth_index(weights, z_vals, depth_threshold, False, True, False)[1]
 
 

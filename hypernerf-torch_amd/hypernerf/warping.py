@@ -170,7 +170,8 @@ class SE3Field(nn.Module):
     def warp_with_rows(self, points: torch.Tensor, table: torch.Tensor, idx: torch.Tensor):
         """points (B, S, 3) -> (xyz (B, S, 3), warped (B, S, 3 + H)) with warped = [xyz | table[idx[ray]]]: the
         `warped_points` of an axis-aligned-plane level (models.py:533-534, 578-581) written by the exp-map launch
-        itself.  Gradients flow through xyz only."""
+        itself.  Both outputs are differentiable (a loss on `warped` reaches the field through its xyz columns and the
+        table through its row columns, as the reference's cat([xyz, rows]) does)."""
         b, s = points.shape[0], points.shape[1]
         flat = points.reshape(-1, self.in_ch_pts)
         pg = bool(points.requires_grad and torch.is_grad_enabled())

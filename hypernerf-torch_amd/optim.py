@@ -143,10 +143,24 @@ class _EpochScheduler:
         return [self.lr]
 
     def state_dict(self):
-        return {k: v for k, v in self.__dict__.items() if k not in ("optimizer", "after")}
+        """Everything needed to resume mid-schedule: the scheduler's own fields, the learning rate the optimizer holds
+        right now (the chainable forms compute the next rate FROM it) and — GradualWarmup — the wrapped scheduler's
+        state (the reference's _LRScheduler.state_dict keeps `after_scheduler` inside its __dict__ the same way)."""
+        sd = {k: v for k, v in self.__dict__.items() if k not in ("optimizer", "after")}
+        sd["lr"] = self.lr
+        after = getattr(self, "after", None)
+        if after is not None:
+            sd["after"] = after.state_dict()
+        return sd
 
     def load_state_dict(self, sd):
+        sd = dict(sd)
+        lr, after = sd.pop("lr", None), sd.pop("after", None)
         self.__dict__.update(sd)
+        if after is not None and getattr(self, "after", None) is not None:
+            self.after.load_state_dict(after)
+        if lr is not None:
+            self._set(lr)           # the optimizer holds the restored rate, not the one it was constructed with
 
 
 class StepLR(_EpochScheduler):

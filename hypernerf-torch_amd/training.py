@@ -24,7 +24,7 @@ import torch.distributed as dist
 from . import functional as F
 from . import machine
 from .arena import ParamArena
-from .dist import GradSync
+from .dist import GradSync, collective_capturable
 from .graphs import GraphedStep
 from .hypernerf import model_utils
 from .losses import MSELoss, psnr
@@ -37,7 +37,7 @@ class TrainStep:
     def __init__(self, model: torch.nn.Module, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, use_graph: bool = True, group=None, chunk: int = 32 * 1024,
                  decay_step: Optional[Sequence[int]] = None, decay_gamma: float = 0.1, overlap_grad_sync: bool = False,
-                 hparams=None):
+                 hparams=None, force_dp: bool = False, capture_collective: bool = True):
         self.model = model
         self.arena = ParamArena(model.parameters())
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -45,7 +45,12 @@ class TrainStep:
         self.use_graph = use_graph
         self.chunk = int(chunk)          # rays per model call (train.py:108-111); the default exceeds any batch size
         self.sync: Optional[GradSync] = None
-        if self.world > 1:
+        # force_dp: take the data-parallel code path (broadcast, gradient all-reduce, Adam behind it) in a ONE-rank
+        # group too — a one-GPU box can then run the captured RCCL all-reduce (tests, bench.py --force-dp)
+        self.dp = self.world > 1 or (bool(force_dp) and dist.is_available() and dist.is_initialized())
+        self.capture_collective = bool(capture_collective)
+        self.dp_graph = None             # how the N>1 step runs: "one graph" | "three pieces (<why>)"
+        if self.dp:
             # replicas must start identical (Lightning DDP broadcasts module state from rank 0 at wrap time)
             dist.broadcast(self.arena.data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             self.arena.bump()
@@ -102,6 +107,16 @@ class TrainStep:
         self._forward_backward()
         self.optimizer.step()
 
+    def _whole_dp(self):
+        """forward + backward | ONE in-place SUM all-reduce of the gradient buffer | Adam, as one capturable program
+        (RCCL's kernel is enqueued on the capturing stream like any launch): one graph replay per step, no host in
+        the loop between backward and the optimizer (reference: Lightning DDP's reduce inside backward,
+        train.py:224-229)."""
+        self._forward_backward()
+        F.flush_held_wgrads()
+        self.arena.all_reduce_sum(self.group, force=True)
+        self.optimizer.step()
+
     def _snapshot(self):
         o = self.optimizer
         return [t.clone() for t in (self.arena.data, self.arena.grad, o.exp_avg, o.exp_avg_sq, o.step_count)]
@@ -117,8 +132,10 @@ class TrainStep:
         """Warm-up runs + capture execute `fn` for real; parameters, gradient buffer and optimizer state are put back
         afterwards so that the first step() applies exactly ONE update (and, with N>1, all-reduces ONE gradient)."""
         snap = self._snapshot()
-        g = GraphedStep(fn, warmup=2)
-        self._restore(snap)
+        try:
+            g = GraphedStep(fn, warmup=2)
+        finally:
+            self._restore(snap)
         return g
 
     def _capture_data_parallel(self):
@@ -133,6 +150,27 @@ class TrainStep:
               if F.held_wgrads() else None)
         self._restore(snap)
         return g1, g2
+
+    def _capture_dp(self):
+        """The N>1 step as ONE graph when the collective can be captured (RCCL, single all-reduce); otherwise — gloo,
+        the two-bucket overlap, or a capture that raised — graph | eager all-reduce | eager Adam, in this process
+        (never a re-exec)."""
+        why = None
+        if self.sync.split is not None:
+            why = "two overlapped buckets"
+        elif not self.capture_collective:
+            why = "capture_collective=False"
+        elif not collective_capturable(self.group):
+            why = f"backend {dist.get_backend(self.group)} stages through the host"
+        else:
+            try:
+                g = self._capture(self._whole_dp)
+                self.dp_graph = "one graph: forward + backward + all-reduce + Adam"
+                return g
+            except Exception as e:      # noqa: BLE001 (whatever the runtime says about capturing the collective)
+                why = f"capturing the all-reduce raised {type(e).__name__}: {str(e)[:120]}"
+        self.dp_graph = f"three pieces: graph | eager all-reduce | Adam ({why})"
+        return self._capture_data_parallel()
 
     # ---- public -----------------------------------------------------------------------------------
     def step(self, rays: torch.Tensor, rgbs: torch.Tensor, rng: Optional[Dict[str, torch.Tensor]] = None
@@ -158,20 +196,23 @@ class TrainStep:
         self.optimizer.sync_hyper()      # a replayed Adam launch reads lr & co. from device memory
         if not self.use_graph:
             self._forward_backward()
-            if self.world > 1:
-                self.sync.reduce(F.flush_held_wgrads)
+            if self.dp:
+                self.sync.reduce(F.flush_held_wgrads, force=True)
             self.optimizer.step()
-        elif self.world == 1:
+        elif not self.dp:
             if self._graph is None:
                 self._graph = self._capture(self._whole)
             self._graph()
         else:
             if self._graph is None:
-                self._graph = self._capture_data_parallel()
-            fwd_bwd, held = self._graph
-            fwd_bwd()
-            self.sync.reduce(held)      # all-reduce(bucket 0) || held weight gradients, then all-reduce(bucket 1)
-            self.optimizer.step()
+                self._graph = self._capture_dp()
+            if isinstance(self._graph, GraphedStep):
+                self._graph()               # forward + backward + all-reduce + Adam: ONE replay
+            else:
+                fwd_bwd, held = self._graph
+                fwd_bwd()
+                self.sync.reduce(held, force=True)   # all-reduce(bucket 0) || held weight gradients, then all-reduce(bucket 1)
+                self.optimizer.step()
         # a replay updates the parameters without running any Python: tell the weight packers (an eval forward
         # after this must repack — see machine.MlpRunner.pack)
         self.arena.bump()

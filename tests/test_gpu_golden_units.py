@@ -111,6 +111,12 @@ def test_g09_depth_index_names(golden_dir, inf, wb):
     assert safe.float().mean() > 0.9
     assert torch.equal(MU.compute_depth_index(w3.to(DEV)).cpu()[safe], i_ref[safe])
     assert torch.equal(MU.compute_depth_map(w3.to(DEV), z3.to(DEV)).cpu()[safe], (m_ref.float() * z3).sum(-1)[safe])
+    # differentiable w.r.t. z_vals like the reference's sum(mask * z_vals): the gradient IS the mask
+    zg = z.clone().requires_grad_(True)
+    d = MU.compute_depth_map(w, zg)
+    assert np.array_equal(d.detach().cpu().numpy(), g[f"med_depth_inf{inf}_wb{wb}"])
+    d.sum().backward()
+    assert torch.equal(zg.grad.cpu(), mask_ref.float().expand_as(zg))
 
 
 @pytest.mark.parametrize("name,kw", [

@@ -957,6 +957,76 @@ def test_config2_full_size_fp32_vs_oracle():
         HN.set_precision("bf16")
 
 
+def test_config3_full_size_subset_vs_oracle():
+    """BASELINE config 3 at its FULL size — ONE launch of 16,384 rays x (64 + 128) samples = 4.2 M evaluated points,
+    the persistent tile loops, weight-gradient jobs of hundreds of LDS stages, a > 100 GB fp32 activation stash — pinned
+    to the CPU oracle through a seeded subset: rays are independent (models.py:673-780), so the oracle run on 256 of
+    the launch's rays (same rows of the draws) must reproduce those rows of the full launch (forward 1e-4), and with the
+    loss masked to those rays the WHOLE weight gradient and the GLO-table gradient of the full-size backward (every
+    other ray contributes an exact zero through every kernel) must be the oracle's (rel L2 <= 3e-3)."""
+    HN.set_precision("fp32")
+    try:
+        kw = CASES["bendy_cond"]
+        b, nc, nf, nsel, seed = 16384, 64, 128, 256, 93
+        m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=1.0, view_fourier_dim=6, **kw)
+        sd = load_hash(m, seed)
+        m = m.to(DEV)
+        free, _ = torch.cuda.mem_get_info()
+        prog = m._level_call("fine").program
+        need = sum(prog.layout(L.HN_MODE_F32, b * s)[1] + prog.layout(L.HN_MODE_F32, b * s)[2] for s in (nc, nc + nf))
+        if need * 1.15 > free:
+            pytest.skip(f"fp32 stash of the full launch needs {need / 2**30:.0f} GiB, {free / 2**30:.0f} GiB free")
+        o, d, idx = rays_for(seed, b)
+        rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1),
+               "noise_coarse": H.normal(seed, "n1", (b, nc, 1)), "noise_fine": H.normal(seed, "n2", (b, nc + nf, 1))}
+        gt = H.uniform(seed, "gt", (b, 3), 0, 1)
+        sel = torch.from_numpy(np.sort(np.random.RandomState(seed).choice(b, nsel, replace=False)))
+        # the oracle on the subset only
+        cfg = O.ModelCfg(n_samples_coarse=nc, n_samples_fine=nf, noise_std=1.0, view_fourier_dim=6, **kw)
+        torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = O.nerf_model_forward(p, cfg, o[sel], d[sel], idx[sel], {k: v[sel] for k, v in rng.items()})
+        ref_loss = O.mse_loss(ref, gt[sel])
+        ref_loss.backward()
+        # the full launch
+        rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+        out = m(rays, {}, rng={k: v.to(DEV) for k, v in rng.items()})
+        assert out["fine"]["weights"].shape == (b, nc + nf)
+        sd_ = sel.to(DEV)
+        for k in ("rgb", "depth", "acc", "weights", "warped_points"):
+            assert_close(out["coarse"][k][sd_], ref["coarse"][k], 1e-4, f"config3 full size coarse/{k} (256-ray subset)")
+        inds = m.last_sampling["inds"][sd_].cpu()
+        same = (inds == ref["fine"]["_inds"]).float().mean().item()
+        assert same > 0.999, f"only {same:.5f} of the subset's fine-sample indices agree"
+        ok = (inds == ref["fine"]["_inds"]).all(dim=1)
+        assert float(ok.float().mean()) > 0.9
+        for k in ("rgb", "depth", "acc"):
+            assert_close(out["fine"][k][sd_][ok.to(DEV)], ref["fine"][k][ok], 1e-4, f"config3 full size fine/{k} (subset)")
+        # loss masked to the subset (losses.py:10-14 on those rays), backward through the FULL launch
+        loss = ((out["coarse"]["rgb"][sd_] - gt[sel].to(DEV)) ** 2).mean() + ((out["fine"]["rgb"][sd_] - gt[sel].to(DEV)) ** 2).mean()
+        assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-5 * max(1.0, float(ref_loss.detach()))
+        loss.backward()
+        g, gr = m.warp_embed.embed.weight.grad, p["warp_embed.embed.weight"].grad
+        assert_grad_close(g, gr, 5e-3, "config3 full size d GLO table (rel L2)", frobenius=True)
+        rows_off = torch.ones(g.shape[0], dtype=torch.bool)
+        rows_off[torch.unique(idx[sel])] = False
+        assert float(g[rows_off.to(DEV)].abs().max()) == 0.0, "rays outside the subset must contribute exact zeros"
+        named = dict(m.named_parameters())
+        ks = [k for k in named if p[k].grad is not None and named[k].grad is not None]
+        assert len(ks) >= 60
+        ga = torch.cat([named[k].grad.detach().cpu().double().reshape(-1) for k in ks])
+        ra = torch.cat([p[k].grad.double().reshape(-1) for k in ks])
+        tot = float(ra.norm())
+        rel = float((ga - ra).norm()) / tot
+        assert rel <= 3e-3, f"config 3 full size: whole-gradient rel L2 {rel:.2e} against the oracle on the subset"
+        for k in ks:
+            if float(p[k].grad.norm()) >= 1e-3 * tot:
+                assert_grad_close(named[k].grad, p[k].grad, 1e-2, f"config3 full size d {k}", frobenius=True)
+    finally:
+        HN.set_precision("bf16")
+
+
 def test_config5_full_size_fp32_vs_oracle():
     """BASELINE config 5 (SE3Field warp + axis-aligned slice, GLO conditions) at its FULL size, 1024 rays x (64+64), in
     fp32 mode against the CPU oracle: coarse tensors element-wise to 1e-4, fine-index agreement, loss, and the whole
@@ -1180,6 +1250,42 @@ def test_se3_field_warp_vs_oracle():
         assert set(f(pts.to(DEV), None, {"warp_alpha": None}).keys()) == {"warped_points"}
     finally:
         HN.set_precision("bf16")
+
+
+@pytest.mark.gpu
+def test_se3_warped_rows_carry_gradients_to_field_and_table():
+    """A loss on `warped_points` of a config-5 level (= [xyz | GLO row], written by the exp-map launch) reaches the
+    field through its xyz columns and the embedding table through its row columns, like the reference's differentiable
+    cat([xyz, rows]) (models.py:578-581): compared with the same loss on torch.cat of the plain se3_warp output and
+    an index_select of the table."""
+    from hypernerf_torch_amd import functional as F
+    b, s, hdim, rows, seed = 5, 32, 8, 11, 77
+    n = b * s
+    wv = (H.normal(seed, "wv", (n, 6)) * 0.3).to(DEV)
+    pts = H.uniform(seed, "p", (n, 3), -1.0, 1.0).to(DEV)
+    table = H.normal(seed, "tab", (rows, hdim)).to(DEV)
+    idx = torch.tensor([3, 0, 10, 3, 7], device=DEV)
+    gx = H.normal(seed, "gx", (n, 3)).to(DEV)
+    gw = H.normal(seed, "gw", (n, 3 + hdim)).to(DEV)
+    a_wv, a_p, a_t = (t.clone().requires_grad_(True) for t in (wv, pts, table))
+    xyz, warped = F.se3_warp(a_wv, a_p, a_t, idx, s)
+    assert warped.requires_grad and warped.shape == (n, 3 + hdim)
+    ((xyz * gx).sum() + (warped * gw).sum()).backward()
+    r_wv, r_p, r_t = (t.clone().requires_grad_(True) for t in (wv, pts, table))
+    xyz_r = F.se3_warp(r_wv, r_p)
+    warped_r = torch.cat([xyz_r, r_t.index_select(0, idx).repeat_interleave(s, dim=0)], dim=1)
+    ((xyz_r * gx).sum() + (warped_r * gw).sum()).backward()
+    assert_close(warped, warped_r, 1e-6, "warped rows")
+    assert_grad_close(a_wv.grad, r_wv.grad, 1e-5, "d wv through warped")
+    assert_grad_close(a_p.grad, r_p.grad, 1e-5, "d points through warped")
+    assert_grad_close(a_t.grad, r_t.grad, 1e-5, "d table through warped")
+    # the training step's own use (gradient through xyz only) is unchanged
+    b_wv = wv.clone().requires_grad_(True)
+    xyz2, warped2 = F.se3_warp(b_wv, pts, table, idx, s)
+    (xyz2 * gx).sum().backward()
+    c_wv = wv.clone().requires_grad_(True)
+    (F.se3_warp(c_wv, pts) * gx).sum().backward()
+    assert torch.equal(b_wv.grad, c_wv.grad)
 
 
 @pytest.mark.gpu

@@ -316,10 +316,31 @@ def test_bench_launch_plan():
         assert rk["cmd"][1].endswith("bench.py") and "--launch-plan" not in rk["cmd"]
         assert rk["cmd"][2:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert len(ports) == 1
+    # the 8-GPU node of BASELINE config 4: 8 commands, RANK == LOCAL_RANK == 0..7 (one rank per GPU, never two on one),
+    # one rendezvous port, the caller's MASTER_PORT honoured; the IPC variable is the caller's if set, and left alone
+    # entirely under HN_KEEP_IPC_ENV=1
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod_plan", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    plan8 = bench.launch_plan(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], env={"MASTER_PORT": "29611"})
+    assert len(plan8) == 8
+    assert [e["LOCAL_RANK"] for _, e in plan8] == [str(i) for i in range(8)] == [e["RANK"] for _, e in plan8]
+    assert {e["MASTER_PORT"] for _, e in plan8} == {"29611"} and {e["WORLD_SIZE"] for _, e in plan8} == {"8"}
+    assert all(c[2:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] for c, _ in plan8)
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for _, e in plan8)
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+               for _, e in bench.launch_plan(2, [], env={"HSA_ENABLE_IPC_MODE_LEGACY": "1"}))
+    assert all("HSA_ENABLE_IPC_MODE_LEGACY" not in e for _, e in bench.launch_plan(2, [], env={"HN_KEEP_IPC_ENV": "1"}))
     # a rank whose WORLD_SIZE disagrees with --gpus refuses to run (it would report a point of the wrong curve)
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
     assert bad.returncode == 4 and "WORLD_SIZE=1" in bad.stderr
+    # more RCCL ranks than GPUs is refused (two ranks on one device hang RCCL); only the gloo debugging mode may fold
+    fold = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                          env=dict({k: v for k, v in env.items() if k != "HN_DIST_BACKEND"}, WORLD_SIZE="2", RANK="1",
+                                   LOCAL_RANK="1"), timeout=300)
+    assert fold.returncode == 5 and "HN_DIST_BACKEND=gloo" in fold.stderr
 
 
 def test_pmc_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
@@ -385,6 +406,24 @@ def test_lr_schedules_match_the_reference(golden_dir):
             sch.step()
             lrs.append(opt.param_groups[0]["lr"])
         np.testing.assert_allclose(np.array(lrs), g[name], rtol=1e-9, atol=1e-15, err_msg=name)
+        # resume mid-schedule (checkpoint at every epoch, warm-up hand-over included): a FRESH optimizer + scheduler
+        # loaded with the saved state continues on the recorded sequence — the wrapped scheduler's state and the
+        # learning rate the optimizer held travel with it
+        for cut in range(1, len(g[name]) - 1):
+            opt = types.SimpleNamespace(param_groups=[{"lr": 5e-4}])
+            sch = optim.get_scheduler(types.SimpleNamespace(optimizer="adam", **hp), opt)
+            for _ in range(cut):
+                sch.step()
+            saved = json.loads(json.dumps(sch.state_dict()))          # plain data: survives a checkpoint file
+            opt2 = types.SimpleNamespace(param_groups=[{"lr": 5e-4}])
+            sch2 = optim.get_scheduler(types.SimpleNamespace(optimizer="adam", **hp), opt2)
+            sch2.load_state_dict(saved)
+            assert opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"], (name, cut)
+            rest = []
+            for _ in range(len(g[name]) - 1 - cut):
+                sch2.step()
+                rest.append(opt2.param_groups[0]["lr"])
+            np.testing.assert_allclose(np.array(rest), g[name][cut + 1:], rtol=1e-9, atol=1e-15, err_msg=f"{name} resumed at {cut}")
     opt = types.SimpleNamespace(param_groups=[{"lr": 5e-4}])
     sch = optim.get_scheduler(types.SimpleNamespace(lr_scheduler="poly", num_epochs=10, poly_exp=0.9, warmup_epochs=0), opt)
     for e in range(1, 11):

@@ -53,6 +53,8 @@ def main():
     res["forward_flops"] = fl
     res["forward_tflops"] = fl / dt / 1e12
     res["mfma_frac_of_2.5PF"] = fl / dt / 2.5e15
+    from hypernerf_torch_amd import _lib
+    res["build"] = _lib.build_id()
     print(json.dumps(res))
 
 

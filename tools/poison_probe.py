@@ -163,6 +163,7 @@ def repeat_probe(case="bendy_cond", prec="bf16", size=(1024, 64, 64), n=200, are
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "repeat":
     for case in CASES:
         for prec, n, size in (("bf16", 200, (1024, 64, 64)), ("fp32", 40, (1024, 64, 64)), ("bf16", 300, (40, 8, 8)),
+                              ("bf16s8", 200, (1024, 64, 64)), ("bf16s8", 300, (100, 16, 24)),
                               ("bf16", 300, (100, 16, 24)), ("fp32", 100, (100, 16, 24))):
             bad = repeat_probe(case, prec, size, n)
             print(case, prec, size, "runs", n, "deviations", len(bad), bad[:4])

@@ -1,0 +1,59 @@
+"""bf16 TrainStep against the CPU oracle + torch.optim.Adam (the reference's arithmetic) on the same small scene,
+batches and draws: held-out PSNR of both final parameter sets (same fp32 evaluator), per seed, the gap of the means
+and its standard error.  The CPU runs go to spawned worker processes (they never touch the GPU).
+
+    python tools/psnr_vs_oracle.py [steps=300] [rays=64] [nc=16] [nf=16] [seeds=8] [lr=1e-3] [modes=bf16,fp32]
+Prints one JSON line."""
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+
+def main():
+    import torch.multiprocessing as mp
+    import oracle_train as OT
+    a = sys.argv[1:]
+    steps = int(a[0]) if len(a) > 0 else 300
+    b = int(a[1]) if len(a) > 1 else 64
+    nc = int(a[2]) if len(a) > 2 else 16
+    nf = int(a[3]) if len(a) > 3 else 16
+    n_seeds = int(a[4]) if len(a) > 4 else 8
+    lr = float(a[5]) if len(a) > 5 else 1e-3
+    modes = (a[6] if len(a) > 6 else "bf16,fp32").split(",")
+    noise = 0.5
+    cores = len(os.sched_getaffinity(0))
+    procs = max(1, min(n_seeds, cores // 4))
+    threads = max(1, cores // procs)
+    t0 = time.perf_counter()
+    ctx = mp.get_context("spawn")
+    pool = ctx.Pool(procs)
+    fut = pool.map_async(OT.cpu_run, [(s, steps, b, nc, nf, lr, noise, threads) for s in range(n_seeds)])
+    gpu = {}
+    for mode in modes:
+        gpu[mode] = [OT.gpu_run(s, steps, b, nc, nf, lr, noise, mode) for s in range(n_seeds)]
+    t_gpu = time.perf_counter() - t0
+    cpu = sorted(fut.get(timeout=3600))
+    pool.close()
+    wall = time.perf_counter() - t0
+    res = {"config": f"{steps} steps x {b} rays x ({nc}+{nf}) samples, Adam lr {lr}, noise_std {noise}, {n_seeds} seeds",
+           "cpu_oracle_psnr_db": [round(c[1], 3) for c in cpu], "cpu_first_last_loss": [(round(c[2][0], 4), round(c[2][-1], 4)) for c in cpu],
+           "wall_s": round(wall, 1), "gpu_part_s": round(t_gpu, 1), "cpu_procs": procs, "threads_per_proc": threads}
+    ref = [c[1] for c in cpu]
+    for mode in modes:
+        ps = [g[0] for g in gpu[mode]]
+        diffs = [p - r for p, r in zip(ps, ref)]
+        mean = sum(diffs) / len(diffs)
+        sd = math.sqrt(sum((x - mean) ** 2 for x in diffs) / max(1, len(diffs) - 1))
+        res[mode] = {"psnr_db": [round(p, 3) for p in ps], "gap_db_per_seed": [round(x, 3) for x in diffs],
+                     "mean_gap_db": round(mean, 4), "se_db": round(sd / math.sqrt(len(diffs)), 4),
+                     "first_last_loss": [(round(g[1][0], 4), round(g[1][-1], 4)) for g in gpu[mode]]}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
