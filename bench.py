@@ -622,9 +622,15 @@ def cpu_baseline(a, model, data, dev):
     from oracle import hypernerf_oracle as O
     from hypernerf_torch_amd.hypernerf import model_utils
     try:
-        cores = len(os.sched_getaffinity(0))        # cores this process may actually use (cgroup-aware)
+        cores = len(os.sched_getaffinity(0))        # cores in this process's affinity mask ...
     except AttributeError:
         cores = os.cpu_count() or 1
+    try:                                            # ... capped by the cgroup CPU quota (the pool's GPU boxes show 256
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]      # CPUs under a 16-CPU quota)
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
     b = min(a.rays, 2048)

@@ -20,6 +20,13 @@ def rays_for(seed, b, n_img=100):
     return o, d, torch.from_numpy(idx)
 
 
+def oracle_threads(cap=64):
+    """Threads for a CPU-oracle run inside a GPU test: the affinity mask capped by the cgroup CPU quota (the pool's GPU
+    boxes show 256 CPUs under a 16-CPU quota; a thread pool sized by the mask runs several times slower)."""
+    from oracle_train import usable_cores
+    return max(1, min(int(cap), usable_cores()))
+
+
 def load_hash(module, seed):
     sd = module.state_dict()
     new = H.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed)

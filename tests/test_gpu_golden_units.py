@@ -14,7 +14,7 @@ import torch
 
 import hashprng as H
 import hypernerf_torch_amd as HN
-from gpu_common import DEV, EMB, assert_close, assert_rel_close, load_hash, rays_for
+from gpu_common import oracle_threads, DEV, EMB, assert_close, assert_rel_close, load_hash, rays_for
 from hypernerf_torch_amd import functional as F
 from hypernerf_torch_amd import losses
 from hypernerf_torch_amd.hypernerf import model_utils as MU
@@ -221,7 +221,7 @@ def test_persistent_loop_more_than_1024_tiles(precision):
     emb = H.uniform(21, "emb", (b, 8), -0.5, 0.5)
     tp = {"w." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
     er = emb.clone().requires_grad_(True)
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    torch.set_num_threads(oracle_threads(32))
     y_ref = O.translation_field(tp, "w", pts, er[:, None, :].expand(b, s, 8))
     gsel = H.uniform(22, "g", (b, s, 3), -1, 1)
     (y_ref * gsel).sum().backward()

@@ -15,7 +15,7 @@ import torch
 
 import hashprng as H
 import hypernerf_torch_amd as HN
-from gpu_common import DEV, EMB, assert_close, load_hash, rays_for
+from gpu_common import oracle_threads, DEV, EMB, assert_close, load_hash, rays_for
 from hypernerf_torch_amd import functional as F
 from hypernerf_torch_amd.hypernerf import models
 from hypernerf_torch_amd.dist import GradSync
@@ -148,7 +148,7 @@ def test_training_tracks_the_cpu_oracle():
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     topt = torch.optim.Adam(list(p.values()), lr=1e-4, eps=1e-8)          # utils/__init__.py:29-31
     ts = TrainStep(m, lr=1e-4, use_graph=True, chunk=40)                   # 96 rays in chunks of 40, 40, 16
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    torch.set_num_threads(oracle_threads(32))
     cpu_loss, hip_loss, cpu_psnr, hip_psnr = [], [], [], []
     for it in range(steps):
         o, d, idx, rays = ray_rows(seed + it % 3, b)                       # three batches, cycled
@@ -175,6 +175,46 @@ def test_training_tracks_the_cpu_oracle():
     print("cpu loss:", np.array2string(cl, precision=4))
     from gpu_common import _record
     _record("TrainStep vs CPU oracle + torch Adam: loss curve, 16 steps", "max rel", rel.max(), 2e-3)
+
+
+def test_bf16_training_psnr_vs_cpu_oracle():
+    """The north star's 'PSNR within 0.1 dB of reference' for the THROUGHPUT mode, tied to the reference's arithmetic
+    (train.py:147-163, metrics.py:4-13) instead of to this repository's own fp32 mode: the bf16 `TrainStep` (HIP graph,
+    fused Adam) and the CPU oracle + torch.optim.Adam train the same small scene — 400 steps x 128 rays x (16+16)
+    samples, lr 1e-3 -> 1e-4 — from the same weights on the same batches and draws, 8 seeds; both final parameter sets
+    are scored on held-out rays by the SAME evaluator (fp32 oracle, deterministic branch), so the two numbers differ by
+    the training trajectory only.  Two fp32 implementations of such a run already end 0.4-0.5 dB apart seed by seed
+    (chaotic trajectories), so with 8 seeds the standard error of the mean gap is ~0.15 dB: the test
+    asserts what 8 seeds can carry — the mean gap is statistically compatible with the 0.1 dB bound (|mean| <= 0.1 +
+    2 s.e.), no seed is off by more than 2 dB, both sides learned — and prints the numbers; the 64-seed run of the same
+    harness (tools/psnr_vs_oracle.py, profiles/r04_psnr_vs_oracle_64seeds.json) is the tight statement."""
+    import torch.multiprocessing as mp
+    import oracle_train as OT
+    steps, b, nc, nf, n_seeds, lr, lr_end, freq, noise = 400, 128, 16, 16, 8, 1e-3, 1e-4, 0.5, 0.5
+    procs = max(1, min(n_seeds, OT.usable_cores() // 2))
+    ctx = mp.get_context("spawn")
+    pool = ctx.Pool(procs)
+    try:
+        fut = pool.map_async(OT.cpu_run, [(s_, steps, b, nc, nf, lr, noise, 2, lr_end, freq) for s_ in range(n_seeds)])
+        gpu = [OT.gpu_run(s_, steps, b, nc, nf, lr, noise, "bf16", lr_end=lr_end, freq=freq) for s_ in range(n_seeds)]
+        cpu = sorted(fut.get(timeout=900))
+    finally:
+        pool.terminate()
+    ref = np.array([c[1] for c in cpu])
+    got = np.array([g[0] for g in gpu])
+    diffs = got - ref
+    mean, se = float(diffs.mean()), float(diffs.std(ddof=1) / math.sqrt(n_seeds))
+    print(f"bf16 TrainStep vs CPU oracle + torch Adam, held-out PSNR over {n_seeds} seeds: oracle {ref.mean():.2f} dB, "
+          f"bf16 {got.mean():.2f} dB, gap {mean:+.3f} dB (s.e. {se:.3f}); per seed {np.array2string(diffs, precision=2)}")
+    from gpu_common import _record
+    _record("bf16 TrainStep vs CPU oracle: mean held-out PSNR gap (dB), 8 seeds", "abs", abs(mean), 0.1 + 2 * se)
+    for c, g in zip(cpu, gpu):
+        assert abs(c[2][0] - g[1][0]) <= 5e-2 * c[2][0], "the first step's loss: same weights, batch and draws"
+        assert c[2][-1] < 0.5 * c[2][0] and g[1][-1] < 0.5 * g[1][0], "both runs must learn"
+    assert ref.mean() > 20.0 and got.mean() > 20.0
+    assert se <= 0.35, f"standard error {se:.3f} dB: the harness lost its resolution"
+    assert abs(mean) <= 0.1 + 2.0 * se, f"mean held-out PSNR gap {mean:+.3f} dB (s.e. {se:.3f}) vs the CPU oracle"
+    assert float(np.abs(diffs).max()) <= 2.0, diffs
 
 
 def test_eager_training_steps_do_not_leak_device_memory():

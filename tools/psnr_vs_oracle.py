@@ -2,7 +2,7 @@
 batches and draws: held-out PSNR of both final parameter sets (same fp32 evaluator), per seed, the gap of the means
 and its standard error.  The CPU runs go to spawned worker processes (they never touch the GPU).
 
-    python tools/psnr_vs_oracle.py [steps=300] [rays=64] [nc=16] [nf=16] [seeds=8] [lr=1e-3] [modes=bf16,fp32]
+    python tools/psnr_vs_oracle.py [steps=300] [rays=64] [nc=16] [nf=16] [seeds=8] [lr=1e-3] [modes=bf16,fp32] [lr_end=0] [freq=1]
 Prints one JSON line."""
 import json
 import math
@@ -25,22 +25,27 @@ def main():
     n_seeds = int(a[4]) if len(a) > 4 else 8
     lr = float(a[5]) if len(a) > 5 else 1e-3
     modes = (a[6] if len(a) > 6 else "bf16,fp32").split(",")
+    lr_end = float(a[7]) if len(a) > 7 and float(a[7]) > 0 else None
+    freq = float(a[8]) if len(a) > 8 else 1.0
     noise = 0.5
-    cores = len(os.sched_getaffinity(0))
-    procs = max(1, min(n_seeds, cores // 4))
-    threads = max(1, cores // procs)
+    cores = OT.usable_cores()
+    # the oracle's small-batch steps are op-overhead bound (0.09 s per step at 8 threads, 0.12 at 2): few threads per run,
+    # one process per seed — and never more threads than the affinity mask admits (an over-subscribed OpenMP pool on a
+    # quota-limited box is orders of magnitude slower)
+    procs = max(1, min(n_seeds, cores // 2))
+    threads = 2
     t0 = time.perf_counter()
     ctx = mp.get_context("spawn")
     pool = ctx.Pool(procs)
-    fut = pool.map_async(OT.cpu_run, [(s, steps, b, nc, nf, lr, noise, threads) for s in range(n_seeds)])
+    fut = pool.map_async(OT.cpu_run, [(s, steps, b, nc, nf, lr, noise, threads, lr_end, freq) for s in range(n_seeds)])
     gpu = {}
     for mode in modes:
-        gpu[mode] = [OT.gpu_run(s, steps, b, nc, nf, lr, noise, mode) for s in range(n_seeds)]
+        gpu[mode] = [OT.gpu_run(s, steps, b, nc, nf, lr, noise, mode, lr_end=lr_end, freq=freq) for s in range(n_seeds)]
     t_gpu = time.perf_counter() - t0
     cpu = sorted(fut.get(timeout=3600))
     pool.close()
     wall = time.perf_counter() - t0
-    res = {"config": f"{steps} steps x {b} rays x ({nc}+{nf}) samples, Adam lr {lr}, noise_std {noise}, {n_seeds} seeds",
+    res = {"config": f"{steps} steps x {b} rays x ({nc}+{nf}) samples, Adam lr {lr} -> {lr_end}, scene freq {freq}, noise_std {noise}, {n_seeds} seeds",
            "cpu_oracle_psnr_db": [round(c[1], 3) for c in cpu], "cpu_first_last_loss": [(round(c[2][0], 4), round(c[2][-1], 4)) for c in cpu],
            "wall_s": round(wall, 1), "gpu_part_s": round(t_gpu, 1), "cpu_procs": procs, "threads_per_proc": threads}
     ref = [c[1] for c in cpu]
