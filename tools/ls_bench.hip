@@ -65,6 +65,9 @@ constexpr int BLK_BYTES = 16384;        // one 32-point block of a 256-feature a
 #ifndef LS_STAGGER
 #define LS_STAGGER 0     /* 1: waves 4-7 (the SIMD partners of 0-3) run dW before dX: matrix work beside the partner's issue / wait phases */
 #endif
+#ifndef LS_BBUF
+#define LS_BBUF 2        /* B-fragment buffers of the dX product (2: the next four are read under the current products) */
+#endif
 #ifndef LS_NST
 #define LS_NST 4
 #endif
@@ -285,6 +288,10 @@ __global__ __launch_bounds__(512, 2) void ls_stage_kernel(const LsArgs a) {
 #ifdef LS_PROF
   unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
 #endif
+  // the block loop, instantiated once per phase order (a run-time choice of the order inside ONE loop makes hipcc merge
+  // the register state of both orders at every iteration: 480-544 B/lane of scratch)
+  auto block_loop = [&](auto hi_) __attribute__((always_inline)) {
+  constexpr bool HI = decltype(hi_)::value;
   for (int q = 0; q < nq; ++q) {
     TS(s0);
     // ---- top: block q has landed; flags; barrier ------------------------------------------------------------
@@ -323,8 +330,21 @@ __global__ __launch_bounds__(512, 2) void ls_stage_kernel(const LsArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) dx[e] = 0.0f;
     {
-      u32x4 b0[4], b1[4];
       const unsigned z0 = sb + bo0, z1 = sb + bo1;
+#if LS_BBUF == 1
+      // one buffer of four fragments: 16 registers fewer (what the counter-phase build needs to stay out of scratch);
+      // every group's LDS latency is exposed to this wave (its SIMD partner covers it)
+      u32x4 b0[4];
+      static_for<4>([&](auto G_) __attribute__((always_inline)) {
+        constexpr int g4 = decltype(G_)::value;
+        read4<4096 * g4, 4096 * g4, 4096 * g4 + 2048, 4096 * g4 + 2048>(b0[0], b0[1], b0[2], b0[3], z0, z1);
+        LGKM_WAIT4(b0[0], b0[1], b0[2], b0[3], 0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) dx = mfma(wt[4 * g4 + f], __builtin_bit_cast(bf16x8, b0[f]), dx);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#else
+      u32x4 b0[4], b1[4];
       read4<0, 0, 2048, 2048>(b0[0], b0[1], b0[2], b0[3], z0, z1);
       read4<4096, 4096, 6144, 6144>(b1[0], b1[1], b1[2], b1[3], z0, z1);
       LGKM_WAIT4(b0[0], b0[1], b0[2], b0[3], 4);
@@ -344,6 +364,7 @@ __global__ __launch_bounds__(512, 2) void ls_stage_kernel(const LsArgs a) {
       LGKM_WAIT4(b1[0], b1[1], b1[2], b1[3], 0);
 #pragma unroll
       for (int f = 0; f < 4; ++f) dx = mfma(wt[12 + f], __builtin_bit_cast(bf16x8, b1[f]), dx);
+#endif
     }
     TS(s3);
     // ---- ReLU mask off the stashed X tile `wave`, conversion, write-through stores ---------------------------------
@@ -424,11 +445,14 @@ __global__ __launch_bounds__(512, 2) void ls_stage_kernel(const LsArgs a) {
     }
     issue_mark();
     };
-    if (LS_STAGGER && wave >= 4) { phase_dw(); phase_dx(); }
+    if constexpr (HI) { phase_dw(); phase_dx(); }
     else { phase_dx(); phase_dw(); }
     TS(s6);
     ACC(0, s0, s1); ACC(1, s1, s2); ACC(2, s2, s3); ACC(3, s3, s4); ACC(4, s4, s5); ACC(5, s5, s6);
   }
+  };
+  if (LS_STAGGER && wave >= 4) block_loop(std::true_type{});
+  else block_loop(std::false_type{});
 #ifdef LS_PROF
   if (lane == 0 && a.prof != nullptr && (wave == 0 || wave == 5)) {
     unsigned long long* o = a.prof + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;

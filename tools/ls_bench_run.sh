@@ -8,7 +8,7 @@ out=$dir/runs.log
 : > "$out"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 build() { [ -x tools/$1 ] || $HIPCC -O3 --offload-arch=gfx950 $2 -o tools/$1 tools/ls_bench.hip; }
-build ls_bench ""; build ls_bench_n3 "-DLS_NST=3"; build ls_bench_prof "-DLS_PROF"; build ls_bench_sp "-DLS_SPREAD=1"
+build ls_bench ""; build ls_bench_n3 "-DLS_NST=3"; build ls_bench_prof "-DLS_PROF"; build ls_bench_sp "-DLS_SPREAD=1"; build ls_bench_b1 "-DLS_BBUF=1"; build ls_bench_st "-DLS_STAGGER=1 -DLS_BBUF=1"
 run() { b=$1; shift; echo "\$ tools/$b $*" >> "$out"; timeout 120 tools/$b "$@" >> "$out" 2>&1; echo "rc=$?" >> "$out"; }
 # points layers reps mode G R check dbg
 for m in 0 1 2 3; do run ls_bench 1048576 3 10 $m 85 16 1 0; done                 # 3 stages, cross-XCD pairs
