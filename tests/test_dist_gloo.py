@@ -57,6 +57,15 @@ def _worker(rank, world, port, q):
             torch.allclose(e.grad, torch.arange(5, dtype=torch.float32) * 1.5) and \
             arena.attached(d) == 0 and arena.attached(e) == 12 and \
             torch.allclose(arena.grad[:9], torch.full((9,), 1.5))
+        # gloo stages through host memory: the collective cannot be recorded into a HIP graph, so TrainStep / bench.py
+        # keep it out of the step graph on this backend (round 4: with nccl = RCCL it is captured with the step)
+        from hypernerf_torch_amd.dist import collective_capturable
+        ok = ok and collective_capturable() is False
+        # force=True issues the collective whatever the group size (what lets ONE RCCL rank exercise the captured
+        # all-reduce on a one-GPU box); a plain call in a 2-rank group reduces as before
+        arena.grad.fill_(float(rank + 1))
+        arena.all_reduce_sum(force=True)
+        ok = ok and torch.allclose(arena.grad, torch.full_like(arena.grad, 3.0))
         px = torch.full((4, 3), float(rank))
         allpx = all_gather_pixels(px)
         ok = ok and allpx.shape == (8, 3) and torch.equal(allpx[:4], torch.zeros(4, 3)) and \

@@ -343,6 +343,54 @@ def test_bench_launch_plan():
     assert fold.returncode == 5 and "HN_DIST_BACKEND=gloo" in fold.stderr
 
 
+def test_bench_also_block_host_logic(monkeypatch):
+    """The `also` block the default `python bench.py` appends to its line (configs 3, 5, 1 + the eval image loop as child
+    processes): entries are built from the children's own JSON lines, a child that fails or times out becomes an
+    `error` / `skipped` entry instead of costing the headline, the flags every child gets keep it from recursing or
+    timing the CPU oracle, and the block stops starting children when its time budget is spent."""
+    import importlib.util
+    import json
+    import subprocess
+    spec = importlib.util.spec_from_file_location("bench_mod_also", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+
+    def fake_run(cmd, capture_output, text, timeout):
+        calls.append((cmd, timeout))
+        script = os.path.basename(cmd[1])
+        if script == "eval_bench.py":
+            line = {"images_per_s": 13.5, "s_per_image": 0.074, "ray_samples_per_s": 3.3e8, "mfma_frac_of_2.5PF": 0.32,
+                    "build": {"kernel_src_sha256": "abc"}}
+            return subprocess.CompletedProcess(cmd, 0, "banner\n" + json.dumps(line) + "\n", "")
+        cfg = cmd[cmd.index("--config") + 1]
+        if cfg == "5":
+            return subprocess.CompletedProcess(cmd, 3, "", "boom")
+        if cfg == "1":
+            raise subprocess.TimeoutExpired(cmd, timeout)
+        line = {"value": 8.2e7, "unit": "ray-samples/s", "ms_per_step": 38.0, "dtype": "bf16", "steps": 5, "repeats": 3,
+                "ms_per_step_spread": [37.9, 38.1], "config": {"workload": "w"}, "step_mfma_frac": 0.21,
+                "roofline": {"kernel": "hn_wgrad_kernel<true>", "frac": 0.18}, "build": {"kernel_src_sha256": "abc"}}
+        return subprocess.CompletedProcess(cmd, 0, json.dumps(line) + "\n", "")
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    out = bench.also_block()
+    assert set(out) >= {"config3", "config5", "config1", "render_image", "wall_s", "note"}
+    assert out["config3"]["value"] == 8.2e7 and out["config3"]["frac"] == 0.18 and out["config3"]["kernel"].startswith("hn_wgrad")
+    assert out["config3"]["build"]["kernel_src_sha256"] == "abc"
+    assert "error" in out["config5"] and "boom" in out["config5"]["stderr_tail"]
+    assert "skipped" in out["config1"]
+    assert out["render_image"]["value"] == 13.5 and out["render_image"]["frac"] == 0.32
+    for cmd, timeout in calls:
+        assert timeout <= 40.0
+        if os.path.basename(cmd[1]) == "bench.py":
+            assert "--no-also" in cmd and "--no-cpu-baseline" in cmd
+    # budget spent: no further child is started
+    calls.clear()
+    monkeypatch.setattr(bench, "ALSO_BUDGET_S", 0.0)
+    out = bench.also_block()
+    assert not calls and all("skipped" in out[k] for k in ("config3", "config5", "config1", "render_image"))
+
+
 def test_pmc_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
     """bench.py quotes a profiles/rNN_traffic_configC.json only when it was collected on the running kernels."""
     import importlib.util
