@@ -16,6 +16,10 @@ gradient all-reduce (N>1), Adam step.  Workloads (BASELINE.json `configs`):
     1  legacy nerf_pl render_rays, coarse only, 256 rays x 64 samples, fp32 (the reference's CPU-runnable case)
 The K timed steps are repeated `--repeats` times back to back (each repeat bracketed by barrier + synchronize);
 `value` comes from the MEDIAN repeat, `ms_per_step_repeats` lists all of them.  Prints ONE JSON line (rank 0).
+With N>1 over RCCL the whole step — forward, backward, gradient all-reduce, Adam — is ONE HIP graph (the collective is
+captured with it; `config.dp_step` says which form ran).  The default single-GPU config-2 run appends an `also` block to
+its line: configs 3, 5, 1 and the eval image loop as short child runs (`--no-also` skips it), so that the one command
+the driver runs measures every single-GPU configuration of BASELINE.json.
 """
 import argparse
 import ctypes
