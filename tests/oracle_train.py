@@ -1,6 +1,6 @@
 """Test infrastructure: one small training run of the CPU oracle (oracle/hypernerf_oracle.py + torch.optim.Adam — the
 reference's training step, train.py:147-163 with utils.get_optimizer's Adam, utils/__init__.py:29-31) next to the same
-run on the HIP path, for the bf16-training-vs-reference PSNR statement (tests/test_gpu_training.py, tools/psnr_vs_oracle.py).
+run on the HIP path, for the bf16-training-vs-reference PSNR statement (tests/test_gpu_training.py, tests/psnr_vs_oracle.py).
 
 Everything a run needs is derived from (seed, sizes): initial weights (hash-filled state dict), the analytic scene,
 the ray batch of every step and its random draws (a seeded torch.Generator on the CPU) — so the CPU worker processes and

@@ -1,8 +1,9 @@
 """bf16 TrainStep against the CPU oracle + torch.optim.Adam (the reference's arithmetic) on the same small scene,
 batches and draws: held-out PSNR of both final parameter sets (same fp32 evaluator), per seed, the gap of the means
-and its standard error.  The CPU runs go to spawned worker processes (they never touch the GPU).
+and its standard error.  The CPU runs go to spawned worker processes (they never touch the GPU).  Lives under tests/
+because it executes the oracle as the checker (only tests/, smoke() and bench.py's cpu_baseline leg may).
 
-    python tools/psnr_vs_oracle.py [steps=300] [rays=64] [nc=16] [nf=16] [seeds=8] [lr=1e-3] [modes=bf16,fp32] [lr_end=0] [freq=1]
+    python tests/psnr_vs_oracle.py [steps=300] [rays=64] [nc=16] [nf=16] [seeds=8] [lr=1e-3] [modes=bf16,fp32] [lr_end=0] [freq=1]
 Prints one JSON line."""
 import json
 import math
@@ -11,7 +12,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]      # ROOT = the repository (this file sits in tests/)
 
 
 def main():

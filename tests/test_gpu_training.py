@@ -187,7 +187,7 @@ def test_bf16_training_psnr_vs_cpu_oracle():
     (chaotic trajectories), so with 8 seeds the standard error of the mean gap is ~0.15 dB: the test
     asserts what 8 seeds can carry — the mean gap is statistically compatible with the 0.1 dB bound (|mean| <= 0.1 +
     2 s.e.), no seed is off by more than 2 dB, both sides learned — and prints the numbers; the 64-seed run of the same
-    harness (tools/psnr_vs_oracle.py, profiles/r04_psnr_vs_oracle_64seeds.json) is the tight statement."""
+    harness (tests/psnr_vs_oracle.py, profiles/r04_psnr_vs_oracle_64seeds.json) is the tight statement."""
     import torch.multiprocessing as mp
     import oracle_train as OT
     steps, b, nc, nf, n_seeds, lr, lr_end, freq, noise = 400, 128, 16, 16, 8, 1e-3, 1e-4, 0.5, 0.5
