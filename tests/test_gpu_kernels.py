@@ -16,6 +16,7 @@ from hypernerf_torch_amd.hypernerf import model_utils as MU
 from oracle import hypernerf_oracle as O
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rho(i, h):
@@ -377,3 +378,21 @@ def test_model_draws_are_one_launch_and_reproducible():
         x = m(rays, {}, rng=rng)
         y = m(rays, {}, rng=rng)
     assert torch.equal(x["fine"]["rgb"], y["fine"]["rgb"])
+
+
+def test_ls_bench_handoff_pipeline_checks_out():
+    """tools/ls_bench.hip (round 4, step A: a persistent pipeline of workgroups, each keeping one layer's W^T and dW in
+    registers and handing dZ to the next CU through a ring — write-through `sc1` stores, `sc1` LDS-DMA loads, published /
+    consumed counters) checks every word of its result against plain reference kernels.  Run here at a small size in
+    the cross-XCD and the XCD-local form so that the hand-off recipe DESIGN.md section 8.0 documents stays a tested one
+    (the timing is the tool's business, not this test's)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "ls_bench")
+    if not os.path.exists(exe):
+        from hypernerf_torch_amd import _lib
+        subprocess.run([_lib.hipcc_path(), "--offload-arch=gfx950", "-O3", "-o", exe, exe + ".hip"], check=True,
+                       capture_output=True, timeout=300)
+    for args in (["131072", "3", "2", "2", "85", "16", "1"], ["262144", "8", "2", "2", "32", "16", "1"],
+                 ["262144", "8", "2", "4", "32", "16", "1"], ["131072", "8", "2", "3", "32", "16", "1"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and "check ok" in out.stdout and "SPIN TIMEOUT" not in out.stdout, (args, out.stdout[-600:])
