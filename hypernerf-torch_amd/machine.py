@@ -651,9 +651,27 @@ class Program:
     @staticmethod
     def _wave_grid(n_nt: int, n_kt: int) -> Tuple[int, int]:
         """(gn, gk), gn*gk <= 8 waves, every wave's rectangle <= 4x2 tiles."""
-        if n_nt <= 4:
-            return 1, min(8, max(1, n_kt)) if n_kt <= 8 else 8
-        return 2, 4
+        if WGRAD_GRID == 0:         # rounds 1-3: one row of waves for <= 4 dZ tiles (a 4x4 job runs on 4 of its 8 waves)
+            if n_nt <= 4:
+                return 1, min(8, max(1, n_kt)) if n_kt <= 8 else 8
+            return 2, 4
+        # round 4: as many ACTIVE waves as the rectangle admits (a wave without a tile only issues DMA; with one
+        # active wave per SIMD nothing hides its LDS read latencies), then the smallest rectangle per wave, then the
+        # fewest operand tiles read per block over all waves
+        best = None
+        for gn in range(1, 9):
+            for gk in range(1, 8 // gn + 1):
+                if gn > n_nt or gk > n_kt:
+                    continue
+                tn, tk = -(-n_nt // gn), -(-n_kt // gk)
+                if tn > 4 or tk > 2:
+                    continue
+                key = (-(gn * gk), tn * tk, gn * gk * (tn + tk))
+                if best is None or key < best[0]:
+                    best = (key, gn, gk)
+        if best is None:
+            raise NotImplementedError(f"no wave grid for a {n_nt} x {n_kt} tile rectangle")
+        return best[1], best[2]
 
     def wgrad_jobs(self, mode: int, n_points: int, target_jobs: int = 512,
                    grad_offsets: Optional[Sequence[int]] = None, job_bytes: Optional[int] = None) -> np.ndarray:
@@ -741,6 +759,7 @@ def wgrad_mode_word(mode: int) -> int:
     return mode | (DZ_SCALE_LOG2 << 8) if mode == L.HN_MODE_BF16_S8 else mode
 
 
+WGRAD_GRID = int(os.environ.get("HN_WGRAD_GRID", 1))       # 0: the wave grids of rounds 1-3 (Program._wave_grid)
 WGRAD_TAIL_FRAC = float(os.environ.get("HN_WGRAD_TAIL_FRAC", 0.4))   # lightest 40 % of the jobs are halved: -1.8 % step time at config 2
 WGRAD_TAIL_PARTS = int(os.environ.get("HN_WGRAD_TAIL_PARTS", 2))
 WGRAD_JOB_BYTES = int(float(os.environ.get("HN_WGRAD_JOB_MB", 5)) * (1 << 20))     # stash bytes one job of a batched weight-gradient launch streams (~3 jobs per CU

@@ -3,7 +3,7 @@
 for cfg in "$@"; do
   echo "=== cfg: $cfg"
   env $cfg python -c "import hypernerf_torch_amd._lib as L; L.build(force=True)" || continue
-  env $cfg timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+  env $cfg timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-also 2>&1 | tail -1 | python -c "
 import json,sys
 r=json.loads(sys.stdin.read()); print('ms/step', round(r['ms_per_step'],4), {k: round(v['ms_per_step'],4) for k,v in r['roofline']['per_kernel'].items()})"
 done
