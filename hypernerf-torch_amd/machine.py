@@ -649,9 +649,9 @@ class Program:
         return offs, tot
 
     @staticmethod
-    def _wave_grid(n_nt: int, n_kt: int) -> Tuple[int, int]:
-        """(gn, gk), gn*gk <= 8 waves, every wave's rectangle <= 4x2 tiles."""
-        if WGRAD_GRID == 0:         # rounds 1-3: one row of waves for <= 4 dZ tiles (a 4x4 job runs on 4 of its 8 waves)
+    def _wave_grid(n_nt: int, n_kt: int, one_row: bool = False) -> Tuple[int, int]:
+        """(gn, gk), gn*gk <= 8 waves, every wave's rectangle <= 4x2 tiles.  `one_row`: the grids of rounds 1-3."""
+        if WGRAD_GRID == 0 or one_row:   # one row of waves for <= 4 dZ tiles (a 4x4 job runs on 4 of its 8 waves)
             if n_nt <= 4:
                 return 1, min(8, max(1, n_kt)) if n_kt <= 8 else 8
             return 2, 4
@@ -707,7 +707,10 @@ class Program:
         total_tiles = sum(r[8] + r[9] for r in rects)
         jobs = []
         for (ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias, prt) in rects:
-            gn, gk = self._wave_grid(n_nt, n_kt)
+            # fp32 (parity) mode at full batch sizes is bound by the 16x slower fp32 matrix pipe, not by latencies: there
+            # the extra operand reads of more, smaller wave rectangles cost 6 % on the launch (config 2, same box:
+            # 4.74 -> 5.04 ms), while small batches gain like the bf16 mode (config 1: 0.966 -> 0.750 ms)
+            gn, gk = self._wave_grid(n_nt, n_kt, one_row=(not bf16_like(mode)) and n_points >= 65536)
             bps = max(1, stage_tiles // (n_nt + n_kt))
             nstage = -(-nblk // bps)
             if job_bytes is not None:
