@@ -674,7 +674,8 @@ class Program:
         return best[1], best[2]
 
     def wgrad_jobs(self, mode: int, n_points: int, target_jobs: int = 512,
-                   grad_offsets: Optional[Sequence[int]] = None, job_bytes: Optional[int] = None) -> np.ndarray:
+                   grad_offsets: Optional[Sequence[int]] = None, job_bytes: Optional[int] = None,
+                   launch_bytes: Optional[float] = None) -> np.ndarray:
         """One job per (layer input segment, tile rectangle, block chunk).  The chunks are sized so that the
         launch is about `target_jobs` workgroups of equal stash bytes — or, with `job_bytes`, so that every job
         streams about that many bytes (the batched launch mixes the jobs of several programs)."""
@@ -715,7 +716,22 @@ class Program:
             nstage = -(-nblk // bps)
             if job_bytes is not None:
                 tile_bytes = mode_consts(mode)[1]
-                share = max(1, min(nstage, round((n_nt + n_kt) * nblk * tile_bytes / job_bytes)))
+                # a job ends with the flush of its dW rectangle by float atomics, which a CU retires at ~5 GB/s (one
+                # 256-B wave-instruction per ~50 ns: MI355X_MICROARCH.md) while it streams at ~21 GB/s: an 8 x 8
+                # rectangle (256 KiB) costs 51 us per job — 22 % on top of a 5-MiB job's stream —, a 4 x 4 one 13 us.
+                # Jobs of big rectangles therefore stream as much as one CU's share of the whole launch allows (ONE
+                # flush per CU and rectangle; measured at config 2, same box: 12.5-15 MiB jobs 0.661-0.668 ms against
+                # 0.717-0.725 ms with 5 MiB, 20 MiB 0.835 ms: one job longer than the launch), jobs of small ones
+                # fewer (they fill the tail of the launch): WGRAD_JOB_SCALE / `launch_bytes`
+                big, small = n_nt * n_kt >= 48, n_nt * n_kt < 12
+                if WGRAD_JOB_SCALE is not None:
+                    jb = job_bytes * WGRAD_JOB_SCALE[0 if big else (2 if small else 1)]
+                elif big:
+                    share_cu = (launch_bytes if launch_bytes else total_tiles * nblk * tile_bytes) / N_CUS
+                    jb = min(max(0.85 * share_cu, job_bytes), 8.0 * job_bytes)
+                else:
+                    jb = job_bytes * (0.5 if small else 1.0)
+                share = max(1, min(nstage, round((n_nt + n_kt) * nblk * tile_bytes / jb)))
             else:
                 share = max(1, min(nstage, round(target_jobs * (n_nt + n_kt) / total_tiles)))
             # split the stages as evenly as possible over `share` jobs
@@ -762,6 +778,12 @@ def wgrad_mode_word(mode: int) -> int:
     return mode | (DZ_SCALE_LOG2 << 8) if mode == L.HN_MODE_BF16_S8 else mode
 
 
+# job size relative to WGRAD_JOB_BYTES for rectangles of >= 48 / >= 12 / fewer tiles (see wgrad_jobs)
+# HN_WGRAD_JOB_SCALE="a,b,c" pins them (A/B runs: "1,1,1" = rounds 1-3); default: sized from the launch's bytes
+WGRAD_JOB_SCALE = (tuple(float(x) for x in os.environ["HN_WGRAD_JOB_SCALE"].split(","))
+                   if os.environ.get("HN_WGRAD_JOB_SCALE") else None)
+N_CUS = 256                      # MI355X
+_LAUNCH_BYTES = [0.0]            # stash bytes of the last batched weight-gradient launch (all its programs)
 WGRAD_GRID = int(os.environ.get("HN_WGRAD_GRID", 1))       # 0: the wave grids of rounds 1-3 (Program._wave_grid)
 WGRAD_TAIL_FRAC = float(os.environ.get("HN_WGRAD_TAIL_FRAC", 0.4))   # lightest 40 % of the jobs are halved: -1.8 % step time at config 2
 WGRAD_TAIL_PARTS = int(os.environ.get("HN_WGRAD_TAIL_PARTS", 2))
@@ -797,6 +819,10 @@ def launch_pending_wgrads(pending: Sequence[PendingWgrad]):
     by_mode: Dict[int, List[PendingWgrad]] = {}
     for p in pending:
         by_mode.setdefault(p.mode, []).append(p)
+    if pending:
+        # what the NEXT backward pass sizes its jobs by (Program.wgrad_jobs: one big-rectangle job ~ one CU's share of
+        # the launch); shapes repeat from step to step, and a captured step has run eagerly before its capture
+        _LAUNCH_BYTES[0] = float(sum(int(p.weights.sum()) * mode_consts(p.mode)[1] for p in pending if p.bucket == 0))
     for mode, lst in by_mode.items():
         lst.sort(key=lambda p: -p.n_jobs)
         for i in range(0, len(lst), L.HN_MAX_WGRAD_BATCH):
@@ -1024,10 +1050,14 @@ class MlpRunner:
         goffs = tuple(grad_target[1]) if grad_target is not None else None
         deferred = defer and grad_target is not None
         split = WGRAD_SPLIT_OFFSET if deferred else None
-        jkey = (str(device), mode, n_points, goffs, deferred, split)
+        # the launch's bytes as of the last batched launch, in steps of 2^(1/4) (job tables are cached per step)
+        hint = _LAUNCH_BYTES[0] if deferred else 0.0
+        qh = round(4.0 * math.log2(hint)) if hint > 0 else 0
+        jkey = (str(device), mode, n_points, goffs, deferred, split, qh)
         if jkey not in self._jobs:
             jobs = self.prog.wgrad_jobs(mode, n_points, grad_offsets=goffs,
-                                        job_bytes=self._job_bytes(mode) if deferred else None)
+                                        job_bytes=self._job_bytes(mode) if deferred else None,
+                                        launch_bytes=(2.0 ** (qh / 4.0)) if qh else None)
             parts = [jobs]
             if split is not None:
                 # the held bucket runs as a launch of its own, next to the all-reduce of the first: it holds ~1/6 of
