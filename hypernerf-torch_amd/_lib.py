@@ -95,7 +95,8 @@ FEAT_DT = np.dtype([("packed", "<i4"), ("freq", "<f4")])
 DWJOB_DT = np.dtype([("z_off", "<u8"), ("x_off", "<u8"), ("z_nt", "<i4"), ("x_nt", "<i4"), ("z_t0", "<i4"),
                      ("x_t0", "<i4"), ("n_nt", "<i4"), ("n_kt", "<i4"), ("blk0", "<i4"), ("blk1", "<i4"),
                      ("w_off", "<i4"), ("ld", "<i4"), ("r0", "<i4"), ("c0", "<i4"), ("r_end", "<i4"),
-                     ("c_end", "<i4"), ("b_off", "<i4"), ("pad", "<i4")])
+                     ("c_end", "<i4"), ("b_off", "<i4"), ("pad", "<i4"), ("x2_off", "<u8"), ("x2_nt", "<i4"),
+                     ("x2_t0", "<i4"), ("n_kt1", "<i4"), ("pad2", "<i4")])
 
 EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
            "hn_mlp_wgrad_batched", "hn_mlp_workspace_bytes",

@@ -1344,8 +1344,8 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   // sbase[i] + (first block of the stage) * sstride[i]  to  stage buffer + sdst[i], if sblk[i] < blocks in stage.
   constexpr int MAXSLOT = 8;                     // <= 32 units per stage / 8 waves... (fp32 tiles: 4 units each)
   unsigned long long sbase[MAXSLOT];
-  int sinfo[MAXSLOT];          // block index inside the stage << 1 | (dZ tile ? 1 : 0) ; huge = unused slot
-  const unsigned zstride = (unsigned)(jb.z_nt * TB), xstride = (unsigned)(jb.x_nt * TB);
+  int sinfo[MAXSLOT];          // block index inside the stage << 2 | kind (0: X slot 1, 1: dZ, 2: X slot 2) ; huge = unused slot
+  const unsigned zstride = (unsigned)(jb.z_nt * TB), xstride = (unsigned)(jb.x_nt * TB), x2stride = (unsigned)(jb.x2_nt * TB);
   int per_stage = 0;
 #pragma unroll
   for (int i = 0; i < MAXSLOT; ++i) {
@@ -1356,10 +1356,13 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
       const int bi = q / UB, r = q % UB;
       const int tile = r / TU, u = r % TU;
       const bool isz = tile < jb.n_nt;
+      const int kt = tile - jb.n_nt;                  // k-tile: the first n_kt1 from X slot 1, the rest from X slot 2
+      const bool isx2 = !isz && kt >= jb.n_kt1;
       const unsigned long long rel = isz ? ((unsigned long long)bi * jb.z_nt + jb.z_t0 + tile) * TB
-                                         : ((unsigned long long)bi * jb.x_nt + jb.x_t0 + (tile - jb.n_nt)) * TB;
-      sbase[i] = (isz ? jb.z_off : jb.x_off) + rel + (unsigned long long)u * 1024;
-      sinfo[i] = bi << 1 | (isz ? 1 : 0);
+                                   : isx2 ? ((unsigned long long)bi * jb.x2_nt + jb.x2_t0 + (kt - jb.n_kt1)) * TB
+                                          : ((unsigned long long)bi * jb.x_nt + jb.x_t0 + kt) * TB;
+      sbase[i] = (isz ? jb.z_off : (isx2 ? jb.x2_off : jb.x_off)) + rel + (unsigned long long)u * 1024;
+      sinfo[i] = bi << 2 | (isz ? 1 : (isx2 ? 2 : 0));
       ++per_stage;
     }
   }
@@ -1369,8 +1372,9 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     const int nblk_s = min(bps, jb.blk1 - b0);
 #pragma unroll
     for (int i = 0; i < MAXSLOT; ++i) {
-      if ((sinfo[i] >> 1) < nblk_s) {
-        const char* src = stash + sbase[i] + (unsigned long long)b0 * ((sinfo[i] & 1) ? zstride : xstride);
+      if ((sinfo[i] >> 2) < nblk_s) {
+        const unsigned kind = sinfo[i] & 3;
+        const char* src = stash + sbase[i] + (unsigned long long)b0 * (kind == 1 ? zstride : (kind == 2 ? x2stride : xstride));
 #ifndef HN_WGRAD_AUX
 #define HN_WGRAD_AUX 2      /* nt: every stash byte is read once, do not keep it in L2 / MALL */
 #endif
@@ -1390,7 +1394,7 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   int last_cnt = 0;
 #pragma unroll
   for (int i = 0; i < MAXSLOT; ++i)
-    if ((sinfo[i] >> 1) < nb_last) ++last_cnt;
+    if ((sinfo[i] >> 2) < nb_last) ++last_cnt;
 #ifdef HN_PROF   // diagnostic build: wave 0 of every 97th workgroup sums the cycles of its four phases per stage
   long long* prof_buf = (long long*)tab.b[HN_MAX_WGRAD_BATCH - 1].jobs;     // set by hn_set_wgrad_prof
   const bool prof_on = prof_buf != nullptr && tab.n < HN_MAX_WGRAD_BATCH && (blockIdx.x % 97) == 0 && wave == 0;

@@ -693,6 +693,14 @@ class Program:
             if ly.aux is not None:
                 segs.append((offs[ly.aux.slot][0], 2 * ly.aux.groups, ly.aux_c0, ly.aux.n))
             z_off = offs[ly.dz_slot][0]
+            # a skip layer's two input segments (running activation | re-appended encoder input) as ONE rectangle
+            # with two X slots when it fits a job (<= 8 k-tiles): its dZ tiles are then read once, not once per
+            # segment (round 4: the launch is HBM-bound, every byte counts — 3.6 % of its reads at config 2)
+            x2 = None
+            if (WGRAD_FUSE_SEGS and bf16_like(mode) and len(segs) == 2 and segs[0][2] == 0 and segs[0][3] % 32 == 0
+                    and segs[1][2] == segs[0][3] and segs[0][3] // 32 + (segs[1][3] + 31) // 32 <= tmax):
+                x2 = (segs[1][0], segs[1][1], segs[0][3] // 32)          # (offset, tiles per block, k-tiles of slot 1)
+                segs = [(segs[0][0], segs[0][1], 0, segs[0][3] + segs[1][3])]
             first = True
             for (x_off, x_nt, c0, ncols) in segs:
                 k_tiles = (ncols + 31) // 32
@@ -703,11 +711,11 @@ class Program:
                         for kt0 in range(0, k_tiles, tmax):
                             n_kt = min(tmax, k_tiles - kt0)
                             with_bias = first and kt0 == 0 and prt[1] >= 0
-                            rects.append((ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias, prt))
+                            rects.append((ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias, prt, x2))
                 first = False
         total_tiles = sum(r[8] + r[9] for r in rects)
         jobs = []
-        for (ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias, prt) in rects:
+        for (ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias, prt, x2) in rects:
             # fp32 (parity) mode at full batch sizes is bound by the 16x slower fp32 matrix pipe, not by latencies: there
             # the extra operand reads of more, smaller wave rectangles cost 6 % on the launch (config 2, same box:
             # 4.74 -> 5.04 ms), while small batches gain like the bf16 mode (config 1: 0.966 -> 0.750 ms)
@@ -742,7 +750,8 @@ class Program:
                     c_end = min(c0 + ncols, ly.in_features)      # window layers: the matrix is narrower than cur
                     jobs.append((z_off, x_off, ly.nt, x_nt, nt0, kt0, n_nt, n_kt, b0, b1,
                                  goffs[prt[0]], ly.in_features, 32 * nt0 - prt[2], c0 + 32 * kt0, prt[3], c_end,
-                                 goffs[prt[1]] if with_bias else -1, gn | gk << 8 | bps << 16))
+                                 goffs[prt[1]] if with_bias else -1, gn | gk << 8 | bps << 16)
+                                + ((x2[0], x2[1], 0, x2[2], 0) if x2 is not None else (0, 0, 0, n_kt, 0)))
         # heaviest jobs first: the tail of the launch is then made of short jobs
         jobs.sort(key=lambda j: -(j[6] + j[7]) * (j[9] - j[8]))
         if job_bytes is not None and WGRAD_TAIL_FRAC > 0.0:
@@ -784,6 +793,7 @@ WGRAD_JOB_SCALE = (tuple(float(x) for x in os.environ["HN_WGRAD_JOB_SCALE"].spli
                    if os.environ.get("HN_WGRAD_JOB_SCALE") else None)
 N_CUS = 256                      # MI355X
 _LAUNCH_BYTES = [0.0]            # stash bytes of the last batched weight-gradient launch (all its programs)
+WGRAD_FUSE_SEGS = int(os.environ.get("HN_WGRAD_FUSE_SEGS", 1))     # 0: one job per input segment of a skip layer (rounds 1-3)
 WGRAD_GRID = int(os.environ.get("HN_WGRAD_GRID", 1))       # 0: the wave grids of rounds 1-3 (Program._wave_grid)
 WGRAD_TAIL_FRAC = float(os.environ.get("HN_WGRAD_TAIL_FRAC", 0.4))   # lightest 40 % of the jobs are halved: -1.8 % step time at config 2
 WGRAD_TAIL_PARTS = int(os.environ.get("HN_WGRAD_TAIL_PARTS", 2))

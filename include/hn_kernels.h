@@ -207,7 +207,10 @@ typedef struct {
 /* weight-gradient job: one workgroup (8 waves) accumulates the dW tile grid n_nt x n_kt of one Linear input
  * segment over a block range; pad = gn | gk<<8 | bps<<16: gn x gk (<= 8 waves) is the wave grid, each wave
  * owns a ceil(n_nt/gn) x ceil(n_kt/gk) (<= 4x2) tile rectangle; bps = point blocks per LDS stage
- * (bps * (n_nt+n_kt) tiles <= 32 KiB).  n_nt, n_kt <= 8 tiles (bf16) / 4 tiles (fp32). */
+ * (bps * (n_nt+n_kt) tiles <= 32 KiB).  n_nt, n_kt <= 8 tiles (bf16) / 4 tiles (fp32).
+ * The k-tiles may come from TWO stash slots (a skip layer's running activation followed by its re-appended encoder
+ * input, hypernerf/modules.py:122-124): tiles 0 .. n_kt1-1 from (x_off, x_nt, x_t0), the rest from (x2_off, x2_nt,
+ * x2_t0) — one job, one read of the dZ tiles, instead of one job per segment.  n_kt1 == n_kt: one slot. */
 typedef struct {
   uint64_t z_off, x_off;  /* stash byte offsets (block 0) of dZ and X slots */
   int32_t z_nt, x_nt;     /* tiles per block of the two slots */
@@ -221,6 +224,10 @@ typedef struct {
   int32_t r_end, c_end;   /* valid bounds */
   int32_t b_off;          /* offset of the bias gradient or -1 (db[r] += sum_p dZ[p][r]) */
   int32_t pad;
+  uint64_t x2_off;        /* second X slot: stash byte offset (block 0) */
+  int32_t x2_nt, x2_t0;   /* its tiles per block, first tile used */
+  int32_t n_kt1;          /* k-tiles taken from the first X slot (the remaining n_kt - n_kt1 from the second) */
+  int32_t pad2;
 } HnDwJob;
 
 int hn_version(void);

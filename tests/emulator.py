@@ -558,8 +558,11 @@ def run_wgrad(prog, mode, jobs, stash, n_grad):
             for b in range(jb["blk0"], jb["blk1"]):
                 za = [stash.get_tile(int(jb["z_off"]) + (b * jb["z_nt"] + jb["z_t0"] + n0 + i) * tb)
                       for i in range(max(my_n, 0))]
-                xb = [stash.get_tile(int(jb["x_off"]) + (b * jb["x_nt"] + jb["x_t0"] + k0 + j) * tb)
-                      for j in range(max(my_k, 0))]
+                def x_tile(kt):        # k-tiles 0 .. n_kt1-1 from the first X slot, the rest from the second
+                    if kt < jb["n_kt1"]:
+                        return stash.get_tile(int(jb["x_off"]) + (b * jb["x_nt"] + jb["x_t0"] + kt) * tb)
+                    return stash.get_tile(int(jb["x2_off"]) + (b * jb["x2_nt"] + jb["x2_t0"] + kt - jb["n_kt1"]) * tb)
+                xb = [x_tile(k0 + j) for j in range(max(my_k, 0))]
                 for i in range(max(my_n, 0)):
                     for j in range(max(my_k, 0)):
                         if mode.bf16:
