@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* hnStream_t; /* hipStream_t */
 
-#define HN_VERSION 310
+#define HN_VERSION 320   /* 320: HnDwJob carries a second X slot */
 
 /* numeric modes of the MLP machine */
 #define HN_MODE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode (<=1e-4 vs oracle) */
