@@ -1343,9 +1343,13 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   // otherwise cost ~600 scalar instructions per stage): slot i moves 1 KiB from
   // sbase[i] + (first block of the stage) * sstride[i]  to  stage buffer + sdst[i], if sblk[i] < blocks in stage.
   constexpr int MAXSLOT = 8;                     // <= 32 units per stage / 8 waves... (fp32 tiles: 4 units each)
-  unsigned long long sbase[MAXSLOT];
+  // offsets in KiB (every slot offset, tile and unit is a multiple of 1 KiB; 32 bits reach 4 TiB): one register per
+  // DMA slot instead of a 64-bit pair — the fp32 build sits at 256 registers, and a spilled address reloaded inside the
+  // stage loop drains the ring (scratch loads share the in-order vmcnt queue)
+  unsigned sbase[MAXSLOT];
   int sinfo[MAXSLOT];          // block index inside the stage << 2 | kind (0: X slot 1, 1: dZ, 2: X slot 2) ; huge = unused slot
-  const unsigned zstride = (unsigned)(jb.z_nt * TB), xstride = (unsigned)(jb.x_nt * TB), x2stride = (unsigned)(jb.x2_nt * TB);
+  constexpr unsigned TK = (unsigned)(TBc / 1024);      // KiB per tile
+  const unsigned zstride = (unsigned)jb.z_nt * TK, xstride = (unsigned)jb.x_nt * TK, x2stride = (unsigned)jb.x2_nt * TK;
   int per_stage = 0;
 #pragma unroll
   for (int i = 0; i < MAXSLOT; ++i) {
@@ -1358,10 +1362,10 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
       const bool isz = tile < jb.n_nt;
       const int kt = tile - jb.n_nt;                  // k-tile: the first n_kt1 from X slot 1, the rest from X slot 2
       const bool isx2 = !isz && kt >= jb.n_kt1;
-      const unsigned long long rel = isz ? ((unsigned long long)bi * jb.z_nt + jb.z_t0 + tile) * TB
-                                   : isx2 ? ((unsigned long long)bi * jb.x2_nt + jb.x2_t0 + (kt - jb.n_kt1)) * TB
-                                          : ((unsigned long long)bi * jb.x_nt + jb.x_t0 + kt) * TB;
-      sbase[i] = (isz ? jb.z_off : (isx2 ? jb.x2_off : jb.x_off)) + rel + (unsigned long long)u * 1024;
+      const unsigned rel = isz ? ((unsigned)bi * jb.z_nt + jb.z_t0 + tile) * TK
+                         : isx2 ? ((unsigned)bi * jb.x2_nt + jb.x2_t0 + (kt - jb.n_kt1)) * TK
+                                : ((unsigned)bi * jb.x_nt + jb.x_t0 + kt) * TK;
+      sbase[i] = (unsigned)((isz ? jb.z_off : (isx2 ? jb.x2_off : jb.x_off)) >> 10) + rel + (unsigned)u;
       sinfo[i] = bi << 2 | (isz ? 1 : (isx2 ? 2 : 0));
       ++per_stage;
     }
@@ -1374,7 +1378,7 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     for (int i = 0; i < MAXSLOT; ++i) {
       if ((sinfo[i] >> 2) < nblk_s) {
         const unsigned kind = sinfo[i] & 3;
-        const char* src = stash + sbase[i] + (unsigned long long)b0 * (kind == 1 ? zstride : (kind == 2 ? x2stride : xstride));
+        const char* src = stash + ((unsigned long long)(sbase[i] + (unsigned)b0 * (kind == 1 ? zstride : (kind == 2 ? x2stride : xstride))) << 10);
 #ifndef HN_WGRAD_AUX
 #define HN_WGRAD_AUX 2      /* nt: every stash byte is read once, do not keep it in L2 / MALL */
 #endif
