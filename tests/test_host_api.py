@@ -507,7 +507,10 @@ def test_hot_kernels_stay_within_their_register_budget():
               "_Z17hn_mlp_bwd_kernelILb1ELb0ELb0EEv9HnMlpArgs": 0, "_Z17hn_mlp_bwd_kernelILb1ELb1ELb0EEv9HnMlpArgs": 256, "_Z15hn_wgrad_kernelILb1ELb0EEv14HnDwBatchTable": 0,
               # the opt-in 8-bit-stash builds (HN_MODE_BF16_S8)
               "_Z17hn_mlp_fwd_kernelILb1ELi2ELb0ELb1ELb1EEv9HnMlpArgs": 0, "_Z17hn_mlp_fwd_kernelILb1ELi3ELb0ELb1ELb1EEv9HnMlpArgs": 0,
-              "_Z17hn_mlp_bwd_kernelILb1ELb0ELb1EEv9HnMlpArgs": 0, "_Z15hn_wgrad_kernelILb1ELb1EEv14HnDwBatchTable": 0}
+              "_Z17hn_mlp_bwd_kernelILb1ELb0ELb1EEv9HnMlpArgs": 0, "_Z15hn_wgrad_kernelILb1ELb1EEv14HnDwBatchTable": 0,
+              # round 4: the fp32 weight-gradient build reloaded a spilled DMA address inside its stage loop (24-28 B of
+              # scratch since round 2; a scratch reload waits for every LDS-DMA in front of it): offsets in KiB, no scratch
+              "_Z15hn_wgrad_kernelILb0ELb0EEv14HnDwBatchTable": 0}
     for name, max_scratch in bounds.items():
         assert name in info, sorted(info)
         assert info[name]["VGPRs"] <= 256 and info[name]["Occupancy [waves/SIMD]"] == 2, (name, info[name])
