@@ -705,8 +705,10 @@ extern "C" int hn_adam_step(float* params, float* grads, float* exp_avg, float* 
       hyper_dev == nullptr)
     return -3;
   if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return -4;
+  // one block per CU, grid-stride: every thread pays the bias-correction arithmetic (two powf, an rsqrtf) once for ~6
+  // vectors instead of once per vector (2048 blocks: 26.3 us per launch at config 2, 512: 16.5, 256: 15.2)
   long long blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(hn_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                      exp_avg_sq, n, hyper_dev, step_dev, zero_grad);
