@@ -9,8 +9,12 @@ import torch
 import emulator as E
 import hashprng as H
 import hypernerf_torch_amd  # noqa: F401
-from hypernerf_torch_amd.hypernerf import modules, warping
+from hypernerf_torch_amd import _lib as L
+from hypernerf_torch_amd import machine
+from hypernerf_torch_amd.hypernerf import models, modules, warping
 from oracle import hypernerf_oracle as O
+
+EMB = {"warp": list(range(100)), "camera": [0], "appearance": list(range(100)), "time": list(range(100))}
 
 
 def load_hash(module, seed):
@@ -474,3 +478,77 @@ def test_eight_bit_stash_layout_and_transposed_read():
                     assert got[lane].tolist() == [16 * mm + 8 * kg + b for b in range(8)], (mm, lane, got[lane])
                 else:
                     assert set(got[lane].tolist()) == {E.dw8_feature(c)}, (mm, lane, got[lane])
+
+
+@pytest.mark.parametrize("launch_bytes", [None, 3.8e9, 8.5e10])
+def test_wgrad_job_tables_cover_every_tile_product_once(launch_bytes):
+    """Host logic of the batched weight-gradient launch (Program.wgrad_jobs, round 4: wave grids that use every wave a
+    rectangle admits, job sizes that follow the launch's bytes, skip layers' two input segments as one rectangle with two
+    X slots): whatever the sizing, every (layer part, dZ tile, input k-tile, point block) product is computed by exactly
+    ONE job, every bias by exactly one, a job's k-tiles map onto the right stash slot, and every job satisfies the
+    kernel's limits (<= 8 waves, <= 4 x 2 tiles per wave, a stage of `bps` blocks inside 32 / 48 KiB, block ranges
+    aligned to stages)."""
+    m = models.NerfModel(EMB, n_samples_coarse=8, n_samples_fine=8, hyper_slice_method="bendy_sheet",
+                         use_nerf_embed=True, use_alpha_cond=True)
+    progs = [m._level_call("fine").program, warping.SE3Field(in_ch=3)._field_call(True).program]
+    for prog in progs:
+        for mode in (L.HN_MODE_BF16, L.HN_MODE_F32, L.HN_MODE_BF16_S8):
+            for n_points in (196608, 1000):
+                offs, _, _ = prog.layout(mode, n_points)
+                nblk = (n_points + 31) // 32
+                tile_kib = machine.mode_consts(mode)[1] // 1024
+                stage_kib = 48 if mode == L.HN_MODE_BF16_S8 else 32
+                jobs = prog.wgrad_jobs(mode, n_points, job_bytes=machine.WGRAD_JOB_BYTES, launch_bytes=launch_bytes)
+                assert len(jobs) > 0
+                slot_of = {int(o[0]): i for i, o in enumerate(offs)}
+                seen, bias_seen = {}, {}
+                for jb in jobs:
+                    gn, gk, bps = int(jb["pad"]) & 255, (int(jb["pad"]) >> 8) & 255, (int(jb["pad"]) >> 16) & 255
+                    n_nt, n_kt, n_kt1 = int(jb["n_nt"]), int(jb["n_kt"]), int(jb["n_kt1"])
+                    assert 1 <= gn * gk <= 8 and gn <= n_nt and gk <= n_kt
+                    assert -(-n_nt // gn) <= 4 and -(-n_kt // gk) <= 2
+                    assert bps >= 1 and bps * (n_nt + n_kt) * tile_kib <= stage_kib
+                    assert int(jb["blk0"]) % bps == 0 and 0 <= jb["blk0"] < jb["blk1"] <= nblk
+                    assert 1 <= n_kt1 <= n_kt
+                    assert int(jb["x_off"]) in slot_of and int(jb["z_off"]) in slot_of
+                    if n_kt1 < n_kt:
+                        assert int(jb["x2_off"]) in slot_of and jb["x2_t0"] + (n_kt - n_kt1) <= jb["x2_nt"]
+                        assert jb["x_t0"] + n_kt1 <= jb["x_nt"]
+                    else:
+                        assert jb["x_t0"] + n_kt <= jb["x_nt"]
+                    assert jb["z_t0"] + n_nt <= jb["z_nt"]
+                    for i in range(n_nt):
+                        row = int(jb["r0"]) + 32 * i
+                        if row >= jb["r_end"]:
+                            continue
+                        for j in range(n_kt):
+                            col = int(jb["c0"]) + 32 * j
+                            if col >= jb["c_end"]:
+                                continue
+                            key = (int(jb["w_off"]), row, col)
+                            iv = seen.setdefault(key, [])
+                            iv.append((int(jb["blk0"]), int(jb["blk1"])))
+                        if jb["b_off"] >= 0:
+                            bias_seen.setdefault((int(jb["b_off"]), row), []).append((int(jb["blk0"]), int(jb["blk1"])))
+                for table in (seen, bias_seen):
+                    for key, iv in table.items():
+                        iv.sort()
+                        assert iv[0][0] == 0 and iv[-1][1] == nblk, (key, iv[:3])
+                        assert all(a[1] == b[0] for a, b in zip(iv[:-1], iv[1:])), (key, iv[:4])
+                # every weight element of every layer is covered
+                goffs, _ = prog.grad_offsets()
+                for ly in prog.layers:
+                    for (w_id, b_id, row0, rows) in ly.parts:
+                        for rt in range(0, rows, 32):
+                            for ct in range(0, ly.in_features, 32):
+                                assert (goffs[w_id], rt, ct) in seen, (ly.name, rt, ct)
+                            if b_id >= 0:
+                                assert (goffs[b_id], rt) in bias_seen, (ly.name, rt)
+    # the wave grid itself: maximal active waves within the kernel's limits, for every rectangle shape
+    for n_nt in range(1, 9):
+        for n_kt in range(1, 9):
+            gn, gk = machine.Program._wave_grid(n_nt, n_kt)
+            assert gn * gk <= 8 and -(-n_nt // gn) <= 4 and -(-n_kt // gk) <= 2
+            best = max(a * b for a in range(1, 9) for b in range(1, 8 // a + 1)
+                       if a <= n_nt and b <= n_kt and -(-n_nt // a) <= 4 and -(-n_kt // b) <= 2)
+            assert gn * gk == best, (n_nt, n_kt, gn, gk, best)
