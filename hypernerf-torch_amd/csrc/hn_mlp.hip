@@ -981,31 +981,41 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
       } else if (code == HN_BOP_AUX) {
         // gradient of generated features: per 32-feature tile tmp = W_aux^T . dZ, then the chain rule
         const int K32 = w[1] & 255, K32b = (w[1] >> 8) & 255, nG = (w[1] >> 16) & 255;
+        // w2: bit tt = tile tt holds a feature that differentiates into a source (the others are neither in the weight
+        // stream nor computed: encoders of plain inputs in front of a GLO row, padding); bit 8 + tt = one of them is
+        // trigonometric (a tile of identity features only — GLO rows — takes W^T dZ as it is: d feature / dx = 1)
+        const int tiles = w[2];
+        bool first = true;
+        mnext_ready = false;
         for (int tt = 0; tt < 2 * nG; ++tt) {
+          if (!((tiles >> tt) & 1)) continue;
           f32x16 acc;
           hn_init_acc(acc, nullptr, 0, h);
           hn_gemm_k<BF16>(acc, cur, K32, ws);
           if (K32b) hn_gemm_blocks<BF16, 1>(acc, cur2, ws);
-          if (tt == 0) mnext_ready = hn_prefetch_masks(a, w_next, blk, lane, wave_valid, mnext);
+          if (first) mnext_ready = hn_prefetch_masks(a, w_next, blk, lane, wave_valid, mnext);
+          first = false;
           // chain rule per feature, then the reduction over the features of each source component as one more
           // matrix product: dacc[slot][point] += S[slot][feature] . G[feature][point]  (S: 0/1 selection block that
           // the host put in the weight stream right behind this tile's weights).  No LDS accumulators: an LDS
           // atomic after an LDS-DMA makes the compiler drain vmcnt, i.e. the weight prefetch.
           const HnFeat* ft = feat_lds + w[3] + 32 * tt;
-          if constexpr (BF16) {
-            // accumulator register i is feature rho(i, h): four runs of 4 consecutive table entries
-            const HnDFeat* dft = dfeat_lds + w[3] + 32 * tt + 4 * h;
-            const char* srcv_r = reinterpret_cast<const char*>(srcv) + 4 * r;
+          if ((tiles >> (8 + tt)) & 1) {
+            if constexpr (BF16) {
+              // accumulator register i is feature rho(i, h): four runs of 4 consecutive table entries
+              const HnDFeat* dft = dfeat_lds + w[3] + 32 * tt + 4 * h;
+              const char* srcv_r = reinterpret_cast<const char*>(srcv) + 4 * r;
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-              float g[4];
-              hn_feature_grads4(dft + 8 * q4, srcv_r, g);
+              for (int q4 = 0; q4 < 4; ++q4) {
+                float g[4];
+                hn_feature_grads4(dft + 8 * q4, srcv_r, g);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[4 * q4 + e] *= g[e];
+                for (int e = 0; e < 4; ++e) acc[4 * q4 + e] *= g[e];
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) acc[i] *= hn_feature_grad<BF16>(ft[hn_rho(i, h)], srcv, r);
             }
-          } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] *= hn_feature_grad<BF16>(ft[hn_rho(i, h)], srcv, r);
           }
           Frag gfr[M::STEPS32];
           hn_acc_to_frags(acc, gfr);

@@ -412,6 +412,21 @@ class Program:
             return []
         return [g for g in range(ly.aux.groups) if any(f.need_grad for f in ly.aux.feats[64 * g:64 * g + 64])]
 
+    @staticmethod
+    def _aux_tile_word(ly: Layer, g: int) -> int:
+        """w2 of an HN_BOP_AUX op: bit tt = 32-feature tile tt of the group holds a feature with a gradient (only those
+        tiles are in the backward weight stream and computed: the encoder of a plain input in front of a GLO row and the
+        padding behind it cost a W^T dZ product and 16 sines per lane each — 7 of the 22 tiles of a config-2 level),
+        bit 8 + tt = one of them is trigonometric (identity-only tiles skip the chain-rule factor, which is 1)."""
+        word = 0
+        for tt in range(2):
+            fts = [f for f in ly.aux.feats[64 * g + 32 * tt:64 * g + 32 * tt + 32] if f.need_grad]
+            if fts or not AUX_TILE_SKIP:
+                word |= 1 << tt
+            if any(f.kind not in (L.HN_FEAT_ID, L.HN_FEAT_ZERO) for f in fts) or AUX_TILE_SKIP < 2:
+                word |= 256 << tt
+        return word
+
     def _build_bwd_ops(self) -> np.ndarray:
         """Reverse walk, chain by chain (last chain first).  Records, next to the ops, the weight blocks each op
         streams (self.bwd_plan)."""
@@ -435,8 +450,8 @@ class Program:
         def emit_aux(ly: Layer, from2: bool):
             for g in self._aux_grad_groups(ly):
                 k32 = 0 if from2 else ly.nt
-                ops.append([L.HN_BOP_AUX, k32 | (1 if from2 else 0) << 8 | 1 << 16, 0, ly.aux.feat_off + 64 * g,
-                            0, 0, 0, 0])
+                ops.append([L.HN_BOP_AUX, k32 | (1 if from2 else 0) << 8 | 1 << 16, self._aux_tile_word(ly, g),
+                            ly.aux.feat_off + 64 * g, 0, 0, 0, 0])
                 plan.append(("aux", ly, g, from2))
 
         for items in reversed(self.chains()):
@@ -527,6 +542,8 @@ class Program:
             elif step[0] == "aux":
                 _, ly, g, from2 = step
                 for tt in range(2):
+                    if not (self._aux_tile_word(ly, g) >> tt) & 1:
+                        continue
                     c0 = ly.aux_c0 + 64 * g + 32 * tt
                     if not from2:
                         pos, ctr = self._take(ctr, ly.nt * u32)
@@ -792,6 +809,9 @@ def wgrad_mode_word(mode: int) -> int:
 WGRAD_JOB_SCALE = (tuple(float(x) for x in os.environ["HN_WGRAD_JOB_SCALE"].split(","))
                    if os.environ.get("HN_WGRAD_JOB_SCALE") else None)
 N_CUS = 256                      # MI355X
+# backward feature-gradient ops: 2 = only tiles with a differentiable feature, no chain-rule factor on identity-only tiles;
+# 1 = only the tile skip; 0 = every tile of a group with a gradient (rounds 1-3)
+AUX_TILE_SKIP = int(os.environ.get("HN_AUX_TILE_SKIP", 2))
 _LAUNCH_BYTES = [0.0]            # stash bytes of the last batched weight-gradient launch (all its programs)
 WGRAD_FUSE_SEGS = int(os.environ.get("HN_WGRAD_FUSE_SEGS", 1))     # 0: one job per input segment of a skip layer (rounds 1-3)
 WGRAD_GRID = int(os.environ.get("HN_WGRAD_GRID", 1))       # 0: the wave grids of rounds 1-3 (Program._wave_grid)

@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* hnStream_t; /* hipStream_t */
 
-#define HN_VERSION 320   /* 320: HnDwJob carries a second X slot */
+#define HN_VERSION 321   /* 320: HnDwJob carries a second X slot; 321: HN_BOP_AUX w2 = tile word */
 
 /* numeric modes of the MLP machine */
 #define HN_MODE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode (<=1e-4 vs oracle) */
@@ -92,7 +92,9 @@ typedef void* hnStream_t; /* hipStream_t */
 /* gradient w.r.t. GENERATED input features: per 32-feature tile of nG*64 features,
  * tmp = W_aux^T . (cur | cur2), then the chain rule through the feature table into the per-point
  * source-gradient accumulators (LDS), written to `dsrc` at the end of the program.               */
-#define HN_BOP_AUX 4       /* w1 = K32 | K32b<<8 | nG<<16 ; w3=feat_off                            */
+#define HN_BOP_AUX 4       /* w1 = K32 | K32b<<8 | nG<<16 ; w3=feat_off ; w2 = tile word: bit tt = tile tt (of 2*nG) holds
+                              a feature with a gradient — only those tiles are in the weight stream and computed —,
+                              bit 8+tt = one of them is trigonometric (else d feature / dx = 1, no factor applied)  */
 
 /* feature table entry (8 bytes).  value(p) = kind(freq * x), x = staged source component `ci` of point p.
  * The distinct (source, column) pairs a program reads are listed once in HnMlpArgs.comps; every workgroup

@@ -514,6 +514,8 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
             elif code == 4:
                 k32, k32b, ng = w[1] & 255, (w[1] >> 8) & 255, (w[1] >> 16) & 255
                 for tt in range(2 * ng):
+                    if not (w[2] >> tt) & 1:       # no feature of this tile has a gradient: not in the stream either
+                        continue
                     acc = np.zeros((64, 16))
                     acc = gemm_blocks(mode, acc, ws, cur, k32)
                     if k32b:
@@ -523,7 +525,8 @@ def run_backward(prog, mode, tables, params, srcs, n_points, spr, stash):
                     for l in range(64):
                         for i in range(16):
                             e = ft[rho(i, l >> 5)]
-                            G[l, i] = acc[l, i] * feature_grad(e, srcs, p[l], ray[l])
+                            # identity-only tiles (bit 8 + tt clear) take W^T dZ as it is
+                            G[l, i] = acc[l, i] * (feature_grad(e, srcs, p[l], ray[l]) if (w[2] >> (8 + tt)) & 1 else 1.0)
                     # dacc[slot][point] += S[slot][feature] . G[feature][point]  (selection units of the stream)
                     sel = ws.take(mode.units32)
                     dacc = mma_block32(mode, dacc, sel, acc_to_frags(mode, G))
