@@ -8,9 +8,35 @@ other work) and then replays it.  Inputs must live in fixed tensors that the cal
 """
 from __future__ import annotations
 
+import os
+import time
 from typing import Callable, Optional
 
 import torch
+
+
+def _capture_mode() -> str:
+    """How the capture treats HIP calls of OTHER threads.  With a torch.distributed process group alive its watchdog
+    thread polls the events of collectives that were enqueued eagerly (the warm-up runs' all-reduces) with
+    hipEventQuery every ~100 ms; under the default "global" mode such a call from any thread while a capture is open
+    fails with hipErrorStreamCaptureUnsupported, the watchdog rethrows and the process aborts (seen on the MI355X in
+    one of three `bench.py --force-dp` runs, round 4).  "thread_local" confines the restriction to the capturing
+    thread — the only one that launches work here."""
+    dist = torch.distributed
+    forced = os.environ.get("HN_CAPTURE_MODE")           # diagnosis only: "global" reproduces the abort
+    if forced:
+        return forced
+    return "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+
+
+def _quiesce_collectives():
+    """Before a capture: let every eagerly enqueued collective finish and give the process group's watchdog one poll
+    period to retire it from its list, so that it has nothing to query while the capture is open (second line of
+    defence next to _capture_mode)."""
+    torch.cuda.synchronize()
+    dist = torch.distributed
+    if dist.is_available() and dist.is_initialized() and os.environ.get("HN_CAPTURE_QUIESCE", "1") != "0":
+        time.sleep(0.25)
 
 
 class GraphedStep:
@@ -29,10 +55,10 @@ class GraphedStep:
                 for _ in range(max(1, warmup)):
                     (warmup_fn or fn)()
             torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        _quiesce_collectives()
         self.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self.graph, pool=pool):
+            with torch.cuda.graph(self.graph, pool=pool, capture_error_mode=_capture_mode()):
                 self.out = fn()
         except BaseException:
             # an operation that cannot be captured (a host-staged collective, a synchronising copy) invalidates the

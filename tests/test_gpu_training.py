@@ -401,6 +401,58 @@ def _rccl_one_rank_worker(port, q):
         dist.destroy_process_group()
 
 
+def _capture_beside_watchdog_worker(port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from hypernerf_torch_amd.graphs import GraphedStep, _capture_mode
+        buf = torch.ones(1 << 20, device="cuda")
+        acc = torch.zeros(1 << 20, device="cuda")
+
+        def body():
+            dist.all_reduce(buf)
+            acc.add_(buf)
+        n = 0
+        for _ in range(8):
+            # eager collectives right up to the capture: their works are still on the watchdog's list when it opens
+            for _ in range(16):
+                dist.all_reduce(buf)
+            g = GraphedStep(body, warmup=1, mutates_params=False)
+            for _ in range(3):
+                g()
+            n += 1
+        torch.cuda.synchronize()
+        q.put({"captures": n, "mode": _capture_mode(), "acc": float(acc[0])})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_graph_capture_survives_the_process_group_watchdog():
+    """ProcessGroupNCCL's watchdog thread polls the events of eagerly enqueued collectives (hipEventQuery, every ~100 ms).
+    Under the default "global" capture mode that query, made while the main thread has a capture open, fails with
+    hipErrorStreamCaptureUnsupported, the watchdog rethrows and the whole rank aborts — one of three `bench.py --force-dp`
+    runs died that way on the MI355X (round 4), i.e. an 8-rank job would hardly ever have started.  GraphedStep now
+    captures in "thread_local" mode whenever a process group is alive and first lets the watchdog retire what was
+    enqueued eagerly.  Eight captures, each directly behind 16 eager all-reduces, in one process."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_capture_beside_watchdog_worker, args=(_free_port(), q))
+    p_.start()
+    try:
+        res = q.get(timeout=300)
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    finally:
+        if p_.is_alive():
+            p_.kill()
+    assert res["captures"] == 8 and res["mode"] == "thread_local"
+    assert res["acc"] == 8 * (1 + 3)        # per capture: one eager warm-up run + three replays (the capture pass does not execute)
+
+
 def test_one_rank_rccl_step_is_one_graph_with_the_all_reduce_inside():
     """N>1 readiness on one GPU: with the nccl (= RCCL) backend the data-parallel step — forward, backward, in-place SUM
     all-reduce of the gradient arena, Adam — is captured as ONE HIP graph (the collective's kernel is recorded like any
