@@ -101,6 +101,10 @@ def _worker(rank, world, port, q):
         tb.grad.fill_(1.0)
         s2.reduce(lambda: tb.grad.add_(float(rank)))
         ok = ok and s2.split is None and torch.allclose(tb.grad, torch.full((tb.numel,), 3.0))
+        # a graph capture next to a live process group must not bind other threads (the group's watchdog polls events
+        # while the capture is open: graphs._capture_mode, GPU test test_graph_capture_survives_the_process_group_watchdog)
+        from hypernerf_torch_amd import graphs
+        ok = ok and graphs._capture_mode() == "thread_local"
         q.put((rank, bool(ok), (lo, hi)))
     finally:
         dist.destroy_process_group()
@@ -120,6 +124,14 @@ def test_two_rank_gloo():
     res.sort()
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == (0, 6) and res[1][2] == (6, 11)     # contiguous, remainder to the first ranks
+
+
+def test_capture_mode_without_a_process_group_is_global():
+    sys.path.insert(0, ROOT)
+    import hypernerf_torch_amd  # noqa: F401
+    from hypernerf_torch_amd import graphs
+    assert not dist.is_initialized()
+    assert graphs._capture_mode() == "global"
 
 
 def test_shard_range_covers_everything():
