@@ -83,7 +83,9 @@ class HnCompositeArgs(C.Structure):
         ("out_med_depth", C.c_void_p), ("out_med_points", C.c_void_p),
         ("g_rgb", C.c_void_p), ("g_depth", C.c_void_p), ("g_acc", C.c_void_p), ("g_weights", C.c_void_p),
         ("d_rgb", C.c_void_p), ("d_raw", C.c_void_p), ("keep", C.c_void_p),
-        ("noise_scale", C.c_float), ("pad_", C.c_int32),
+        ("noise_scale", C.c_float), ("split", C.c_int32),
+        ("perm", C.c_void_p), ("rgb1", C.c_void_p), ("raw1", C.c_void_p), ("warped1", C.c_void_p),
+        ("d_rgb1", C.c_void_p), ("d_raw1", C.c_void_p), ("out_warped", C.c_void_p),
     ]
 
 
@@ -100,7 +102,7 @@ DWJOB_DT = np.dtype([("z_off", "<u8"), ("x_off", "<u8"), ("z_nt", "<i4"), ("x_nt
 
 EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
            "hn_mlp_wgrad_batched", "hn_mlp_workspace_bytes",
-           "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf",
+           "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf", "hn_sample_pdf_split",
            "hn_embed_gather", "hn_embed_backward", "hn_se3_apply_forward", "hn_se3_apply_backward", "hn_se3_warp_forward", "hn_se3_warp_backward", "hn_generate_rays", "hn_adam_step",
            "hn_mse_loss_forward", "hn_mse_loss_backward", "hn_depth_index", "hn_random_fill",
            "hn_probe_mfma"]

@@ -175,9 +175,18 @@ constexpr int HN_MAX_SEG = 8;  // up to 512 samples per ray
 HN_DEV float hn_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }  // torch Softplus(beta=1,threshold=20)
 HN_DEV float hn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-struct HnRaySample {
-  float alpha, one_minus, trans, w, sigma_pre;  // one_minus = 1 - alpha + eps
+// Where sorted sample s of a ray lives when the level was evaluated in two parts (HnCompositeArgs.perm): the part
+// (0 = the coarse level's samples, 1 = the new ones) and the row inside that part's (B, n, .) arrays.
+struct HnPartRow {
+  size_t row;
+  bool second;
 };
+HN_DEV HnPartRow hn_part_row(const HnCompositeArgs& a, int ray, size_t row, int s) {
+  if (a.perm == nullptr) return HnPartRow{row + s, false};
+  const int k = a.perm[row + s];
+  if (k < a.split) return HnPartRow{(size_t)ray * a.split + k, false};
+  return HnPartRow{(size_t)ray * (a.n_samples - a.split) + (k - a.split), true};
+}
 
 template <bool BACKWARD>
 __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs a) {
@@ -204,10 +213,12 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
       const int s = k * 64 + lane;
       const bool in = s < S;
       float zz = 0.f, zn = 0.f, raw = 0.f;
+      HnPartRow pr{row, false};
       if (in) {
         zz = a.z[row + s];
         zn = (s + 1 < S) ? a.z[row + s + 1] : 0.f;
-        raw = a.raw[row + s];
+        pr = hn_part_row(a, ray, row, s);
+        raw = (pr.second ? a.raw1 : a.raw)[pr.row];
         if (a.noise != nullptr) raw = __fadd_rn(raw, __fmul_rn(a.noise[row + s], a.noise_scale));
       }
       const float dz = (s + 1 < S) ? (zn - zz) : last;
@@ -232,12 +243,18 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
       if (!BACKWARD) {
         if (in) {
           a.out_weights[row + s] = w;
-          s_r += w * a.rgb[(row + s) * 3 + 0];
-          s_g += w * a.rgb[(row + s) * 3 + 1];
-          s_b += w * a.rgb[(row + s) * 3 + 2];
+          const float* c = (pr.second ? a.rgb1 : a.rgb) + pr.row * 3;
+          s_r += w * c[0];
+          s_g += w * c[1];
+          s_b += w * c[2];
           s_d += w * zz;
           s_w += w;
           if (s < S - 1) s_wl += w;
+          if (a.out_warped != nullptr) {     // the level's `warped_points` in sorted order, gathered from the parts
+            const float* wsrc = (pr.second ? a.warped1 : a.warped) + pr.row * a.warped_ld;
+            float* wdst = a.out_warped + (row + s) * a.warped_ld;
+            for (int cc = 0; cc < a.warped_ld; ++cc) wdst[cc] = wsrc[cc];
+          }
         }
         if (a.out_med_depth != nullptr) {
           // first sample whose inclusive weight sum reaches 0.5 (model_utils.py:319-345)
@@ -247,7 +264,10 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
             const int first = __ffsll((long long)m) - 1;
             med_z = __shfl(zz, first, 64);
             const int sidx = k * 64 + first;
-            if (a.warped != nullptr) med_pt = a.warped[(row + sidx) * a.warped_ld];
+            if (a.warped != nullptr) {
+              const HnPartRow mp = hn_part_row(a, ray, row, sidx);
+              med_pt = (mp.second ? a.warped1 : a.warped)[mp.row * a.warped_ld];
+            }
             med_found = true;
           }
           csum = __shfl(cs, 63, 64);
@@ -267,8 +287,14 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
       a.out_acc[ray] = (a.variant != 1 && a.sample_at_infinity) ? s_wl : s_w;
       if (a.out_med_depth != nullptr) {
         a.out_med_depth[ray] = med_z;
-        if (a.out_med_points != nullptr)
-          a.out_med_points[ray] = med_found ? med_pt : (a.warped != nullptr ? a.warped[row * a.warped_ld] : 0.0f);
+        if (a.out_med_points != nullptr) {
+          float first_pt = 0.0f;
+          if (a.warped != nullptr) {
+            const HnPartRow mp = hn_part_row(a, ray, row, 0);
+            first_pt = (mp.second ? a.warped1 : a.warped)[mp.row * a.warped_ld];
+          }
+          a.out_med_points[ray] = med_found ? med_pt : first_pt;
+        }
       }
     }
     return;
@@ -289,8 +315,11 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
       const int s = k * 64 + lane;
       const bool in = s < S;
       float dw = 0.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+      HnPartRow pr{row, false};
       if (in) {
-        c0 = a.rgb[(row + s) * 3]; c1 = a.rgb[(row + s) * 3 + 1]; c2 = a.rgb[(row + s) * 3 + 2];
+        pr = hn_part_row(a, ray, row, s);
+        const float* c = (pr.second ? a.rgb1 : a.rgb) + pr.row * 3;
+        c0 = c[0]; c1 = c[1]; c2 = c[2];
         dw = gr * c0 + gg * c1 + gb * c2 + gd * a.z[row + s] + gbg;
         if (!acc_drops_last || s < S - 1) dw += ga;
         if (a.g_weights != nullptr) dw += a.g_weights[row + s];
@@ -314,11 +343,12 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
         if (a.variant == 0) draw = dsigma * (pre[k] > 20.0f ? 1.0f : hn_sigmoid(pre[k]));
         else if (a.variant == 1) draw = pre[k] > 0.0f ? dsigma : 0.0f;
         else draw = dsigma;
-        a.d_raw[row + s] = draw;
+        (pr.second ? a.d_raw1 : a.d_raw)[pr.row] = draw;
         const float ws = wgt[k];
-        a.d_rgb[(row + s) * 3 + 0] = gr * ws;
-        a.d_rgb[(row + s) * 3 + 1] = gg * ws;
-        a.d_rgb[(row + s) * 3 + 2] = gb * ws;
+        float* dc = (pr.second ? a.d_rgb1 : a.d_rgb) + pr.row * 3;
+        dc[0] = gr * ws;
+        dc[1] = gg * ws;
+        dc[2] = gb * ws;
       }
     }
   }
@@ -331,6 +361,13 @@ static int hn_check_comp(const HnCompositeArgs* a, bool bwd) {
   if (!bwd && (a->out_rgb == nullptr || a->out_depth == nullptr || a->out_acc == nullptr || a->out_weights == nullptr))
     return -3;
   if (bwd && (a->d_rgb == nullptr || a->d_raw == nullptr)) return -3;
+  if (a->perm != nullptr) {     // a level in two parts
+    if (a->split < 0 || a->split > a->n_samples) return -2;
+    if (a->split < a->n_samples && (a->rgb1 == nullptr || a->raw1 == nullptr)) return -3;
+    if (bwd && a->split < a->n_samples && (a->d_rgb1 == nullptr || a->d_raw1 == nullptr)) return -3;
+    if (a->warped != nullptr && a->split < a->n_samples && a->warped1 == nullptr) return -3;
+  }
+  if (!bwd && a->out_warped != nullptr && a->warped == nullptr) return -3;
   return 0;
 }
 
@@ -397,6 +434,7 @@ extern "C" int hn_depth_index(const float* weights, const float* z, int n_rays, 
 constexpr int HN_PDF_MAXC = 256;   // max coarse samples
 constexpr int HN_PDF_MAXT = 512;   // max coarse + fine
 
+template <bool PERM>
 __global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const float* __restrict__ weights, int w_ld,
                                                             const float* __restrict__ bins_in, int nb,
                                                             const float* __restrict__ z, int nc,
@@ -404,10 +442,13 @@ __global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const float* __restr
                                                             const float* __restrict__ dirs, int ray_ld, int n_rays,
                                                             int nf, float* __restrict__ z_all,
                                                             float* __restrict__ pts, int64_t* __restrict__ inds,
-                                                            float* __restrict__ z_samples) {
+                                                            float* __restrict__ z_samples, int32_t* __restrict__ perm,
+                                                            float* __restrict__ pts_new) {
   __shared__ float s_cdf[4][HN_PDF_MAXC];
   __shared__ float s_bins[4][HN_PDF_MAXC];
   __shared__ float s_sort[4][HN_PDF_MAXT];
+  __shared__ int s_idx[PERM ? 4 : 1][PERM ? HN_PDF_MAXT : 1];   // the sort's payload: position in cat(z, z_samples)
+  int* sidx = s_idx[PERM ? (threadIdx.x >> 6) : 0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ray = blockIdx.x * 4 + wv;
   if (ray >= n_rays) return;
@@ -487,6 +528,12 @@ __global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const float* __restr
     const float smp = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));
     if (inds != nullptr) inds[(size_t)ray * nf + i] = ind;
     if (z_samples != nullptr) z_samples[(size_t)ray * nf + i] = smp;
+    if (pts_new != nullptr) {
+      const float* o = origins + (size_t)ray * ray_ld;
+      const float* d = dirs + (size_t)ray * ray_ld;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pts_new[((size_t)ray * nf + i) * 3 + c] = __fadd_rn(o[c], __fmul_rn(smp, d[c]));
+    }
     srt[nmerge + i] = smp;
   }
   if (z_all == nullptr) return;
@@ -497,6 +544,8 @@ __global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const float* __restr
   int n2 = 1;
   while (n2 < total) n2 <<= 1;
   for (int i = total + lane; i < n2; i += 64) srt[i] = __builtin_inff();
+  if (PERM)
+    for (int i = lane; i < n2; i += 64) sidx[i] = i;
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   for (int k = 2; k <= n2; k <<= 1) {
@@ -506,7 +555,13 @@ __global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const float* __restr
         if (ixj > i) {
           const float x = srt[i], y = srt[ixj];
           const bool up = (i & k) == 0;
-          if ((x > y) == up) { srt[i] = y; srt[ixj] = x; }
+          if (PERM) {
+            // (depth, position) pairs: equal depths keep the order of cat(z, z_samples) — the key sequence that
+            // comes out is the same as without the payload
+            const int px = sidx[i], py = sidx[ixj];
+            const bool gt = x > y || (x == y && px > py);
+            if (gt == up) { srt[i] = y; srt[ixj] = x; sidx[i] = py; sidx[ixj] = px; }
+          } else if ((x > y) == up) { srt[i] = y; srt[ixj] = x; }
         }
       }
       __builtin_amdgcn_s_waitcnt(0);
@@ -516,6 +571,7 @@ __global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const float* __restr
   for (int i = lane; i < total; i += 64) {
     const float zz = srt[i];
     z_all[(size_t)ray * total + i] = zz;
+    if (PERM) perm[(size_t)ray * total + i] = sidx[i];
     if (pts != nullptr) {
       const float* o = origins + (size_t)ray * ray_ld;
       const float* d = dirs + (size_t)ray * ray_ld;
@@ -525,21 +581,38 @@ __global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const float* __restr
   }
 }
 
-extern "C" int hn_sample_pdf(const float* weights, int w_ld, const float* bins, int n_bins, const float* z,
-                             int n_coarse, const float* u, const float* origins, const float* dirs, int ray_ld,
-                             int n_rays, int n_fine, float* z_all, float* pts, int64_t* inds, float* z_samples,
-                             hnStream_t stream) {
+extern "C" int hn_sample_pdf_split(const float* weights, int w_ld, const float* bins, int n_bins, const float* z,
+                                   int n_coarse, const float* u, const float* origins, const float* dirs, int ray_ld,
+                                   int n_rays, int n_fine, float* z_all, float* pts, int64_t* inds, float* z_samples,
+                                   int32_t* perm, float* pts_new, hnStream_t stream) {
   if (n_rays <= 0 || n_bins < 1 || n_fine <= 0) return -2;
   if (z != nullptr && n_coarse < 2) return -2;
   if (bins == nullptr && (z == nullptr || n_coarse - 2 != n_bins)) return -2;
   if (n_bins + 1 > HN_PDF_MAXC || (z != nullptr ? n_coarse : 0) + n_fine > HN_PDF_MAXT) return -2;
   if (weights == nullptr || u == nullptr) return -3;
-  if (z_all == nullptr && z_samples == nullptr && inds == nullptr) return -3;
+  if (z_all == nullptr && z_samples == nullptr && inds == nullptr && pts_new == nullptr) return -3;
   if (pts != nullptr && (origins == nullptr || dirs == nullptr || z_all == nullptr)) return -3;
-  hipLaunchKernelGGL(hn_sample_pdf_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, weights, w_ld,
-                     bins, n_bins, z, n_coarse, u, origins, dirs, ray_ld, n_rays, n_fine, z_all, pts, inds, z_samples);
+  if (pts_new != nullptr && (origins == nullptr || dirs == nullptr)) return -3;
+  if (perm != nullptr && (z == nullptr || z_all == nullptr)) return -3;
+  if (perm != nullptr)
+    hipLaunchKernelGGL(hn_sample_pdf_kernel<true>, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, weights,
+                       w_ld, bins, n_bins, z, n_coarse, u, origins, dirs, ray_ld, n_rays, n_fine, z_all, pts, inds,
+                       z_samples, perm, pts_new);
+  else
+    hipLaunchKernelGGL(hn_sample_pdf_kernel<false>, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, weights,
+                       w_ld, bins, n_bins, z, n_coarse, u, origins, dirs, ray_ld, n_rays, n_fine, z_all, pts, inds,
+                       z_samples, perm, pts_new);
   HN_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int hn_sample_pdf(const float* weights, int w_ld, const float* bins, int n_bins, const float* z,
+                             int n_coarse, const float* u, const float* origins, const float* dirs, int ray_ld,
+                             int n_rays, int n_fine, float* z_all, float* pts, int64_t* inds, float* z_samples,
+                             hnStream_t stream) {
+  if (z_all == nullptr && z_samples == nullptr && inds == nullptr) return -3;
+  return hn_sample_pdf_split(weights, w_ld, bins, n_bins, z, n_coarse, u, origins, dirs, ray_ld, n_rays, n_fine, z_all,
+                             pts, inds, z_samples, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

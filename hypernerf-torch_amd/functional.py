@@ -13,7 +13,7 @@ import torch
 
 from . import _lib as L
 from .arena import ParamArena
-from .machine import MlpRunner, PendingWgrad, Program, launch_pending_wgrads
+from .machine import MlpRunner, PendingWgrad, Program, ResolvedWgrad, launch_resolved_wgrads, resolve_pending
 
 _PRECISION = os.environ.get("HN_PRECISION", "bf16")
 
@@ -252,11 +252,11 @@ BATCH_WGRADS = True
 WGRAD_OVERLAP = os.environ.get("HN_WGRAD_OVERLAP", "0") == "1"
 _PENDING: List[PendingWgrad] = []
 _PENDING_TASK = [-1]      # autograd graph-task id the pending entries belong to
-_FORKED: List[PendingWgrad] = []     # launched on the side stream, not yet joined (keeps their stashes alive)
+_FORKED: List[ResolvedWgrad] = []    # launched on the side stream, not yet joined (keeps their stashes alive)
 _SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
 
 
-_HELD: List[PendingWgrad] = []       # bucket-1 shares (machine.WGRAD_SPLIT_OFFSET), launched by flush_held_wgrads()
+_HELD: List[ResolvedWgrad] = []      # bucket-1 shares (machine.WGRAD_SPLIT_OFFSET), launched by flush_held_wgrads()
 
 
 def set_wgrad_overlap(on: bool):
@@ -276,13 +276,19 @@ def _side_stream(device) -> "torch.cuda.Stream":
 
 def _fork_wgrad(p: PendingWgrad):
     """Launch one program's weight-gradient jobs on the side stream, ordered behind everything the main stream has
-    been given so far (its backward-data kernel wrote the dZ stash the jobs read)."""
+    been given so far (its backward-data kernel wrote the dZ stash the jobs read).  A launch of its own: the jobs are
+    sized by this program's bytes; a held bucket (data-parallel split) still waits for flush_held_wgrads()."""
     dev = p.stash.device
+    shares = resolve_pending([p])
+    _HELD.extend(r for r in shares if r.bucket != 0)
+    now = [r for r in shares if r.bucket == 0]
+    if not now:
+        return
     main, side = torch.cuda.current_stream(dev), _side_stream(dev)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        launch_pending_wgrads([p])
-    _FORKED.append(p)
+        launch_resolved_wgrads(now)
+    _FORKED.extend(now)
 
 
 def _join_wgrads():
@@ -299,11 +305,20 @@ def _join_wgrads():
 def _flush_wgrads():
     pending = list(_PENDING)
     _PENDING.clear()
-    now = [p for p in pending if p.bucket == 0]
-    _HELD.extend(p for p in pending if p.bucket != 0)
+    shares = resolve_pending(pending) if pending else []
+    now = [p for p in shares if p.bucket == 0]
+    _HELD.extend(p for p in shares if p.bucket != 0)
     if now:
-        launch_pending_wgrads(now)
+        launch_resolved_wgrads(now)
     _join_wgrads()
+
+
+def drop_pending_wgrads():
+    """Forget every queued / held weight-gradient share WITHOUT launching it (their stashes may belong to a stream
+    capture that was abandoned part-way: training.TrainStep falls back to another schedule after a failed capture)."""
+    _PENDING.clear()
+    _HELD.clear()
+    _FORKED.clear()
 
 
 def held_wgrads() -> int:
@@ -316,7 +331,7 @@ def flush_held_wgrads():
     held = list(_HELD)
     _HELD.clear()
     if held:
-        launch_pending_wgrads(held)
+        launch_resolved_wgrads(held)
 
 
 def _defer_wgrad(p: PendingWgrad):
@@ -326,7 +341,7 @@ def _defer_wgrad(p: PendingWgrad):
     if not _PENDING and not _FORKED:
         _PENDING_TASK[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
-    if WGRAD_OVERLAP and p.bucket == 0:
+    if WGRAD_OVERLAP:
         _fork_wgrad(p)
     else:
         _PENDING.append(p)
@@ -455,12 +470,14 @@ def sample_along_rays(origins, directions, lower, upper, t_rand, scale: float = 
     return z, pts
 
 
-def sample_pdf(weights, z, u, origins=None, directions=None, want_points=True, bins=None, merge=True):
+def sample_pdf(weights, z, u, origins=None, directions=None, want_points=True, bins=None, merge=True, split=False):
     """Inverse-CDF sampling at draws u (B,Nf).
 
     Fused form (bins=None): `weights` = coarse weights (B,S); the kernel uses columns 1..S-2 and the
     midpoints of z (B,S) as bin edges.  General form: `bins` (B,n+1) and `weights` (B,n) given.
-    Returns (z_all | None, pts | None, inds (B,Nf) int64, z_samples (B,Nf))."""
+    Returns (z_all | None, pts | None, inds (B,Nf) int64, z_samples (B,Nf)); with `split` (needs the merge and the
+    rays) two more: perm (B,S+Nf) int32 — sorted position -> entry of cat(z, z_samples) — and pts_new (B,Nf,3), the
+    points of the new samples in draw order (a fine level that evaluates only those through the warp field)."""
     L.require_gpu(weights, u)
     L.load()
     nf = u.shape[1]
@@ -487,6 +504,16 @@ def sample_pdf(weights, z, u, origins=None, directions=None, want_points=True, b
     pts = torch.empty(b, nc + nf, 3, dtype=torch.float32, device=dev) if want_points else None
     inds = torch.empty(b, nf, dtype=torch.int64, device=dev)
     zs = torch.empty(b, nf, dtype=torch.float32, device=dev)
+    if split:
+        if not (do_merge and want_points):
+            raise L.HnError("sample_pdf(split=True) needs the merge (z) and the rays (origins, directions)")
+        perm = torch.empty(b, nc + nf, dtype=torch.int32, device=dev)
+        pts_new = torch.empty(b, nf, 3, dtype=torch.float32, device=dev)
+        L.launch("hn_sample_pdf_split", w_ptr, C.c_int(weights.stride(0)), L.ptr(bins), C.c_int(nb), L.ptr(z), C.c_int(nc),
+                 L.ptr(u.contiguous()), L.ptr(origins), L.ptr(directions), C.c_int(origins.stride(0)), C.c_int(b),
+                 C.c_int(nf), L.ptr(z_all), L.ptr(pts), L.ptr(inds), L.ptr(zs), L.ptr(perm), L.ptr(pts_new),
+                 L.stream_handle())
+        return z_all, pts, inds, zs, perm, pts_new
     L.launch("hn_sample_pdf", w_ptr, C.c_int(weights.stride(0)), L.ptr(bins), C.c_int(nb),
                               L.ptr(z if (do_merge or bins is None) else None), C.c_int(nc), L.ptr(u.contiguous()),
                               L.ptr(origins if want_points else None), L.ptr(directions if want_points else None),
@@ -546,14 +573,30 @@ def random_draws(specs: Sequence[Tuple[Tuple[int, ...], str]], device) -> List[t
 # compositing
 # --------------------------------------------------------------------------------------------
 class _CompositeFn(torch.autograd.Function):
+    """One level's compositing.  With `perm` the level arrives in TWO parts (include/hn_kernels.h, HnCompositeArgs.perm):
+    (rgb, raw, warped) = the coarse level's samples re-evaluated by the fine template, (rgb1, raw1, warped1) = the new
+    samples; z, noise, keep and the returned weights are in sorted order, and one more output — the parts' warped
+    rows in sorted order, the level's `warped_points` — is appended."""
+
     @staticmethod
     def forward(ctx, rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median,
-                dust_threshold=None, keep=None, noise_scale=1.0):
+                dust_threshold=None, keep=None, noise_scale=1.0, rgb1=None, raw1=None, warped1=None, perm=None):
         L.require_gpu(rgb, raw, z, dirs)
         L.load()
         b, s = z.shape
         dev = z.device
-        rgb_c, raw_c, z_c = rgb.detach().contiguous(), raw.detach().reshape(b, s).contiguous(), z.contiguous()
+        s0 = s
+        if perm is not None:
+            L.require_gpu(rgb1, raw1, perm)
+            if perm.dtype != torch.int32 or tuple(perm.shape) != (b, s):
+                raise L.HnError("composite: perm must be a (B, S) int32 tensor")
+            s0 = raw.numel() // b
+            if raw.numel() != b * s0 or raw1.numel() != b * (s - s0) or rgb.numel() != 3 * b * s0 or \
+                    rgb1.numel() != 3 * b * (s - s0):
+                raise L.HnError("composite: the two parts do not add up to the level's samples")
+            if (warped is None) != (warped1 is None) or (warped is not None and warped.shape[-1] != warped1.shape[-1]):
+                raise L.HnError("composite: both parts need warped points of the same width (or neither)")
+        rgb_c, raw_c, z_c = rgb.detach().contiguous(), raw.detach().reshape(b, s0).contiguous(), z.contiguous()
         noise_c = noise.detach().reshape(b, s).contiguous() if noise is not None else None
         dirs_c = dirs if dirs.stride(-1) == 1 else dirs.contiguous()
         warped_c = warped.detach().contiguous() if warped is not None else None
@@ -568,6 +611,16 @@ class _CompositeFn(torch.autograd.Function):
         a.has_dust, a.dust_threshold = int(dust_threshold is not None), float(dust_threshold or 0.0)
         a.keep = keep_c.data_ptr() if keep_c is not None else 0
         a.noise_scale = float(noise_scale)
+        rgb1_c = raw1_c = warped1_c = perm_c = o_warped = None
+        if perm is not None:
+            perm_c = perm.contiguous()
+            rgb1_c, raw1_c = rgb1.detach().contiguous(), raw1.detach().reshape(b, s - s0).contiguous()
+            warped1_c = warped1.detach().contiguous() if warped1 is not None else None
+            a.perm, a.split, a.rgb1, a.raw1 = perm_c.data_ptr(), s0, rgb1_c.data_ptr(), raw1_c.data_ptr()
+            if warped1_c is not None:
+                a.warped1 = warped1_c.data_ptr()
+                o_warped = torch.empty(b, s, a.warped_ld, dtype=torch.float32, device=dev)
+                a.out_warped = o_warped.data_ptr()
         o_rgb = torch.empty(b, 3, dtype=torch.float32, device=dev)
         o_depth = torch.empty(b, dtype=torch.float32, device=dev)
         o_acc = torch.empty(b, dtype=torch.float32, device=dev)
@@ -579,24 +632,32 @@ class _CompositeFn(torch.autograd.Function):
         a.out_med_points = o_mp.data_ptr() if o_mp is not None else 0
         L.launch("hn_composite_forward", C.byref(a), L.stream_handle())
         ctx.saved = (rgb_c, raw_c, noise_c, z_c, dirs_c)
+        ctx.parts = (perm_c, rgb1_c, raw1_c, s0)
         ctx.filt = (dust_threshold, keep_c)
         ctx.noise_scale = float(noise_scale)
         ctx.cfg = (variant, int(white_bg), int(sample_at_infinity), b, s)
         ctx.raw_shape = raw.shape
+        ctx.raw1_shape = raw1.shape if raw1 is not None else None
+        ctx.n_med = 0
         outs = [o_rgb, o_depth, o_acc, o_w]
         nd = []
         if o_md is not None:
-            outs.append(o_md); nd.append(o_md)
+            outs.append(o_md); nd.append(o_md); ctx.n_med += 1
         if o_mp is not None:
-            outs.append(o_mp); nd.append(o_mp)
+            outs.append(o_mp); nd.append(o_mp); ctx.n_med += 1
+        if o_warped is not None:
+            # the sorted `warped_points` stays differentiable w.r.t. the parts' warped rows (a loss the caller puts on
+            # it: rare, un-permuted with torch ops in backward)
+            outs.append(o_warped)
         ctx.mark_non_differentiable(*nd)
         ctx.set_materialize_grads(False)      # unused outputs (depth, acc, weights) arrive as None, not as zero fills
         return tuple(outs)
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth, g_acc, g_w, *unused):
+    def backward(ctx, g_rgb, g_depth, g_acc, g_w, *rest):
         L.load()
         rgb_c, raw_c, noise_c, z_c, dirs_c = ctx.saved
+        perm_c, rgb1_c, raw1_c, s0 = ctx.parts
         variant, white_bg, sai, b, s = ctx.cfg
         a = L.HnCompositeArgs()
         a.variant, a.n_rays, a.n_samples, a.white_bg, a.sample_at_infinity = variant, b, s, white_bg, sai
@@ -615,17 +676,32 @@ class _CompositeFn(torch.autograd.Function):
         d_rgb = torch.empty_like(rgb_c)
         d_raw = torch.empty_like(raw_c)
         a.d_rgb, a.d_raw = d_rgb.data_ptr(), d_raw.data_ptr()
+        d_rgb1 = d_raw1 = d_warped = d_warped1 = None
+        if perm_c is not None:
+            d_rgb1, d_raw1 = torch.empty_like(rgb1_c), torch.empty_like(raw1_c)
+            a.perm, a.split, a.rgb1, a.raw1 = perm_c.data_ptr(), s0, rgb1_c.data_ptr(), raw1_c.data_ptr()
+            a.d_rgb1, a.d_raw1 = d_rgb1.data_ptr(), d_raw1.data_ptr()
+            g_ws = rest[ctx.n_med] if len(rest) > ctx.n_med else None
+            if g_ws is not None and g_ws.numel() > 0:      # a loss on the sorted warped points: scatter it back to the parts
+                h = g_ws.shape[-1]
+                cat = torch.zeros(b, s, h, dtype=g_ws.dtype, device=g_ws.device)
+                cat.scatter_(1, perm_c.long().unsqueeze(-1).expand(b, s, h), g_ws.reshape(b, s, h))
+                d_warped, d_warped1 = cat[:, :s0].contiguous(), cat[:, s0:].contiguous()
         L.launch("hn_composite_backward", C.byref(a), L.stream_handle())
-        return d_rgb, d_raw.view(ctx.raw_shape), None, None, None, None, None, None, None, None, None, None, None
+        return (d_rgb, d_raw.view(ctx.raw_shape), None, None, None, d_warped, None, None, None, None, None, None, None,
+                d_rgb1, d_raw1.view(ctx.raw1_shape) if d_raw1 is not None else None, d_warped1, None)
 
 
 def composite(rgb, raw, noise, z, dirs, warped=None, variant=0, white_bg=False, sample_at_infinity=True,
-              want_median=True, dust_threshold=None, keep=None, noise_scale: float = 1.0):
+              want_median=True, dust_threshold=None, keep=None, noise_scale: float = 1.0, rgb1=None, raw1=None,
+              warped1=None, perm=None):
     """Returns (rgb (B,3), depth (B), acc (B), weights (B,S)[, med_depth (B)[, med_points (B)]]).
     `noise` (B,S): standard-normal draws, scaled by `noise_scale` inside the kernel (noise_std of noise_regularize).
-    dust_threshold / keep (B,S 0/1): the reference's filter_sigma (models.py:35-63) applied to the activated density."""
+    dust_threshold / keep (B,S 0/1): the reference's filter_sigma (models.py:35-63) applied to the activated density.
+    With `perm` (B,S) int32 the level comes in two parts — (rgb, raw, warped) and (rgb1, raw1, warped1), see
+    _CompositeFn — and the sorted warped points (B,S,H) are appended to the result."""
     return _CompositeFn.apply(rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median,
-                              dust_threshold, keep, noise_scale)
+                              dust_threshold, keep, noise_scale, rgb1, raw1, warped1, perm)
 
 
 # --------------------------------------------------------------------------------------------

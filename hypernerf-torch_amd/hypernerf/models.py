@@ -8,6 +8,7 @@ fused HIP launches per level: sampling -> warp-field machine -> hyper-sheet mach
 from __future__ import annotations
 
 import functools
+import os
 from typing import Any, Callable, Dict, Mapping, Optional, Sequence
 
 import torch
@@ -295,8 +296,49 @@ class NerfModel(nn.Module):
             self._template_calls[key] = call
         return call
 
+    def _template_reuse_call(self, level: str, n_hyper_pts: int, hyper_from_table: bool, warped_grad: bool) -> F.ProgramCall:
+        """query_template (models.py:447-493) over warped points that ALREADY exist — the fine level's pass over the
+        coarse level's samples (REUSE_COARSE below).  Sources: 0 = warped points (P, 3 + H) as the coarse level program
+        wrote them (xyz in columns 0-2; bendy sheet: the sheet's H outputs behind them), 1 = viewdirs (B,3), 2 = the
+        GLO table gathered by ray (conditions; the axis-aligned slice's hyper coordinates).  The gradient w.r.t. source 0
+        is what the coarse level program takes as the external gradient on its `warped_points` output."""
+        key = ("treuse", level, n_hyper_pts, hyper_from_table, warped_grad)
+        call = self._live_call(key)
+        if call is None:
+            m = self.nerf_mlps_fine if level == 'fine' else self.nerf_mlps_coarse
+            G = self.GLO_dim
+            feats = posenc_features(0, range(3), self.xyz_freq, warped_grad)
+            if n_hyper_pts:
+                feats += posenc_features(0, range(3, 3 + n_hyper_pts), self.hyper_freq, warped_grad)
+            elif hyper_from_table:
+                feats += posenc_features(2, range(G), self.hyper_freq, True)
+            if len(feats) != m.in_ch:
+                raise RuntimeError(f"template input has {len(feats)} channels, the MLP expects {m.in_ch}")
+            rgb_feats = posenc_features(1, range(3), self.dir_freq, False) if self.use_viewdirs else []
+            alpha_aux = None
+            if self.use_nerf_embed:
+                if self.use_alpha_condition:
+                    alpha_aux = AuxSpec(copy_features(2, range(G), True))
+                if self.use_rgb_condition:
+                    rgb_feats += copy_features(2, range(G), True)
+            layers = modules.nerf_mlp_layers(m, f"nerf_mlps_{level}", AuxSpec(feats), alpha_aux,
+                                             AuxSpec(rgb_feats) if rgb_feats else None)
+            call = F.ProgramCall(Program(layers, name=f"template_{level}_reuse", no_direct=(2,)), [False, True, True],
+                                 [3, 1], [("g", 0), ("g", 1), ("y", 0)], gather_src=2)
+            self._template_calls[key] = call
+        return call
+
     # ---- fused level program -------------------------------------------------------------------
     FUSE_LEVELS = True      # warp field -> hyper sheet -> template as ONE launch per level where the model allows it
+    # The fine level's samples are sort(cat(coarse samples, new samples)) (models.py:752-768, model_utils.py:206-232):
+    # half (config 3: a third) of its points ARE the coarse level's points, and the warp field / hyper sheet — shared by
+    # both levels — have already been evaluated there.  With REUSE_COARSE the fine level runs as two launches: the
+    # fine TEMPLATE alone over the coarse level's warped points (read back from HBM, 28 B per point) and the whole
+    # level program over the NEW samples only; the compositing kernel reads both through the merge permutation of
+    # hn_sample_pdf_split.  Same function values (the warp of a point does not depend on which launch computes it);
+    # the fine loss reaches the warp field through the coarse level program's external `warped_points` gradient.
+    # At config 2: 1/3 of all warp + sheet forward, backward and weight-gradient work and ~10 % of the stash bytes.
+    REUSE_COARSE = os.environ.get("HN_REUSE_COARSE", "1") != "0"
 
     def _can_fuse_level(self, use_warp: bool, metadata_encoded: bool, metadata) -> bool:
         """One launch per level needs: a TranslationField warp, hyper coordinates from the sheet MLP (or none), and
@@ -385,17 +427,22 @@ class NerfModel(nn.Module):
         nc, nf = self.num_coarse_samples, self.num_fine_samples
         out = []
         fused = False
+        reuse = getattr(self, "_reused_coarse", False)
         for key, call in self._template_calls.items():
             if call is None:            # the ("nofuse",) marker
                 continue
             if key[0] == "level":
-                out.append((f"level_{key[1]}", call.program, n_rays * (nc if key[1] == 'coarse' else nc + nf)))
+                n_fine = nf if reuse else nc + nf       # with REUSE_COARSE the fine level program sees the new samples only
+                out.append((f"level_{key[1]}", call.program, n_rays * (nc if key[1] == 'coarse' else n_fine)))
                 fused = True
+            elif key[0] == "treuse":
+                if reuse and not any(o[0] == f"level_{key[1]}_reuse" for o in out):      # (training / inference builds)
+                    out.append((f"level_{key[1]}_reuse", call.program, n_rays * nc))
             else:
                 lvl = key[1] if key[0] == "tgather" else key[0]
                 out.append((f"template_{lvl}", call.program, n_rays * (nc if lvl == 'coarse' else nc + nf)))
         if fused:
-            return [o for o in out if o[0].startswith("level_")]
+            return [o for o in out if o[0].startswith("level_")]      # incl. level_fine_reuse
         both = n_rays * (2 * nc + nf)
         for attr, name in (("warp_field", "warp_field"), ("hyper_sheet_mlp", "hyper_sheet_mlp")):
             mod = getattr(self, attr, None)
@@ -539,6 +586,52 @@ class NerfModel(nn.Module):
         return self._composite_level(out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity,
                                      dust, keep, b, s, points.device, level)
 
+    def _render_fine_reusing_coarse(self, coarse, points, z_vals, pts_new, perm, directions, viewdirs, metadata,
+                                    use_sample_at_infinity, render_opts, noise):
+        """The fine level (models.py:752-768 -> render_samples 587-671) without re-evaluating the shared networks on the
+        coarse level's samples (REUSE_COARSE).  `points` / `z_vals` (B, Nc+Nf, .) sorted, `pts_new` (B, Nf, 3) the new
+        samples in draw order, `perm` (B, Nc+Nf) the merge permutation.  Returns the same dict as render_samples."""
+        b, s = z_vals.shape
+        nc = self.num_coarse_samples
+        nf = s - nc
+        dust, keep = None, None
+        if render_opts is not None:
+            if 'dust_threshold' in render_opts:
+                dust = float(render_opts.get('dust_threshold', 0.0))
+            if 'bounding_box' in render_opts:
+                xmin, xmax, ymin, ymax, zmin, zmax = render_opts['bounding_box']
+                keep = ((points[..., 0] >= xmin) & (points[..., 0] <= xmax) & (points[..., 1] >= ymin)
+                        & (points[..., 1] <= ymax) & (points[..., 2] >= zmin) & (points[..., 2] <= zmax)).float()
+        idx = metadata[self.warp_embed_key]
+        if idx.shape[-1] == 1 and idx.dim() > 1:
+            idx = idx.squeeze(-1)
+        table = self.warp_embed.embed.weight
+        vd = viewdirs if self.use_viewdirs else None
+        # (i) the coarse level's samples: their warped points exist — the fine template alone
+        w_old = coarse['warped_points']                                   # (B, Nc, 3 + H), output of the coarse program
+        from_table = self.hyper_slice_method == 'axis_aligned_plane'
+        n_hyper = w_old.shape[-1] - 3 if self.hyper_slice_method == 'bendy_sheet' else 0
+        ge = torch.is_grad_enabled() and w_old.requires_grad
+        call_old = self._template_reuse_call('fine', n_hyper, from_table, ge)
+        rgb_old, alpha_old = F.run_program(call_old, [w_old.reshape(b * nc, w_old.shape[-1]), vd, table], nc,
+                                           self.precision, gather_idx=idx)
+        # (ii) the new samples: warp field -> hyper sheet -> fine template, one launch
+        call_new = self._level_call('fine')
+        w_new, rgb_new, alpha_new = F.run_program(call_new, [pts_new.reshape(b * nf, 3), vd, table, None], nf,
+                                                  self.precision, gather_idx=idx)
+        scale = 1.0
+        if noise is None and (self.noise_std is not None) and self.noise_std > 0.0 and self.use_stratified_sampling:
+            noise = getattr(self, '_auto_noise', {}).pop('fine', None)
+            if noise is None or tuple(noise.shape) != (b, s, 1):
+                noise = torch.randn((b, s, 1), device=z_vals.device, dtype=torch.float32)
+            scale = float(self.noise_std)
+        res = F.composite(rgb_old.view(b, nc, 3), alpha_old.view(b, nc), noise, z_vals, directions, w_old, variant=0,
+                          white_bg=self.use_white_background, sample_at_infinity=use_sample_at_infinity,
+                          want_median=True, dust_threshold=dust, keep=keep, noise_scale=scale,
+                          rgb1=rgb_new.view(b, nf, 3), raw1=alpha_new.view(b, nf), warped1=w_new.view(b, nf, -1), perm=perm)
+        return {'points': points, 'warped_points': res[6], 'rgb': res[0], 'depth': res[1], 'acc': res[2],
+                'weights': res[3], 'med_depth': res[4], 'med_points': res[5].view(b, 1, 1)}
+
     def _empty_result(self, like: torch.Tensor, use_warp: bool):
         """Zero rays in, zero rays out (the reference's ATen ops all accept empty batches): no kernel is launched."""
         e = lambda *shape: like.new_zeros(shape)
@@ -639,12 +732,21 @@ class NerfModel(nn.Module):
                     if u is None:
                         u = torch.linspace(0, 1, self.num_fine_samples).to(origins.device).expand(b, -1).contiguous()
                         self._det_u[key] = u
-            z_fine, pts_fine, inds, _ = F.sample_pdf(coarse['weights'], z_vals, u, origins, directions)
-            fine = self.render_samples('fine', pts_fine, z_fine, directions, viewdirs, metadata, extra_params,
-                                       use_warp=use_warp, metadata_encoded=metadata_encoded,
-                                       return_warp_jacobian=return_warp_jacobian,
-                                       use_sample_at_infinity=use_sample_at_infinity, render_opts=render_opts,
-                                       noise=rng.get('noise_fine'))
+            self._reused_coarse = bool(self.REUSE_COARSE and not return_warp_jacobian
+                                       and self._can_fuse_level(use_warp, metadata_encoded, metadata))
+            if self._reused_coarse:
+                z_fine, pts_fine, inds, _, perm, pts_new = F.sample_pdf(coarse['weights'], z_vals, u, origins,
+                                                                        directions, split=True)
+                fine = self._render_fine_reusing_coarse(coarse, pts_fine, z_fine, pts_new, perm, directions, viewdirs,
+                                                        metadata, use_sample_at_infinity, render_opts,
+                                                        rng.get('noise_fine'))
+            else:
+                z_fine, pts_fine, inds, _ = F.sample_pdf(coarse['weights'], z_vals, u, origins, directions)
+                fine = self.render_samples('fine', pts_fine, z_fine, directions, viewdirs, metadata, extra_params,
+                                           use_warp=use_warp, metadata_encoded=metadata_encoded,
+                                           return_warp_jacobian=return_warp_jacobian,
+                                           use_sample_at_infinity=use_sample_at_infinity, render_opts=render_opts,
+                                           noise=rng.get('noise_fine'))
             out['fine'] = fine
             # not part of the reference's return value: kept for tests / debugging
             self.last_sampling = {'z_coarse': z_vals, 'z_fine': z_fine, 'inds': inds, 'u': u}

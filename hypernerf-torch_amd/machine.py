@@ -690,18 +690,11 @@ class Program:
             raise NotImplementedError(f"no wave grid for a {n_nt} x {n_kt} tile rectangle")
         return best[1], best[2]
 
-    def wgrad_jobs(self, mode: int, n_points: int, target_jobs: int = 512,
-                   grad_offsets: Optional[Sequence[int]] = None, job_bytes: Optional[int] = None,
-                   launch_bytes: Optional[float] = None) -> np.ndarray:
-        """One job per (layer input segment, tile rectangle, block chunk).  The chunks are sized so that the
-        launch is about `target_jobs` workgroups of equal stash bytes — or, with `job_bytes`, so that every job
-        streams about that many bytes (the batched launch mixes the jobs of several programs)."""
+    def _wgrad_rects(self, mode: int, n_points: int) -> list:
+        """The dW rectangles of every layer: (layer, dZ offset, X offset, X tiles per block, first column, columns,
+        first dZ tile, first k-tile, dZ tiles, k-tiles, with bias, stacked part, second X slot | None)."""
         offs, _, _ = self.layout(mode, n_points)
-        goffs = list(grad_offsets) if grad_offsets is not None else self.grad_offsets()[0]
-        nblk = (n_points + 31) // 32
         tmax = 8 if bf16_like(mode) else 4
-        # tiles per LDS stage of hn_wgrad_kernel: 32 KiB (4-stage ring), 8-bit stash 48 KiB (3-stage ring)
-        stage_tiles = 48 if mode == L.HN_MODE_BF16_S8 else 32 * 1024 // mode_consts(mode)[1]
         rects = []
         for ly in self.layers:
             segs = []
@@ -730,6 +723,32 @@ class Program:
                             with_bias = first and kt0 == 0 and prt[1] >= 0
                             rects.append((ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias, prt, x2))
                 first = False
+        return rects
+
+    def wgrad_stream_bytes(self, mode: int, n_points: int, grad_offsets: Optional[Sequence[int]] = None,
+                           min_w_off: Optional[int] = None) -> float:
+        """Stash bytes the weight-gradient jobs of this program stream for `n_points` points (every rectangle reads its
+        dZ and X tiles of every block once) — what `wgrad_jobs` sizes a batched launch's jobs by.  `min_w_off`: only the
+        rectangles whose matrix lies at or behind that offset of the gradient buffer (the first bucket of a split
+        launch, WGRAD_SPLIT_OFFSET)."""
+        goffs = list(grad_offsets) if grad_offsets is not None else self.grad_offsets()[0]
+        nblk = (n_points + 31) // 32
+        tiles = sum(r[8] + r[9] for r in self._wgrad_rects(mode, n_points)
+                    if min_w_off is None or goffs[r[11][0]] >= min_w_off)
+        return float(tiles) * nblk * mode_consts(mode)[1]
+
+    def wgrad_jobs(self, mode: int, n_points: int, target_jobs: int = 512,
+                   grad_offsets: Optional[Sequence[int]] = None, job_bytes: Optional[int] = None,
+                   launch_bytes: Optional[float] = None) -> np.ndarray:
+        """One job per (layer input segment, tile rectangle, block chunk).  The chunks are sized so that the
+        launch is about `target_jobs` workgroups of equal stash bytes — or, with `job_bytes`, so that every job
+        streams about that many bytes (the batched launch mixes the jobs of several programs; `launch_bytes` = the
+        stash bytes of that WHOLE launch, all its programs: jobs of big rectangles are sized to one CU's share of it)."""
+        goffs = list(grad_offsets) if grad_offsets is not None else self.grad_offsets()[0]
+        nblk = (n_points + 31) // 32
+        # tiles per LDS stage of hn_wgrad_kernel: 32 KiB (4-stage ring), 8-bit stash 48 KiB (3-stage ring)
+        stage_tiles = 48 if mode == L.HN_MODE_BF16_S8 else 32 * 1024 // mode_consts(mode)[1]
+        rects = self._wgrad_rects(mode, n_points)
         total_tiles = sum(r[8] + r[9] for r in rects)
         jobs = []
         for (ly, z_off, x_off, x_nt, c0, ncols, nt0, kt0, n_nt, n_kt, with_bias, prt, x2) in rects:
@@ -812,7 +831,6 @@ N_CUS = 256                      # MI355X
 # backward feature-gradient ops: 2 = only tiles with a differentiable feature, no chain-rule factor on identity-only tiles;
 # 1 = only the tile skip; 0 = every tile of a group with a gradient (rounds 1-3)
 AUX_TILE_SKIP = int(os.environ.get("HN_AUX_TILE_SKIP", 2))
-_LAUNCH_BYTES = [0.0]            # stash bytes of the last batched weight-gradient launch (all its programs)
 WGRAD_FUSE_SEGS = int(os.environ.get("HN_WGRAD_FUSE_SEGS", 1))     # 0: one job per input segment of a skip layer (rounds 1-3)
 WGRAD_GRID = int(os.environ.get("HN_WGRAD_GRID", 1))       # 0: the wave grids of rounds 1-3 (Program._wave_grid)
 WGRAD_TAIL_FRAC = float(os.environ.get("HN_WGRAD_TAIL_FRAC", 0.4))   # lightest 40 % of the jobs are halved: -1.8 % step time at config 2
@@ -822,7 +840,21 @@ WGRAD_JOB_BYTES = int(float(os.environ.get("HN_WGRAD_JOB_MB", 5)) * (1 << 20))  
 
 
 class PendingWgrad:
-    """One program's share of a batched weight-gradient launch.  Holds the stash alive until it ran."""
+    """One program's share of a batched weight-gradient launch, not yet cut into jobs: the job sizes follow the bytes of
+    the WHOLE launch (Program.wgrad_jobs), which are only known once every program of the backward pass has queued
+    its share — `resolve_pending`.  Holds the stash alive until the launch ran."""
+
+    def __init__(self, runner: "MlpRunner", mode: int, n_points: int, stash, grads, goffs, split):
+        self.runner, self.mode, self.n_points, self.stash, self.grads = runner, mode, n_points, stash, grads
+        self.goffs, self.split = goffs, split
+
+    def stream_bytes(self, first_bucket_only: bool = True) -> float:
+        return self.runner.prog.wgrad_stream_bytes(self.mode, self.n_points, self.goffs,
+                                                   self.split if first_bucket_only else None)
+
+
+class ResolvedWgrad:
+    """A PendingWgrad cut into jobs (device table cached by the program's runner)."""
 
     def __init__(self, mode, jobs_dev, n_jobs, stash, grads, weights, bucket=0):
         self.mode, self.jobs_dev, self.n_jobs, self.stash, self.grads = mode, jobs_dev, n_jobs, stash, grads
@@ -842,17 +874,27 @@ HELD_JOB_DIV = int(os.environ.get("HN_HELD_JOB_DIV", 6))
 _ORDER_CACHE: Dict[tuple, torch.Tensor] = {}
 
 
-def launch_pending_wgrads(pending: Sequence[PendingWgrad]):
+def resolve_pending(pending: Sequence[PendingWgrad]) -> List[ResolvedWgrad]:
+    """Cut the shares of ONE launch into jobs.  The launch's bytes — the sum over the programs queued for it, first
+    bucket only when the pass is split — size the jobs of big rectangles (one flush of a dW rectangle per CU);
+    they are a function of the programs and sizes of THIS pass, so the first pass of a shape already builds the tables
+    every later pass (and a graph capture after a single warm-up) uses."""
+    total = float(sum(p.stream_bytes() for p in pending))
+    out: List[ResolvedWgrad] = []
+    for p in pending:
+        for b, (jd, nj, w) in enumerate(p.runner.wgrad_tables(p.stash.device, p.mode, p.n_points, p.goffs, p.split, total)):
+            if nj > 0:
+                out.append(ResolvedWgrad(p.mode, jd, nj, p.stash, p.grads, w, bucket=b))
+    return out
+
+
+def launch_resolved_wgrads(shares: Sequence[ResolvedWgrad]):
     """hn_mlp_wgrad_batched over the programs of one backward pass (groups of HN_MAX_WGRAD_BATCH per mode).
     Jobs run in one global heaviest-first order (a device table cached per set of job lists): the hardware
     hands workgroups to CUs as they free up, i.e. list scheduling, and longest-first packs it tightest."""
-    by_mode: Dict[int, List[PendingWgrad]] = {}
-    for p in pending:
+    by_mode: Dict[int, List[ResolvedWgrad]] = {}
+    for p in shares:
         by_mode.setdefault(p.mode, []).append(p)
-    if pending:
-        # what the NEXT backward pass sizes its jobs by (Program.wgrad_jobs: one big-rectangle job ~ one CU's share of
-        # the launch); shapes repeat from step to step, and a captured step has run eagerly before its capture
-        _LAUNCH_BYTES[0] = float(sum(int(p.weights.sum()) * mode_consts(p.mode)[1] for p in pending if p.bucket == 0))
     for mode, lst in by_mode.items():
         lst.sort(key=lambda p: -p.n_jobs)
         for i in range(0, len(lst), L.HN_MAX_WGRAD_BATCH):
@@ -864,6 +906,9 @@ def launch_pending_wgrads(pending: Sequence[PendingWgrad]):
             key = tuple((p.jobs_dev.data_ptr(), p.n_jobs) for p in grp)
             order = _ORDER_CACHE.get(key)
             if order is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise L.HnError("weight-gradient job order: first use of this set of programs inside a stream "
+                                    "capture (run one warm-up step of the same shapes first)")
                 w = np.concatenate([p.weights for p in grp])
                 ids = np.concatenate([(k << 24) | np.arange(p.n_jobs, dtype=np.int64) for k, p in enumerate(grp)])
                 order = torch.from_numpy(ids[np.argsort(-w, kind="stable")].astype(np.int32)).to(grp[0].stash.device)
@@ -1058,8 +1103,8 @@ class MlpRunner:
         """Launch backward-data then the weight-gradient kernel.
         grad_target = (flat fp32 buffer, per-parameter offsets): accumulate the weight gradients there (a
         ParamArena's gradient buffer) instead of into a fresh zero-filled buffer.  With `defer` (and a grad_target)
-        the weight-gradient kernel is NOT launched: a PendingWgrad is returned in place of the gradient buffer,
-        for `launch_pending_wgrads`.
+        the weight-gradient kernel is NOT launched: a list holding one PendingWgrad is returned in place of the
+        gradient buffer, for `resolve_pending` / `launch_resolved_wgrads`.
         embed = (gradient table (rows, dim), int64 ray indices, source index): reduce the source gradient of that
         gathered per-ray source inside the kernel and scatter-add it into the table gradient (needs
         samples_per_ray % 32 == 0).  want_dsrc=False skips the per-point source-gradient tensor altogether.
@@ -1079,14 +1124,36 @@ class MlpRunner:
         L.launch("hn_mlp_backward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         goffs = tuple(grad_target[1]) if grad_target is not None else None
         deferred = defer and grad_target is not None
-        split = WGRAD_SPLIT_OFFSET if deferred else None
-        # the launch's bytes as of the last batched launch, in steps of 2^(1/4) (job tables are cached per step)
-        hint = _LAUNCH_BYTES[0] if deferred else 0.0
-        qh = round(4.0 * math.log2(hint)) if hint > 0 else 0
-        jkey = (str(device), mode, n_points, goffs, deferred, split, qh)
-        if jkey not in self._jobs:
+        if deferred:        # the caller launches it together with the other programs of this backward pass
+            return dsrc, [PendingWgrad(self, mode, n_points, stash, grad_target[0], goffs, WGRAD_SPLIT_OFFSET)]
+        jobs_dev, n_jobs, weights = self.wgrad_tables(device, mode, n_points, goffs, None, None)[0]
+        if grad_target is not None:
+            grads, ret = grad_target[0], None
+        else:
+            _, gtot = self.prog.grad_offsets()
+            grads = ret = torch.zeros(gtot, dtype=torch.float32, device=device)
+        L.launch("hn_mlp_wgrad", C.c_int(wgrad_mode_word(mode)), L.ptr(jobs_dev), C.c_int(n_jobs), L.ptr(stash), L.ptr(grads),
+                 L.stream_handle(), tag=self.prog.name)
+        return dsrc, ret
+
+    def wgrad_tables(self, device, mode: int, n_points: int, goffs, split: Optional[int],
+                     launch_bytes: Optional[float]):
+        """[(device job table | None, jobs, stash tiles per job)] per bucket of this program's weight-gradient jobs
+        (cached).  `launch_bytes` = stash bytes of the WHOLE batched launch the jobs will run in (resolve_pending; None: a
+        launch of its own, `target_jobs` equal jobs) — quantised in steps of 2^(1/4) for the cache.  `split`: two
+        buckets (WGRAD_SPLIT_OFFSET)."""
+        batched = launch_bytes is not None
+        qh = round(4.0 * math.log2(launch_bytes)) if batched and launch_bytes > 0 else 0
+        jkey = ("jobs", str(device), mode, n_points, goffs, batched, split, qh)
+        entry = self._jobs.get(jkey)
+        if entry is None:
+            if torch.cuda.is_current_stream_capturing():
+                # a table upload is a pageable host-to-device copy: never inside a capture (its buffer would also come
+                # from the graph's private pool)
+                raise L.HnError(f"{self.prog.name}: weight-gradient job table for {n_points} points first needed inside "
+                                "a stream capture (run one warm-up step of the same shapes first)")
             jobs = self.prog.wgrad_jobs(mode, n_points, grad_offsets=goffs,
-                                        job_bytes=self._job_bytes(mode) if deferred else None,
+                                        job_bytes=self._job_bytes(mode) if batched else None,
                                         launch_bytes=(2.0 ** (qh / 4.0)) if qh else None)
             parts = [jobs]
             if split is not None:
@@ -1100,20 +1167,7 @@ class MlpRunner:
                 weights = ((part["n_nt"] + part["n_kt"]).astype(np.int64) * (part["blk1"] - part["blk0"]))
                 entry.append((L.to_device_bytes(part, device) if len(part) else None, len(part), weights))
             self._jobs[jkey] = entry
-        entry = self._jobs[jkey]
-        if deferred:        # the caller launches it together with the other programs of this backward pass
-            pend = [PendingWgrad(mode, jd, nj, stash, grad_target[0], w, bucket=b)
-                    for b, (jd, nj, w) in enumerate(entry) if nj > 0]
-            return dsrc, pend
-        jobs_dev, n_jobs, weights = entry[0]
-        if grad_target is not None:
-            grads, ret = grad_target[0], None
-        else:
-            _, gtot = self.prog.grad_offsets()
-            grads = ret = torch.zeros(gtot, dtype=torch.float32, device=device)
-        L.launch("hn_mlp_wgrad", C.c_int(wgrad_mode_word(mode)), L.ptr(jobs_dev), C.c_int(n_jobs), L.ptr(stash), L.ptr(grads),
-                 L.stream_handle(), tag=self.prog.name)
-        return dsrc, ret
+        return entry
 
     def split_grads(self, flat: torch.Tensor) -> List[torch.Tensor]:
         offs, _ = self.prog.grad_offsets()

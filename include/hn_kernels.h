@@ -29,7 +29,8 @@ extern "C" {
 
 typedef void* hnStream_t; /* hipStream_t */
 
-#define HN_VERSION 321   /* 320: HnDwJob carries a second X slot; 321: HN_BOP_AUX w2 = tile word */
+#define HN_VERSION 330   /* 320: HnDwJob carries a second X slot; 321: HN_BOP_AUX w2 = tile word; 330: a level composited
+                            from two parts through a merge permutation (HnCompositeArgs.perm, hn_sample_pdf_split) */
 
 /* numeric modes of the MLP machine */
 #define HN_MODE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode (<=1e-4 vs oracle) */
@@ -330,7 +331,23 @@ typedef struct {
   float* d_raw;           /* (B,S) */
   const float* keep;      /* (B,S) 0/1 density mask (filter_sigma's bounding box) or NULL; forward and backward */
   float noise_scale;      /* noise_std; 1 for draws that arrive already scaled */
-  int32_t pad_;
+  int32_t split;          /* with `perm`: samples per ray held by part 0 (the rest, n_samples - split, by part 1) */
+  /* A level evaluated in TWO parts (ABI 330; NULL perm = one part, everything above as before).  The fine level of
+   * NerfModel.forward re-evaluates the coarse level's samples (hypernerf/models.py:752-768, model_utils.py:206-232:
+   * sort(cat(z_coarse, z_new))); the warp field / hyper sheet results of those points already exist, so the host
+   * evaluates the OLD samples (part 0: rgb, raw, warped — (B, split, .) in the coarse level's order) and the NEW
+   * samples (part 1: rgb1, raw1, warped1 — (B, n_samples - split, .) in draw order) separately and composites them
+   * through the merge permutation of hn_sample_pdf_split: sorted sample s of ray b is entry k = perm[b][s] of
+   * cat(part 0, part 1) of that ray.  z, noise, keep, weights and g_weights stay in sorted order.  The backward writes
+   * d_rgb / d_raw (part 0) and d_rgb1 / d_raw1 (part 1) in the parts' own order. */
+  const int32_t* perm;    /* (B,S) int32 or NULL */
+  const float* rgb1;      /* (B,S-split,3) */
+  const float* raw1;      /* (B,S-split) */
+  const float* warped1;   /* (B,S-split,warped_ld) or NULL */
+  float* d_rgb1;          /* backward */
+  float* d_raw1;          /* backward */
+  float* out_warped;      /* forward, optional: (B,S,warped_ld) = the parts' warped rows in sorted order (the level's
+                             `warped_points`, hypernerf/models.py:654-669) */
 } HnCompositeArgs;
 int hn_composite_forward(const HnCompositeArgs* a, hnStream_t stream);
 int hn_composite_backward(const HnCompositeArgs* a, hnStream_t stream);
@@ -356,6 +373,15 @@ int hn_sample_pdf(const float* weights, int w_ld, const float* bins, int n_bins,
                   int n_coarse, const float* u, const float* origins, const float* dirs, int ray_ld,
                   int n_rays, int n_fine, float* z_all, float* pts, int64_t* inds, float* z_samples,
                   hnStream_t stream);
+/* The same (ABI 330), for a fine level that evaluates only its NEW samples through the warp field (HnCompositeArgs.perm):
+ * two more outputs, each may be NULL — perm (B, n_coarse+n_fine) int32: sorted position s holds entry perm[b][s] of
+ * cat(z[b], z_samples[b]) (k < n_coarse: coarse sample k; else new sample k - n_coarse; equal depths keep that
+ * order), and pts_new (B, n_fine, 3) = o + z_samples * d in draw order.  z_all / pts / inds / z_samples are bit-for-bit
+ * those of hn_sample_pdf (the sort carries the index as a payload; keys are compared first).  perm needs z and z_all. */
+int hn_sample_pdf_split(const float* weights, int w_ld, const float* bins, int n_bins, const float* z,
+                        int n_coarse, const float* u, const float* origins, const float* dirs, int ray_ld,
+                        int n_rays, int n_fine, float* z_all, float* pts, int64_t* inds, float* z_samples,
+                        int32_t* perm, float* pts_new, hnStream_t stream);
 
 /* GLO embedding lookup (modules.GLOEmbed, hypernerf/modules.py:155-167) and its gradient:
  * d_table[idx[b]] += sum_s d_embed[b, s, col0 : col0+dim]. */

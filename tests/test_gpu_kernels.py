@@ -396,3 +396,67 @@ def test_ls_bench_handoff_pipeline_checks_out():
                  ["262144", "8", "2", "4", "32", "16", "1"], ["131072", "8", "2", "3", "32", "16", "1"]):
         out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and "check ok" in out.stdout and "SPIN TIMEOUT" not in out.stdout, (args, out.stdout[-600:])
+
+
+# ---- a level in two parts (round 5: the fine level re-uses the coarse level's warp / sheet results) ----------------
+@pytest.mark.parametrize("b,nc,nf", [(333, 64, 128), (17, 64, 64), (5, 8, 8), (3, 33, 65), (64, 128, 200)])
+def test_sample_pdf_split_permutation(b, nc, nf):
+    """hn_sample_pdf_split: the same depths, points, indices and samples as hn_sample_pdf BIT for bit, plus the merge
+    permutation (sorted position -> entry of cat(z, z_samples), equal depths in that order) and the new samples' points."""
+    o, d, _ = rays_for(7, b)
+    z, _ = torch.sort(H.uniform(7, "z", (b, nc), 0, 1), dim=-1)
+    w = H.uniform(7, "w", (b, nc), 0, 1) ** 4
+    w[0] = 0.0
+    u = H.uniform(7, "u", (b, nf), 0, 1)
+    if nf > 2:
+        u[1, 1] = u[1, 0]                       # two equal new samples
+    a = F.sample_pdf(w.to(DEV), z.to(DEV), u.to(DEV), o.to(DEV), d.to(DEV))
+    s = F.sample_pdf(w.to(DEV), z.to(DEV), u.to(DEV), o.to(DEV), d.to(DEV), split=True)
+    for x, y, name in zip(a, s[:4], ["z_all", "pts", "inds", "z_samples"]):
+        assert torch.equal(x, y), name
+    perm, pts_new = s[4].cpu().long(), s[5].cpu()
+    cat = torch.cat([z, s[3].cpu()], dim=1)
+    assert torch.equal(torch.sort(perm, dim=1)[0], torch.arange(nc + nf).expand(b, -1)), "perm is a permutation per ray"
+    assert torch.equal(torch.gather(cat, 1, perm), s[0].cpu()), "z_all == cat(z, z_samples)[perm]"
+    same = s[0].cpu()[:, 1:] == s[0].cpu()[:, :-1]
+    assert bool((perm[:, 1:][same] > perm[:, :-1][same]).all()), "equal depths keep the order of cat(z, z_samples)"
+    zs = s[3].cpu()
+    ref_new = o[:, None, :] + zs[..., None] * d[:, None, :]          # unfused mul + add, as the sorted points
+    assert torch.equal(pts_new, ref_new), "points of the new samples"
+
+
+@pytest.mark.parametrize("nc,nf", [(64, 64), (64, 128), (8, 8), (33, 70), (128, 200)])
+def test_composite_two_parts_equals_one_part(nc, nf):
+    """hn_composite_* reading a level as two parts through the permutation == the same level gathered into sorted
+    order first: forward outputs, the sorted warped rows and every gradient BIT for bit."""
+    b, s = 23, nc + nf
+    o, d, _ = rays_for(9, b)
+    rgb = H.uniform(9, "rgb", (b, s, 3), 0, 1)
+    raw = H.uniform(9, "raw", (b, s), -3, 6)
+    noise = H.normal(9, "noise", (b, s)) * 0.5
+    warped = H.uniform(9, "wp", (b, s, 7), -1, 1)
+    z_old, _ = torch.sort(H.uniform(9, "z", (b, nc), 0, 1), dim=-1)
+    z_new = H.uniform(9, "zn", (b, nf), 0, 1)
+    z_all, perm = torch.sort(torch.cat([z_old, z_new], 1), dim=1, stable=True)
+    keep = (H.uniform(9, "keep", (b, s), 0, 1) > 0.2).float()
+    g = lambda t, p: torch.gather(t, 1, p if t.dim() == 2 else p[..., None].expand(-1, -1, t.shape[-1]))
+    # one part: everything already in sorted order
+    rgb1_, raw1_ = g(rgb, perm).to(DEV).requires_grad_(True), g(raw, perm).to(DEV).requires_grad_(True)
+    one = F.composite(rgb1_, raw1_, noise.to(DEV), z_all.to(DEV), d.to(DEV), g(warped, perm).to(DEV), variant=0,
+                      sample_at_infinity=True, want_median=True, dust_threshold=0.01, keep=keep.to(DEV), noise_scale=0.7)
+    # two parts in their own order
+    parts = [t.to(DEV).requires_grad_(True) for t in (rgb[:, :nc], raw[:, :nc], rgb[:, nc:], raw[:, nc:])]
+    two = F.composite(parts[0], parts[1], noise.to(DEV), z_all.to(DEV), d.to(DEV), warped[:, :nc].contiguous().to(DEV),
+                      variant=0, sample_at_infinity=True, want_median=True, dust_threshold=0.01, keep=keep.to(DEV),
+                      noise_scale=0.7, rgb1=parts[2], raw1=parts[3], warped1=warped[:, nc:].contiguous().to(DEV),
+                      perm=perm.int().to(DEV))
+    for i, name in enumerate(["rgb", "depth", "acc", "weights", "med_depth", "med_points"]):
+        assert torch.equal(one[i], two[i]), name
+    assert torch.equal(two[6].cpu(), g(warped, perm)), "sorted warped rows"
+    gr = [H.uniform(10, f"g{i}", tuple(one[i].shape), -1, 1).to(DEV) for i in range(4)]
+    sum((one[i] * gr[i]).sum() for i in range(4)).backward()
+    sum((two[i] * gr[i]).sum() for i in range(4)).backward()
+    d_rgb = torch.zeros(b, s, 3).scatter_(1, perm[..., None].expand(-1, -1, 3), rgb1_.grad.cpu())
+    d_raw = torch.zeros(b, s).scatter_(1, perm, raw1_.grad.cpu())
+    assert torch.equal(torch.cat([parts[0].grad, parts[2].grad], 1).cpu(), d_rgb), "d rgb"
+    assert torch.equal(torch.cat([parts[1].grad, parts[3].grad], 1).cpu(), d_raw), "d raw"

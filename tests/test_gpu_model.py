@@ -544,11 +544,12 @@ def test_per_network_launch_path_matches_fused_level(case):
                 loss.backward()
                 torch.cuda.synchronize()
                 L.collect_kernel_times()
-                launches = sorted(k for k in L.KERNEL_TIMES if k.startswith("hn_mlp_forward"))
+                launches = sorted(k for k, v in L.KERNEL_TIMES.items() if k.startswith("hn_mlp_forward") for _ in v)
             finally:
                 L.KERNEL_TIMES = None
             res[fuse] = (out, {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, launches)
-        assert len(res[True][2]) <= 2 and all("level" in k or "template" in k for k in res[True][2]), res[True][2]
+        # fused: one launch per level — the fine level as two when it re-uses the coarse samples' warp (REUSE_COARSE)
+        assert len(res[True][2]) <= 3 and all("level" in k or "template" in k for k in res[True][2]), res[True][2]
         if case != "nowarp_cond":
             assert len(res[False][2]) > len(res[True][2]), (res[True][2], res[False][2])
         for lvl in ("coarse", "fine"):
@@ -557,6 +558,67 @@ def test_per_network_launch_path_matches_fused_level(case):
         assert res[False][1].keys() == res[True][1].keys()
         for k, g in res[True][1].items():
             assert_grad_close(res[False][1][k], g, 1e-4, f"unfused {case} d {k}")
+    finally:
+        HN.set_precision("bf16")
+
+
+@pytest.mark.parametrize("case", ["bendy", "bendy_cond", "bendy_rgbcond", "warp_noslice", "axis"])
+@pytest.mark.parametrize("sizes", [(32, 32, 24), (64, 128, 9), (8, 8, 16), (12, 20, 7)])
+def test_fine_level_reusing_coarse_warp_matches_full_fine_level(case, sizes):
+    """NerfModel.REUSE_COARSE: the fine level runs the fine template alone over the coarse level's warped points and the
+    whole level program over the NEW samples only, composited through the merge permutation — against the reference's
+    structure (every fine sample through warp field, hyper sheet and template: REUSE_COARSE = False) on the same model
+    and draws, fp32.  Same function values: every returned tensor of both levels BIT-identical, fine sample indices
+    included; gradients — the fine loss now reaches the shared networks through the coarse program's external
+    `warped_points` gradient, so sums are taken in another order — to 1e-4 of the tensor's largest entry; also with a
+    loss on `warped_points` itself, a bounding box and a dust threshold (filter_sigma) and a white background."""
+    HN.set_precision("fp32")
+    try:
+        kw = CASES[case]
+        nc, nf, b = sizes
+        seed = 97
+        rays_cpu = rays_for(seed, b)
+        rng = {"t_rand": H.uniform(seed, "t", (b, nc), 0, 1), "u": H.uniform(seed, "u", (b, nf), 0, 1),
+               "noise_coarse": H.normal(seed, "n1", (b, nc, 1)) * 0.5, "noise_fine": H.normal(seed, "n2", (b, nc + nf, 1)) * 0.5}
+        gt = H.uniform(seed, "gt", (b, 3), 0, 1).to(DEV)
+        res = {}
+        for reuse in (True, False):
+            m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, **kw)
+            load_hash(m, seed)
+            m = m.to(DEV)
+            m.REUSE_COARSE = reuse
+            m.use_white_background = True
+            o, d, idx = rays_cpu
+            rays = {"origins": o.to(DEV), "directions": d.to(DEV), "viewdirs": None,
+                    "metadata": {k: idx.to(DEV) for k in ("warp", "camera", "appearance", "time")}}
+            L.KERNEL_TIMES = {}
+            try:
+                out = m(rays, {}, rng={k: v.to(DEV) for k, v in rng.items()},
+                        render_opts={"dust_threshold": 0.05, "bounding_box": (-0.9, 0.9, -0.9, 0.9, -0.9, 0.9)})
+                gw = H.uniform(seed, "gw", tuple(out["fine"]["warped_points"].shape), -1, 1).to(DEV)
+                loss = (((out["coarse"]["rgb"] - gt) ** 2).mean() + ((out["fine"]["rgb"] - gt) ** 2).mean()
+                        + 1e-3 * (out["fine"]["warped_points"] * gw).sum() + 0.1 * out["fine"]["depth"].mean())
+                loss.backward()
+                torch.cuda.synchronize()
+                L.collect_kernel_times()
+                launches = {k: len(v) for k, v in L.KERNEL_TIMES.items() if k.startswith("hn_mlp_forward")}
+            finally:
+                L.KERNEL_TIMES = None
+            res[reuse] = (out, {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None},
+                          launches, m.last_sampling["inds"].clone(), m.compiled_programs(b))
+        assert sorted(res[True][2]) == ["hn_mlp_forward[level_coarse]", "hn_mlp_forward[level_fine]",
+                                        "hn_mlp_forward[template_fine_reuse]"], res[True][2]
+        assert sorted(res[False][2]) == ["hn_mlp_forward[level_coarse]", "hn_mlp_forward[level_fine]"], res[False][2]
+        pts = {name: n for name, _, n in res[True][4]}
+        assert pts == {"level_coarse": b * nc, "level_fine": b * nf, "level_fine_reuse": b * nc}, pts
+        assert {name: n for name, _, n in res[False][4]} == {"level_coarse": b * nc, "level_fine": b * (nc + nf)}
+        assert torch.equal(res[True][3], res[False][3]), "fine sample indices"
+        for lvl in ("coarse", "fine"):
+            for k in ("points", "warped_points", "rgb", "depth", "med_depth", "acc", "weights", "med_points"):
+                assert torch.equal(res[True][0][lvl][k], res[False][0][lvl][k]), f"reuse {case} {lvl}/{k}"
+        assert res[False][1].keys() == res[True][1].keys()
+        for k, g in res[False][1].items():
+            assert_grad_close(res[True][1][k], g, 1e-4, f"reuse {case} {sizes} d {k}")
     finally:
         HN.set_precision("bf16")
 
