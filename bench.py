@@ -39,6 +39,9 @@ import torch.distributed as dist
 
 PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12                             # HBM3E bytes/s, same guide
+# a mid-pool MI355X as the calibration probes see it (hypernerf_torch_amd/calibration.py): lines are
+# re-priced against it so that a box's clock / HBM luck does not read as a code change
+NOMINAL_BOX = {"mfma_probe_tflops": 1600.0, "hbm_probe_tbps": 6.0}
 
 CONFIGS = {
     1: dict(rays=256, nc=64, nf=0, precision="fp32", kind="legacy"),
@@ -63,6 +66,9 @@ def parse():
                          "reported as dtype 'bf16 (8-bit stash: e4m3 X, e5m2 dZ)'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="skip the box calibration (MFMA / HBM-stream probes before the timed region, hwmon power and "
+                         "clock during it)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--overlap", action="store_true",
                     help="data-parallel runs: all-reduce the gradient buffer in two buckets, the first in flight while the "
@@ -153,9 +159,14 @@ def build_workload(a, dev, rank):
 
     def programs():
         return {name: (prog, pts) for name, prog, pts in model.compiled_programs(b)}
+
+    def reference_programs():
+        # the reference's own count: every fine sample through every network (models.py:752-768), no reuse
+        return {name: (prog, pts) for name, prog, pts in model.compiled_programs(b, reference=True)}
     what = "SE3Field warp + axis_aligned_plane" if a.kind == "se3" else "use_warp bendy_sheet"
     workload = (f"NerfModel {what} nerf_embed+alpha_cond, {b} rays x ({a.nc}+{a.nf}) samples per GPU, fwd+bwd+Adam")
     data = dict(o=o, d=d, ids=ids, target=target.cpu(), model_kw=kw, extra=extra)
+    programs.reference = reference_programs
     return fwd_bwd, list(model.parameters()), programs, workload, model, data
 
 
@@ -177,31 +188,30 @@ def launch_plan(n, argv, port=None, env=None):
     for r in range(n):
         e = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
              "MASTER_ADDR": env.get("MASTER_ADDR", "127.0.0.1"), "MASTER_PORT": str(port)}
-        # dmabuf IPC: on the builder's pool RCCL's cross-process handle exchange fails without it (observed on one-GPU
-        # boxes only — an 8-GPU node has never been seen here).  The caller's own value always wins; HN_KEEP_IPC_ENV=1
-        # leaves the variable alone entirely.
-        if env.get("HN_KEEP_IPC_ENV", "0") != "1":
-            e["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # HSA_ENABLE_IPC_MODE_LEGACY is INHERITED as the caller has it (this image exports 0: dmabuf IPC).  The launcher
+        # only writes it on request — HN_SET_IPC_ENV=<value> — or on its one retry after a rank died before its first
+        # step (launch_ranks), where it flips the inherited setting and says so.
+        if env.get("HN_SET_IPC_ENV") not in (None, ""):
+            v = env["HN_SET_IPC_ENV"]
+            e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0" if v == "1" else v      # HN_SET_IPC_ENV=1: the pool's known-good value
         plan.append(([sys.executable, os.path.abspath(__file__)] + args, e))
     return plan
 
 
-def launch_ranks(a, argv):
-    """Parent of a plain `bench.py --gpus N` (N > 1): no GPU call happens in this process.  Children are ordinary
-    child processes (never an exec of a process that touched the GPU); rank 0's stdout is relayed, its JSON line
-    checked against --gpus, and the exit code is the worst of the children's."""
+def _run_ranks(plan, ready_dir, drop_env=()):
+    """Start the ranks of `plan`, relay nothing yet: returns (return codes, rank 0's stdout, ranks that got through their
+    warm-up steps — i.e. process group, collectives and graph capture all worked)."""
     import subprocess
-    plan = launch_plan(a.gpus, argv)
-    if a.launch_plan:
-        print(json.dumps({"n_ranks": len(plan), "ranks": [{"cmd": c, "env": e} for c, e in plan]}))
-        return 0
+    import threading
     procs = []
     for r, (cmd, e) in enumerate(plan):
-        procs.append(subprocess.Popen(cmd, env={**os.environ, **e}, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+        env = {**os.environ, **e, "HN_READY_DIR": ready_dir}
+        for k in drop_env:
+            env.pop(k, None)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
                                       stderr=None, text=True))
     # rank 0's stdout is drained by a thread; the main loop watches for a rank that died (the survivors would sit in
     # the rendezvous / a collective until its timeout) and ends exactly the processes it started
-    import threading
     buf = []
     rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
     rd.start()
@@ -215,12 +225,55 @@ def launch_ranks(a, argv):
         time.sleep(0.05)
     rcs = [p.wait() for p in procs]
     rd.join(timeout=10.0)
+    ready = sum(os.path.exists(os.path.join(ready_dir, f"rank{r}")) for r in range(len(plan)))
+    return rcs, (buf[0] if buf else ""), ready
+
+
+def launch_ranks(a, argv):
+    """Parent of a plain `bench.py --gpus N` (N > 1): no GPU call happens in this process.  Children are ordinary
+    child processes (never an exec of a process that touched the GPU); rank 0's stdout is relayed, its JSON line
+    checked against --gpus, and the exit code is the worst of the children's.  If a rank dies BEFORE every rank got
+    through its warm-up steps (rendezvous, RCCL initialisation, first collectives), the launcher retries ONCE in fresh
+    child processes with HSA_ENABLE_IPC_MODE_LEGACY flipped (set to 0 if the first attempt ran without it or with
+    another value, removed if it ran with 0) and reports which setting worked."""
+    import shutil
+    import tempfile
+    plan = launch_plan(a.gpus, argv)
+    if a.launch_plan:
+        print(json.dumps({"n_ranks": len(plan), "ranks": [{"cmd": c, "env": e} for c, e in plan]}))
+        return 0
+    first_ipc = plan[0][1].get("HSA_ENABLE_IPC_MODE_LEGACY", os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
+    attempts = []
+    ready_dir = tempfile.mkdtemp(prefix="hn_bench_ranks_")
+    try:
+        rcs, out0, ready = _run_ranks(plan, ready_dir)
+        attempts.append({"HSA_ENABLE_IPC_MODE_LEGACY": first_ipc if first_ipc is not None else "<unset>", "rcs": rcs,
+                         "ranks_through_warmup": ready})
+        if any(rcs) and ready < len(plan) and os.environ.get("HN_NO_IPC_RETRY", "0") != "1":
+            shutil.rmtree(ready_dir, ignore_errors=True)
+            os.makedirs(ready_dir, exist_ok=True)
+            flipped = None if first_ipc == "0" else "0"
+            plan2 = launch_plan(a.gpus, argv)         # a fresh rendezvous port
+            for _, e in plan2:
+                e.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+                if flipped is not None:
+                    e["HSA_ENABLE_IPC_MODE_LEGACY"] = flipped
+            print(f"bench.py launcher: rank return codes {rcs} with {ready} of {len(plan)} ranks through their warm-up; "
+                  f"retrying once with HSA_ENABLE_IPC_MODE_LEGACY={'<unset>' if flipped is None else flipped} "
+                  f"(was {'<unset>' if first_ipc is None else first_ipc})", file=sys.stderr)
+            rcs, out0, ready = _run_ranks(plan2, ready_dir, drop_env=("HSA_ENABLE_IPC_MODE_LEGACY",) if flipped is None else ())
+            attempts.append({"HSA_ENABLE_IPC_MODE_LEGACY": "<unset>" if flipped is None else flipped, "rcs": rcs,
+                             "ranks_through_warmup": ready})
+            plan = plan2
+            if not any(rcs):
+                print(f"bench.py launcher: the retry worked — HSA_ENABLE_IPC_MODE_LEGACY="
+                      f"{'<unset>' if flipped is None else flipped} is the setting for this node", file=sys.stderr)
+    finally:
+        shutil.rmtree(ready_dir, ignore_errors=True)
     if any(rcs):
-        ipc = plan[0][1].get("HSA_ENABLE_IPC_MODE_LEGACY")
-        print(f"bench.py launcher: rank return codes {rcs}; ranks ran with HSA_ENABLE_IPC_MODE_LEGACY="
-              f"{ipc if ipc is not None else '<inherited>'} (set it in the environment to override, HN_KEEP_IPC_ENV=1 "
-              "to make the launcher leave it alone), MASTER_ADDR=" + plan[0][1]["MASTER_ADDR"], file=sys.stderr)
-    out0 = buf[0] if buf else ""
+        print(f"bench.py launcher: rank return codes {rcs}; attempts: {json.dumps(attempts)} (HN_SET_IPC_ENV=<value> pins the "
+              "variable for the ranks, HN_NO_IPC_RETRY=1 disables the retry), MASTER_ADDR=" + plan[0][1]["MASTER_ADDR"],
+              file=sys.stderr)
     line = None
     for ln in (out0 or "").splitlines():
         if ln.startswith("{") and '"metric"' in ln:
@@ -239,6 +292,7 @@ def launch_ranks(a, argv):
                   f"collective saw {seen}", file=sys.stderr)
             rc = rc or 3
         res["config"]["launched_by"] = "bench.py (self-spawned ranks)"
+        res["config"]["launch_attempts"] = attempts
         print(json.dumps(res), flush=True)
     return rc
 
@@ -281,11 +335,15 @@ def main():
     from hypernerf_torch_amd.dist import all_gather_pixels
 
     HN.set_precision(a.precision)
+    # the three machine kernels time themselves (HnMlpArgs.timeline): per-kernel durations of the TIMED graph replays,
+    # not of a second, eager pass.  Enabled before the step is captured (the slots' addresses are baked into the graph).
+    L.TIMELINE = {} if not a.no_roofline else None
     from hypernerf_torch_amd import functional as HF0
     if a.fork_wgrad:
         HF0.set_wgrad_overlap(True)
     wgrad_schedule = "forked: side stream / parallel graph branch" if HF0.WGRAD_OVERLAP else "serial: one batched launch"
     fwd_bwd, params, programs, workload, model, data = build_workload(a, dev, rank)
+    reference_programs = getattr(programs, "reference", programs)
     use_graph = not a.no_graph
     # parameters and gradients live in one flat arena each: the kernels accumulate dW straight into it, Adam steps
     # one tensor, and data parallelism SUM-all-reduces the gradient buffer in place (the 1/N sits in the Adam kernel).
@@ -376,6 +434,23 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    barrier()
+    if os.environ.get("HN_READY_DIR"):       # tells the launcher that rendezvous, collectives and capture all worked
+        try:
+            open(os.path.join(os.environ["HN_READY_DIR"], f"rank{rank}"), "w").close()
+        except OSError:
+            pass
+    calibration = None
+    if rank == 0 and not a.no_calibration:
+        from hypernerf_torch_amd import calibration as CAL
+        calibration = CAL.probes(dev)
+        for _ in range(2):                  # back into the step's own thermal / clock state
+            step()
+    if L.TIMELINE is not None:
+        L.timeline_reset()
+    sampler = None
+    if rank == 0 and not a.no_calibration:
+        sampler = CAL.PowerSampler(dev).__enter__()
     reps = []
     for _ in range(max(1, a.repeats)):
         barrier()
@@ -389,6 +464,20 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         reps.append(dt)
+    timeline = L.timeline_read() if L.TIMELINE is not None else None       # the timed replays, nothing else
+    if sampler is not None:
+        sampler.__exit__(None, None, None)
+        calibration["timed_region"] = sampler.summary()
+        # hwmon's power figure is a running average over roughly a second: the timed region (steps x repeats, often
+        # < 0.2 s) is too short for it to settle, so the same step is replayed for another second, untimed, and sampled
+        with CAL.PowerSampler(dev) as soak:
+            t_soak = time.perf_counter()
+            while time.perf_counter() - t_soak < CALIB_SOAK_S:
+                for _ in range(20):
+                    step()
+                torch.cuda.synchronize()
+        calibration["soak"] = dict(soak.summary(), seconds=CALIB_SOAK_S,
+                                   what="the same step replayed back to back right after the timed region (untimed)")
     ranks_seen = world
     if dp:
         all_gather_pixels(out['fine']['rgb'].detach())     # eval-style pixel assembly works on this topology
@@ -414,22 +503,42 @@ def main():
     }
 
     res["build"] = L.build_id()
+    if calibration is not None:
+        res["calibration"] = calibration
     if rank == 0 and not a.no_roofline:
-        res.update(roofline(a, L, fwd_bwd, opt, programs(), dt / a.steps, b))
+        # per-kernel times of the machine kernels come from the timed region itself (kernel timeline); the eager pass
+        # (HIP events around every C-ABI launch) adds the small kernels' list at N = 1 only — with N > 1 every rank
+        # goes straight to the final barrier, no rank waits for another's rank-local work
+        n_timed = a.steps * max(1, a.repeats)
+        res.update(roofline(a, L, fwd_bwd, opt, programs(), reference_programs(), dt / a.steps, b, timeline, n_timed,
+                            eager=(world == 1 and not dp), calibration=calibration))
         if world > 1 and "roofline" in res:
-            # the eager per-kernel pass runs on rank 0 alone, after the timed region (no collective in it): its kernel
-            # times describe ONE GPU's share of the step, next to a whole-job `value`
-            res["roofline"]["scope"] = f"rank 0 only (1 of {world} GPUs), rank-local eager pass after the timed region"
+            res["roofline"]["scope"] = f"rank 0 (1 of {world} GPUs): its own kernels inside the timed region"
             if "hbm" in res:
                 res["hbm"]["scope"] = res["roofline"]["scope"]
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a, model, data, dev)
     if (rank == 0 and world == 1 and not dp and not a.no_also and a.config == 2 and a.precision == "bf16"
             and a.rays == CONFIGS[2]["rays"] and use_graph):
-        # the headline run is over; its ~10 GB stay allocated beside the children's (config 3: a 60 GB stash of 288)
+        # the headline run is over; its ~10 GB stay allocated beside the children's (config 3: a 60 GB stash of 288).
+        # The headline must survive whatever happens to the extras: if this process is told to stop while the children
+        # run (a driver timeout sends SIGTERM), it prints the line it has and exits.
+        import signal
         torch.cuda.synchronize()
-        res["also"] = also_block()
+
+        def _bail(signum, frame):
+            res["also"] = {"skipped": f"interrupted by signal {signum} while the extra configurations ran"}
+            sys.stdout.flush()
+            print(json.dumps(res), flush=True)
+            os._exit(0)
+        old_handlers = {sg: signal.signal(sg, _bail) for sg in (signal.SIGTERM, signal.SIGINT)}
+        try:
+            res["also"] = also_block()
+        finally:
+            for sg, h in old_handlers.items():
+                signal.signal(sg, h)
     if dp:
+        dist.barrier()                      # every rank is done with its own work: tear the group down together
         dist.destroy_process_group()
     if ranks_seen != world or world != a.gpus:
         print(f"bench.py: the collective counted {ranks_seen} ranks, WORLD_SIZE={world}, --gpus {a.gpus}", file=sys.stderr)
@@ -442,7 +551,8 @@ def main():
         print(json.dumps(res), flush=True)
 
 
-ALSO_BUDGET_S = 55.0        # the whole block; a child that would start later is recorded as skipped
+CALIB_SOAK_S = 1.2
+ALSO_BUDGET_S = 60.0        # the whole block; a child that would start later is recorded as skipped
 
 
 def also_block():
@@ -450,8 +560,9 @@ def also_block():
     the evaluation loop would otherwise only ever be builder-run lines under profiles/: the default run therefore
     appends short measurements of configs 3, 5, 1 (<= 10 steps x 3 repeats, HIP-graph replay, no CPU baseline) and of
     `inference.render_image` (tools/eval_bench.py) — each its own child process, started after the headline has been
-    measured and its memory released (ordinary children, never an exec), each with value, ms/step, the dominant
-    kernel's MFMA fraction and the kernel build it ran.  Bounded: ALSO_BUDGET_S for the block, 40 s per child."""
+    measured (its ~10 GB of device memory stay allocated next to the children's; ordinary children, never an exec),
+    each with value, ms/step, the dominant kernel's fractions and the kernel build it ran.  Bounded: ALSO_BUDGET_S for
+    the block, 40 s per child; the parent prints the headline anyway if it is told to stop meanwhile."""
     import subprocess
     t0 = time.perf_counter()
     out = {"note": "short runs appended to the config-2 headline; same metric, same definitions (bench.py --config N); "
@@ -468,7 +579,7 @@ def also_block():
         if argv is None:
             cmd = [sys.executable, os.path.join(ROOT, "tools", "eval_bench.py"), "32768", "3"]
         else:
-            cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-cpu-baseline", "--no-also"]
+            cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-cpu-baseline", "--no-also", "--no-calibration"]
         try:
             t1 = time.perf_counter()
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(40.0, left))
@@ -487,7 +598,8 @@ def also_block():
                 rl = j.get("roofline", {})
                 out[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "dtype": j["dtype"],
                              "steps": j["steps"], "repeats": j["repeats"], "ms_per_step_spread": j["ms_per_step_spread"],
-                             "workload": j["config"]["workload"], "kernel": rl.get("kernel"), "frac": rl.get("frac"),
+                             "workload": j["config"]["workload"], "kernel": rl.get("kernel"), "bound": rl.get("bound"),
+                             "frac": rl.get("frac"), "mfma_frac": rl.get("mfma_frac"),
                              "step_mfma_frac": j.get("step_mfma_frac"), "build": j.get("build"),
                              "wall_s": time.perf_counter() - t1}
         except subprocess.TimeoutExpired:
@@ -498,52 +610,72 @@ def also_block():
     return out
 
 
-def roofline(a, L, fwd_bwd, opt, progs, step_s, b):
-    """Second, eager pass: the same steps with HIP events around every C-ABI launch (on the launch stream).
-    Definitions: the path is MFMA-bound; algorithmic FLOPs = GEMM MACs x 2 of every Linear layer x
-    evaluated points, the same number for the forward, the backward-data and the weight-gradient products;
-    `roofline` describes the DOMINANT kernel (by time): achieved = its algorithmic FLOPs per launch / its average
-    launch duration, peak = dense MFMA peak of the operand dtype.  The HBM view of the same step sits in `hbm`:
-    algorithmic bytes (§8d: rays, targets, outputs, weights read forward + backward, gradients written), the bytes
-    the design really moves (`stash_bytes`: activations written by forward / backward and read once by the
-    weight-gradient kernel) and, when profiles/ holds a PMC summary for this configuration, the measured traffic."""
-    # per-kernel timing needs the kernels one after the other: concurrent launches (the forked weight-gradient
-    # schedule of the timed region) share the chip and inflate each other's durations
+def roofline(a, L, fwd_bwd, opt, progs, ref_progs, step_s, b, timeline, n_timed, eager=True, calibration=None):
+    """Per-kernel view of the step.
+
+    Times: the three machine kernels time THEMSELVES inside the timed graph replays (kernel timeline, include/
+    hn_kernels.h HnMlpArgs.timeline: last workgroup's end - first workgroup's start on the 100 MHz wall clock, summed
+    over the `n_timed` timed steps) — so `machine_kernel_ms_per_step` belongs to the timed region and sums to less than
+    `ms_per_step`; the rest of the step (13 small launches + dispatch gaps) is `other_ms_per_step`.  With `eager` a
+    second, eager pass with HIP events around every C-ABI launch lists the small kernels too (`eager_pass`).
+
+    FLOPs (2 x MACs of every Linear x evaluated points, the same for forward, backward-data and
+    weight-gradient products): `executed` = what these kernels really computed (REUSE_COARSE evaluates warp field and
+    hyper sheet once per coarse sample), `algorithmic` = the reference's own count for the same render.  Every MFMA
+    fraction is EXECUTED FLOPs / time / dense peak — skipped work is not credited.
+
+    `roofline` describes the dominant kernel by time.  hn_wgrad_kernel streams the activation stash once: its bound is
+    HBM (`bound: "hbm"`, achieved = stash bytes it reads per launch / its duration, peak 8 TB/s) with the MFMA fraction
+    of the same launch next to it (`mfma`); the forward / backward machines are matrix-pipe kernels (`bound: "mfma"`)."""
     from hypernerf_torch_amd import functional as HF
-    HF.set_wgrad_overlap(False)
-    L.KERNEL_TIMES = {}
-    for _ in range(a.steps):
-        fwd_bwd()           # rank-local: no collective here, the other ranks are not in this pass
-        opt.step()
-    times = L.collect_kernel_times()
-    L.KERNEL_TIMES = None
-    tot = {k: sum(v) for k, v in times.items()}
-    flops_pass = sum(2.0 * macs_per_point(p) * pts for p, pts in progs.values())      # one of fwd / bwd / wgrad
-    prec_key = "bf16" if a.precision == "bf16s8" else a.precision      # the 8-bit MFMA of the opt-in mode runs at the bf16 rate
     from hypernerf_torch_amd import machine as HM
+    prec_key = "bf16" if a.precision == "bf16s8" else a.precision      # the 8-bit MFMA of the opt-in mode runs at the bf16 rate
+    flops_pass = sum(2.0 * macs_per_point(p) * pts for p, pts in progs.values())      # one of fwd / bwd / wgrad, executed
+    flops_pass_ref = sum(2.0 * macs_per_point(p) * pts for p, pts in ref_progs.values())
     mode = HF.mode_of(a.precision)
     tile_bytes = HM.mode_consts(mode)[1]
     stash_read = 0.0
     for prog, pts_list in _points_by_program(progs):
         for pts in pts_list:
-            j = prog.wgrad_jobs(mode, pts)
-            stash_read += float(((j["n_nt"] + j["n_kt"]).astype("int64") * (j["blk1"] - j["blk0"])).sum()) * tile_bytes
-    groups = {"forward": ("hn_mlp_forward", "hn_level_forward"), "backward": ("hn_mlp_backward", "hn_level_backward"),
-              "wgrad": ("hn_mlp_wgrad",)}
+            stash_read += prog.wgrad_stream_bytes(mode, pts)
     sym = {"forward": "hn_mlp_fwd_kernel", "backward": "hn_mlp_bwd_kernel", "wgrad": "hn_wgrad_kernel"}
-    per_kernel, kern = {}, {}
-    for g, prefixes in groups.items():
-        ks = [k for k in tot if k.split("[")[0].startswith(prefixes)]
-        if not ks:
-            continue
-        ms_step = sum(tot[k] for k in ks) / a.steps
-        launches = sum(len(times[k]) for k in ks) / a.steps
-        kern[g] = (ms_step, launches)
+    prefix = {"forward": "hn_mlp_forward", "backward": "hn_mlp_backward", "wgrad": "hn_mlp_wgrad"}
+    kern, detail = {}, {}
+    if timeline:
+        for g, pre in prefix.items():
+            hits = {k: v for k, v in timeline.items() if k.startswith(pre) and v["runs"] > 0}
+            if hits:
+                kern[g] = (sum(v["ms"] for v in hits.values()) / n_timed, sum(v["runs"] for v in hits.values()) / n_timed)
+                detail.update({k: v["ms"] / n_timed for k, v in hits.items()})
+    eager_times = None
+    if eager or not kern:
+        # per-kernel timing needs the kernels one after the other: concurrent launches (the forked weight-gradient
+        # schedule of the timed region) share the chip and inflate each other's durations
+        HF.set_wgrad_overlap(False)
+        keep_tl, L.TIMELINE = L.TIMELINE, None
+        L.KERNEL_TIMES = {}
+        for _ in range(a.steps):
+            fwd_bwd()           # rank-local: no collective here
+            opt.step()
+        times = L.collect_kernel_times()
+        L.KERNEL_TIMES = None
+        L.TIMELINE = keep_tl
+        eager_times = {k: sum(v) / a.steps for k, v in times.items()}
+        if not kern:            # no timeline (HN kernels built without it / --no-graph paths): fall back to the events
+            for g, pre in prefix.items():
+                ks = [k for k in times if k.split("[")[0].startswith(pre)]
+                if ks:
+                    kern[g] = (sum(eager_times[k] for k in ks), sum(len(times[k]) for k in ks) / a.steps)
+    per_kernel = {}
+    for g, (ms_step, launches) in kern.items():
         mf = flops_pass / (ms_step * 1e-3)
         per_kernel[sym[g]] = {"ms_per_step": ms_step, "launches_per_step": launches,
                               "mfma": {"achieved": mf / 1e12, "peak": PEAK[prec_key] / 1e12, "unit": "TFLOP/s",
-                                       "frac": mf / PEAK[prec_key], "algorithmic_flops_per_step": flops_pass}}
-    out = {}
+                                       "frac": mf / PEAK[prec_key], "executed_flops_per_step": flops_pass}}
+    out = {"executed_flops_per_step": 3.0 * flops_pass, "algorithmic_flops_per_step": 3.0 * flops_pass_ref,
+           "flops_note": "3 x (2 x MACs of every Linear x points): forward, backward-data and weight-gradient products. "
+                         "executed = the points these kernels evaluated; algorithmic = the reference's count for the same "
+                         "render (every fine sample through warp field and hyper sheet again, models.py:752-768)"}
     if kern:
         dom = max(kern, key=lambda k: kern[k][0])
         ms_step, launches = kern[dom]
@@ -554,16 +686,43 @@ def roofline(a, L, fwd_bwd, opt, progs, step_s, b):
         uniq = {id(p): p for p, _ in progs.values()}
         n_params = sum(sum(q.numel() for q in p.params) for p in uniq.values())
         alg_bytes = b * 68.0 + 2.0 * n_params * (2 if prec_key == "bf16" else 4) + 4.0 * n_params
-        rl = {"bound": "mfma", "kernel": sym[dom] + ("<true>" if prec_key == "bf16" else "<false>"),
-              "achieved": pk["achieved"], "peak": pk["peak"], "unit": "TFLOP/s", "frac": pk["frac"],
-              "traffic": None, "avg_launch_ms": ms_step / launches, "launches_per_step": launches,
-              "algorithmic_flops_per_launch": flops_pass / launches,
-              "note": "dominant kernel by time; achieved = GEMM FLOPs of its launches in a step (SURVEY.md §8d: 2 x "
-                      "MACs of every Linear x evaluated points) / their summed HIP-event duration on the launch "
-                      "stream; traffic = measured HBM bytes per launch of that kernel (profiles/, PMC passes)",
-              "per_kernel": per_kernel,
-              "kernel_ms_per_step": {k: tot[k] / a.steps for k in sorted(tot, key=tot.get, reverse=True)},
-              "sum_kernel_ms_per_step": sum(tot.values()) / a.steps}
+        machine_ms = sum(v[0] for v in kern.values())
+        rl = {"kernel": sym[dom] + ("<true>" if prec_key == "bf16" else "<false>"),
+              "avg_launch_ms": ms_step / launches, "launches_per_step": launches,
+              "times_from": "kernel timeline inside the timed graph replays" if timeline else "eager pass, HIP events",
+              "mfma": {"achieved": pk["achieved"], "peak": pk["peak"], "unit": "TFLOP/s", "frac": pk["frac"],
+                       "executed_flops_per_launch": flops_pass / launches},
+              "traffic": None,
+              "per_kernel": per_kernel, "machine_kernel_ms_per_step": dict(sorted(detail.items(), key=lambda kv: -kv[1])),
+              "sum_machine_kernel_ms_per_step": machine_ms,
+              "other_ms_per_step": 1e3 * step_s - machine_ms,
+              "sum_kernel_ms_per_step": 1e3 * step_s,
+              "sum_note": "machine kernels (timeline) + other_ms_per_step (the small launches and every dispatch gap of the "
+                          "replayed graph) = ms_per_step by construction"}
+        if dom == "wgrad":
+            gbps = stash_read / launches / (ms_step / launches * 1e-3) / 1e9
+            rl.update({"bound": "hbm", "bound_detail": "hbm-stream: the launch reads every stash tile (layer inputs X and "
+                       "layer gradients dZ of the step, written by the forward / backward machines) exactly once by LDS-DMA",
+                       "achieved": gbps, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gbps / (HBM_PEAK / 1e9),
+                       "hbm_frac": gbps / (HBM_PEAK / 1e9), "mfma_frac": pk["frac"],
+                       "bytes_per_launch": stash_read / launches,
+                       "note": "dominant kernel by time; achieved = stash bytes the launch streams / its duration inside the "
+                               "timed region; `mfma` = the same launch's executed GEMM FLOPs against the dense peak; traffic = "
+                               "measured HBM bytes per launch (profiles/, PMC passes)"})
+            if calibration:
+                rl["frac_of_box_stream_probe"] = gbps / 1e3 / calibration["hbm_probe_tbps"]
+        else:
+            rl.update({"bound": "mfma", "achieved": pk["achieved"], "peak": pk["peak"], "unit": "TFLOP/s",
+                       "frac": pk["frac"], "mfma_frac": pk["frac"],
+                       "note": "dominant kernel by time; achieved = executed GEMM FLOPs of its launches in a step (SURVEY.md "
+                               "§8d) / their duration inside the timed region"})
+            if calibration:
+                rl["frac_of_box_mfma_probe"] = pk["achieved"] / calibration["mfma_probe_tflops"]
+        if eager_times is not None:
+            rl["eager_pass"] = {"kernel_ms_per_step": {k: eager_times[k] for k in sorted(eager_times, key=eager_times.get, reverse=True)},
+                                "sum_kernel_ms_per_step": sum(eager_times.values()),
+                                "note": "second pass, launches issued eagerly with HIP events around each: lists the small "
+                                        "kernels; runs ~2 % slower than the replayed graph (event records between launches)"}
         hbm = {"algorithmic_bytes_per_step": alg_bytes, "stash_bytes_read_per_step": stash_read,
                "stash_bytes_moved_per_step": 2.0 * stash_read, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                "wgrad_stream_achieved": (stash_read / (kern["wgrad"][0] * 1e-3) / 1e9) if "wgrad" in kern else None,
@@ -579,6 +738,18 @@ def roofline(a, L, fwd_bwd, opt, progs, step_s, b):
         out["hbm"] = hbm
     out["step_tflops"] = 3.0 * flops_pass / step_s / 1e12
     out["step_mfma_frac"] = 3.0 * flops_pass / step_s / PEAK[prec_key]
+    out["step_mfma_frac_if_reference_flops_were_credited"] = 3.0 * flops_pass_ref / step_s / PEAK[prec_key]
+    if calibration and kern:
+        # the step re-priced on a nominal box: matrix-pipe kernels scale with the box's MFMA probe, the stash stream with
+        # its HBM probe, the rest is left as measured — lets lines from different boxes of the pool be compared
+        ref_m, ref_h = NOMINAL_BOX["mfma_probe_tflops"], NOMINAL_BOX["hbm_probe_tbps"]
+        mm = sum(kern[g][0] for g in ("forward", "backward") if g in kern)
+        wg = kern.get("wgrad", (0.0, 0))[0]
+        norm = mm * calibration["mfma_probe_tflops"] / ref_m + wg * calibration["hbm_probe_tbps"] / ref_h + (1e3 * step_s - mm - wg)
+        calibration["normalised"] = {"ms_per_step_on_nominal_box": norm, "nominal_box": NOMINAL_BOX,
+                                     "value_on_nominal_box": a.rays * (a.nc + a.nf) / (norm * 1e-3),
+                                     "how": "forward + backward machine time x (this box's MFMA probe / nominal) + weight-"
+                                            "gradient time x (this box's HBM probe / nominal) + the rest as measured"}
     return out
 
 

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libhn_hip.so")
-SOURCES = ["hn_mlp.hip", "hn_render.hip"]
+SOURCES = ["hn_mlp.hip", "hn_render.hip", "hn_calib.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hn_kernels.h")
 BUILD_MACROS = ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX")     # build-time tuning knobs (A/B experiments)
 
@@ -57,6 +57,7 @@ class HnMlpArgs(C.Structure):
         ("prof", C.c_void_p), ("comps", C.c_void_p), ("n_comps", C.c_int32), ("embed_reg_mask", C.c_int32),
         ("embed_grad", C.c_void_p), ("embed_idx", C.c_void_p), ("embed_rows", C.c_int32), ("embed_dim", C.c_int32),
         ("embed_col", C.c_int8 * 32), ("n_trig_comps", C.c_int32), ("wide_ops", C.c_int32), ("dz_scale_log2", C.c_int32), ("trig_lo_planes", C.c_int32),
+        ("timeline", C.c_void_p),
     ]
 
 
@@ -101,11 +102,11 @@ DWJOB_DT = np.dtype([("z_off", "<u8"), ("x_off", "<u8"), ("z_nt", "<i4"), ("x_nt
                      ("x2_t0", "<i4"), ("n_kt1", "<i4"), ("pad2", "<i4")])
 
 EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
-           "hn_mlp_wgrad_batched", "hn_mlp_workspace_bytes",
+           "hn_mlp_wgrad_batched", "hn_mlp_wgrad_batched_t", "hn_mlp_workspace_bytes",
            "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf", "hn_sample_pdf_split",
            "hn_embed_gather", "hn_embed_backward", "hn_se3_apply_forward", "hn_se3_apply_backward", "hn_se3_warp_forward", "hn_se3_warp_backward", "hn_generate_rays", "hn_adam_step",
            "hn_mse_loss_forward", "hn_mse_loss_backward", "hn_depth_index", "hn_random_fill",
-           "hn_probe_mfma"]
+           "hn_probe_mfma", "hn_calib_mfma", "hn_calib_stream"]
 
 _lib = None
 
@@ -201,6 +202,43 @@ def launch(name: str, *args, tag: str = ""):
     e1.record()
     _PENDING.append((name + (f"[{tag}]" if tag else ""), e0, e1))
     check(rc, name)
+
+
+# Kernel timeline (include/hn_kernels.h, HnMlpArgs.timeline): when TIMELINE is a dict, every launch of the three machine
+# kernels is handed a device uint64[8] slot per launch name and times ITSELF — also inside a HIP-graph replay, where no
+# host-side event can sit between two kernels.  Enable BEFORE the step is captured (the pointers are baked into the
+# graph); `timeline_reset()` zeroes the sums (e.g. after the warm-up), `timeline_read()` returns ms per name.
+TIMELINE = None
+TIMELINE_TICK_S = 1e-8        # wall_clock64(): 100 MHz
+
+
+def timeline_slot(name: str, device) -> int:
+    if TIMELINE is None:
+        return 0
+    t = TIMELINE.get(name)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise HnError(f"kernel timeline: first launch of {name} inside a stream capture (run a warm-up step first)")
+        t = TIMELINE[name] = torch.zeros(8, dtype=torch.int64, device=device)
+    return t.data_ptr()
+
+
+def timeline_reset():
+    torch.cuda.synchronize()
+    for t in (TIMELINE or {}).values():
+        t.zero_()
+    torch.cuda.synchronize()
+
+
+def timeline_read() -> dict:
+    """{launch name: {'ms': summed duration, 'runs': launches, 'span_ms': first start .. last end}} (synchronises)."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, t in (TIMELINE or {}).items():
+        v = t.cpu().tolist()
+        out[name] = {"ms": v[4] * TIMELINE_TICK_S * 1e3, "runs": int(v[5]), "span_ms": (v[7] - v[6]) * TIMELINE_TICK_S * 1e3,
+                     "first_start_tick": v[6], "last_end_tick": v[7]}
+    return out
 
 
 def collect_kernel_times():

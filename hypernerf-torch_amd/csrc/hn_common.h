@@ -25,6 +25,35 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define HN_DEV __device__ __forceinline__
 
+// Kernel timeline (HnMlpArgs.timeline, hn_mlp_wgrad_batched_t): a launch measures ITSELF — the first workgroup to
+// arrive stores the 100 MHz wall clock, the last one to finish adds (now - start) to a running sum and counts the run —
+// so that a step replayed as ONE HIP graph still yields per-kernel durations of exactly the replays that were timed
+// (no events exist between the nodes of a graph).  Two device-scope atomics per workgroup; tickets re-arm themselves.
+//   t[0] start of the current run   t[1] its end   t[2] arrive ticket   t[3] finish ticket
+//   t[4] sum of (end - start) over runs, in 10 ns ticks   t[5] runs   t[6] first start ever   t[7] last end
+HN_DEV void hn_timeline_begin(uint64_t* t) {
+  if (t == nullptr || threadIdx.x != 0) return;
+  const uint64_t now = wall_clock64();
+  if (atomicAdd(reinterpret_cast<unsigned*>(t + 2), 1u) == 0u) {
+    atomicExch(reinterpret_cast<unsigned long long*>(t), (unsigned long long)now);
+    if (atomicAdd(reinterpret_cast<unsigned long long*>(t + 6), 0ull) == 0ull)
+      atomicExch(reinterpret_cast<unsigned long long*>(t + 6), (unsigned long long)now);
+  }
+}
+HN_DEV void hn_timeline_end(uint64_t* t) {
+  if (t == nullptr || threadIdx.x != 0) return;
+  const uint64_t now = wall_clock64();
+  if (atomicAdd(reinterpret_cast<unsigned*>(t + 3), 1u) == gridDim.x - 1) {
+    const uint64_t start = atomicAdd(reinterpret_cast<unsigned long long*>(t), 0ull);
+    atomicExch(reinterpret_cast<unsigned long long*>(t + 1), (unsigned long long)now);
+    atomicExch(reinterpret_cast<unsigned long long*>(t + 7), (unsigned long long)now);
+    atomicAdd(reinterpret_cast<unsigned long long*>(t + 4), (unsigned long long)(now - start));
+    atomicAdd(reinterpret_cast<unsigned long long*>(t + 5), 1ull);
+    atomicExch(reinterpret_cast<unsigned*>(t + 2), 0u);
+    atomicExch(reinterpret_cast<unsigned*>(t + 3), 0u);
+  }
+}
+
 HN_DEV int hn_rho(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 HN_DEV int hn_pi16(int h, int j) { return 8 * (j >> 2) + 4 * h + (j & 3); }
 

@@ -567,6 +567,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   const int r = lane & 31, h = lane >> 5;
   constexpr int PTS = M::WAVES * 32;
   const int ntiles = (a.n_points + PTS - 1) / PTS;
+  hn_timeline_begin(a.timeline);
 #ifdef HN_PROF
   long long* prof_buf = reinterpret_cast<long long*>(a.prof);
   const bool prof_on = prof_buf != nullptr && blockIdx.x == 0 && wave == 0;
@@ -772,6 +773,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
       }
     }
   }
+  hn_timeline_end(a.timeline);
 }
 
 // Backward machine: if the NEXT op is a layer with a ReLU mask, start loading its mask words (raw, not complemented)
@@ -814,6 +816,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
   HnDFeat* dfeat_lds = reinterpret_cast<HnDFeat*>(feat_lds + ((a.n_feat + 1) & ~1));      // bf16 kernel only
   float* srcv = reinterpret_cast<float*>(BF16 ? reinterpret_cast<char*>(dfeat_lds + a.n_feat)
                                               : reinterpret_cast<char*>(dfeat_lds)) + wave * (a.n_comps * 32);
+  hn_timeline_begin(a.timeline);
 #ifdef HN_PROF
   long long* prof_buf = reinterpret_cast<long long*>(a.prof);
   const bool prof_on = prof_buf != nullptr && blockIdx.x == 0 && wave == 0;
@@ -1049,6 +1052,7 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
       }
     }
   }
+  hn_timeline_end(a.timeline);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1282,11 +1286,13 @@ struct HnDwBatchTable {
   HnDwBatch b[HN_MAX_WGRAD_BATCH];
   float unscale;          // HN_MODE_BF16_S8: 2^-dz_scale_log2, applied to every sum before it is added to the gradient
   const int32_t* order;   // optional: workgroup g runs job order[g] & 0xffffff of batch order[g] >> 24
+  uint64_t* timeline;     // optional: the launch times itself (hn_common.h)
   int n;
 };
 
 template <bool BF16, bool S8 = false>
 __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable tab) {
+  hn_timeline_begin(tab.timeline);
   // which batch holds this workgroup's job (<= 8 scalar compares on kernel-argument data)
   int job_id = blockIdx.x, which = 0;
   if (tab.order != nullptr) {     // host-made global order (heaviest job first across ALL batches)
@@ -1314,7 +1320,10 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (job_id >= n_jobs) return;
+  if (job_id >= n_jobs) {
+    hn_timeline_end(tab.timeline);
+    return;
+  }
   const HnDwJob jb = jobs[job_id];
   const int c = lane & 31, h = lane >> 5;
   const int gn = jb.pad & 255, gk = (jb.pad >> 8) & 255, bps = (jb.pad >> 16) & 255;
@@ -1524,6 +1533,7 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
           if (row >= 0 && row < jb.r_end) atomicAdd(gb + row, S8 ? accb[i % NB][q] * tab.unscale : accb[i % NB][q]);
         }
   }
+  hn_timeline_end(tab.timeline);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1752,6 +1762,11 @@ extern "C" int hn_mlp_wgrad(int mode, const HnDwJob* jobs, int n_jobs, const voi
 
 extern "C" int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches, int n_batches, const int32_t* order_dev,
                                     hnStream_t stream) {
+  return hn_mlp_wgrad_batched_t(mode, batches, n_batches, order_dev, nullptr, stream);
+}
+
+extern "C" int hn_mlp_wgrad_batched_t(int mode, const HnDwBatch* batches, int n_batches, const int32_t* order_dev,
+                                      uint64_t* timeline_dev, hnStream_t stream) {
   if (n_batches < 0 || n_batches > HN_MAX_WGRAD_BATCH) return -1;
   if (n_batches > 0 && batches == nullptr) return -3;
   HnDwBatchTable tab = {};
@@ -1767,6 +1782,7 @@ extern "C" int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches, int n_ba
     total += batches[i].n_jobs;
   }
   tab.order = order_dev;
+  tab.timeline = timeline_dev;
 #ifdef HN_PROF
   if (hn_wgrad_prof != nullptr && tab.n < HN_MAX_WGRAD_BATCH) tab.b[HN_MAX_WGRAD_BATCH - 1].jobs = (const HnDwJob*)hn_wgrad_prof;
 #endif

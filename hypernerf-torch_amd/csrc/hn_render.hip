@@ -250,11 +250,6 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
           s_d += w * zz;
           s_w += w;
           if (s < S - 1) s_wl += w;
-          if (a.out_warped != nullptr) {     // the level's `warped_points` in sorted order, gathered from the parts
-            const float* wsrc = (pr.second ? a.warped1 : a.warped) + pr.row * a.warped_ld;
-            float* wdst = a.out_warped + (row + s) * a.warped_ld;
-            for (int cc = 0; cc < a.warped_ld; ++cc) wdst[cc] = wsrc[cc];
-          }
         }
         if (a.out_med_depth != nullptr) {
           // first sample whose inclusive weight sum reaches 0.5 (model_utils.py:319-345)
@@ -273,6 +268,17 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
           csum = __shfl(cs, 63, 64);
         }
       }
+    }
+  }
+  if (!BACKWARD && a.out_warped != nullptr) {
+    // the level's `warped_points` in sorted order, gathered from the parts: the ray's S x ld floats as ONE contiguous
+    // run — lane-consecutive stores (a row per lane would scatter 28-byte pieces over the wave's store)
+    const int ld = a.warped_ld, n = S * ld;
+    float* wdst = a.out_warped + row * ld;
+    for (int e = lane; e < n; e += 64) {
+      const int s = e / ld, cc = e - s * ld;
+      const HnPartRow pr = hn_part_row(a, ray, row, s);
+      wdst[e] = (pr.second ? a.warped1 : a.warped)[pr.row * ld + cc];
     }
   }
   if (!BACKWARD) {

@@ -421,13 +421,15 @@ class NerfModel(nn.Module):
             self._template_calls[key] = call
         return call
 
-    def compiled_programs(self, n_rays: int):
+    def compiled_programs(self, n_rays: int, reference: bool = False):
         """[(name, machine.Program, points evaluated per forward pass of `n_rays` rays)] of the programs this model has
-        compiled so far (i.e. after a forward pass) — what bench.py prices the MFMA roofline with."""
+        compiled so far (i.e. after a forward pass) — what bench.py prices the MFMA roofline with.  `reference`: the
+        point counts of the REFERENCE's forward (every fine sample through every network, models.py:752-768) whatever
+        this model executed (REUSE_COARSE evaluates the shared networks on fewer points)."""
         nc, nf = self.num_coarse_samples, self.num_fine_samples
         out = []
         fused = False
-        reuse = getattr(self, "_reused_coarse", False)
+        reuse = None if reference else getattr(self, "_reused_coarse", None)
         for key, call in self._template_calls.items():
             if call is None:            # the ("nofuse",) marker
                 continue
@@ -443,7 +445,7 @@ class NerfModel(nn.Module):
                 out.append((f"template_{lvl}", call.program, n_rays * (nc if lvl == 'coarse' else nc + nf)))
         if fused:
             return [o for o in out if o[0].startswith("level_")]      # incl. level_fine_reuse
-        both = n_rays * (2 * nc + nf)
+        both = n_rays * ((nc + nf) if reuse == 'outside' else (2 * nc + nf))    # REUSE_COARSE: coarse + new samples
         for attr, name in (("warp_field", "warp_field"), ("hyper_sheet_mlp", "hyper_sheet_mlp")):
             mod = getattr(self, attr, None)
             for call in getattr(mod, "_calls", {}).values():
@@ -534,31 +536,14 @@ class NerfModel(nn.Module):
             if idx.shape[-1] == 1 and idx.dim() > 1:
                 idx = idx.squeeze(-1)
             from_table = use_warp and self.hyper_slice_method == 'axis_aligned_plane'
-            warped_rows = None
-            if use_warp and from_table and isinstance(self.warp_field, warping.SE3Field):
-                # config 5: the exp-map launch writes `warped_points` = [xyz | GLO row] itself (no index_select + cat)
-                xyz, warped_rows = self.warp_field.warp_with_rows(points, emb_mod.embed.weight, idx)
-            elif use_warp:
-                needs_rows = isinstance(self.warp_field, warping.TranslationField)
-                xyz = self.warp_field.warp(points, self.warp_embed(metadata[self.warp_embed_key]) if needs_rows else None,
-                                           extra_params)
-            else:
-                xyz = points
+            xyz, warped_rows = self._warp_outside(points, metadata, idx, emb_mod, from_table, use_warp, extra_params)
             ge = torch.is_grad_enabled() and xyz.requires_grad
             call = self._template_gather_call(level, from_table, ge)
             rgb, alpha = F.run_program(call, [xyz.reshape(b * s, 3), viewdirs if self.use_viewdirs else None,
                                               emb_mod.embed.weight], s, self.precision, gather_idx=idx)
-            if warped_rows is not None:
-                warped = warped_rows
-            elif from_table:
-                with torch.no_grad():
-                    flat = idx.reshape(-1)
-                    safe = flat.clamp(0, emb_mod.embed.weight.shape[0] - 1)
-                    rows = emb_mod.embed.weight.index_select(0, safe)
-                    rows.masked_fill_((safe != flat)[:, None], float("nan"))   # as the kernels' own gather poisons it
-                warped = torch.cat([xyz, rows[:, None, :].expand(b, s, rows.shape[-1])], dim=-1)
-            else:
-                warped = xyz
+            warped = self._warped_of(xyz, warped_rows, from_table, emb_mod, idx, b, s)
+            if use_warp:        # what a fine level re-using these samples needs (REUSE_COARSE)
+                self._level_state = {'level': level, 'xyz': xyz, 'rows': warped_rows is not None, 'tab': tab}
             return self._composite_level(out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity,
                                          dust, keep, b, s, points.device, level)
         if use_warp:
@@ -586,8 +571,47 @@ class NerfModel(nn.Module):
         return self._composite_level(out, warped, rgb, alpha, z_vals, directions, noise, use_sample_at_infinity,
                                      dust, keep, b, s, points.device, level)
 
+    def _warp_outside(self, points, metadata, idx, emb_mod, from_table, use_warp, extra_params):
+        """The warp of a level whose warp field runs as its own program (SE3Field, or a TranslationField next to a
+        gathered template): (xyz (B,S,3), `warped_points` rows (B,S,3+H) written by the exp-map launch | None)."""
+        if use_warp and from_table and isinstance(self.warp_field, warping.SE3Field):
+            # config 5: the exp-map launch writes `warped_points` = [xyz | GLO row] itself (no index_select + cat)
+            return self.warp_field.warp_with_rows(points, emb_mod.embed.weight, idx)
+        if use_warp:
+            needs_rows = isinstance(self.warp_field, warping.TranslationField)
+            return self.warp_field.warp(points, self.warp_embed(metadata[self.warp_embed_key]) if needs_rows else None,
+                                        extra_params), None
+        return points, None
+
+    @staticmethod
+    def _warped_of(xyz, warped_rows, from_table, emb_mod, idx, b, s):
+        """`warped_points` of a level whose template read its hyper coordinates from the GLO table."""
+        if warped_rows is not None:
+            return warped_rows
+        if not from_table:
+            return xyz
+        with torch.no_grad():
+            flat = idx.reshape(-1)
+            safe = flat.clamp(0, emb_mod.embed.weight.shape[0] - 1)
+            rows = emb_mod.embed.weight.index_select(0, safe)
+            rows.masked_fill_((safe != flat)[:, None], float("nan"))   # as the kernels' own gather poisons it
+        return torch.cat([xyz, rows[:, None, :].expand(b, s, rows.shape[-1])], dim=-1)
+
+    def _can_reuse_coarse(self, use_warp, metadata_encoded, metadata, return_warp_jacobian) -> Optional[str]:
+        """'fused' / 'outside' when the fine level may take the warp of the coarse level's samples from the coarse
+        level (REUSE_COARSE), else None: the coarse level ran as one fused program, or with its warp field as a program
+        of its own in front of a gathered template (SE3Field: BASELINE config 5)."""
+        if not (self.REUSE_COARSE and use_warp) or return_warp_jacobian:
+            return None
+        if self._can_fuse_level(use_warp, metadata_encoded, metadata):
+            return 'fused'
+        st = getattr(self, '_level_state', None)
+        if st is not None and st['level'] == 'coarse' and st['xyz'].shape[1] == self.num_coarse_samples:
+            return 'outside'
+        return None
+
     def _render_fine_reusing_coarse(self, coarse, points, z_vals, pts_new, perm, directions, viewdirs, metadata,
-                                    use_sample_at_infinity, render_opts, noise):
+                                    use_sample_at_infinity, render_opts, noise, extra_params=None, how='fused'):
         """The fine level (models.py:752-768 -> render_samples 587-671) without re-evaluating the shared networks on the
         coarse level's samples (REUSE_COARSE).  `points` / `z_vals` (B, Nc+Nf, .) sorted, `pts_new` (B, Nf, 3) the new
         samples in draw order, `perm` (B, Nc+Nf) the merge permutation.  Returns the same dict as render_samples."""
@@ -602,23 +626,44 @@ class NerfModel(nn.Module):
                 xmin, xmax, ymin, ymax, zmin, zmax = render_opts['bounding_box']
                 keep = ((points[..., 0] >= xmin) & (points[..., 0] <= xmax) & (points[..., 1] >= ymin)
                         & (points[..., 1] <= ymax) & (points[..., 2] >= zmin) & (points[..., 2] <= zmax)).float()
-        idx = metadata[self.warp_embed_key]
-        if idx.shape[-1] == 1 and idx.dim() > 1:
-            idx = idx.squeeze(-1)
-        table = self.warp_embed.embed.weight
         vd = viewdirs if self.use_viewdirs else None
-        # (i) the coarse level's samples: their warped points exist — the fine template alone
-        w_old = coarse['warped_points']                                   # (B, Nc, 3 + H), output of the coarse program
         from_table = self.hyper_slice_method == 'axis_aligned_plane'
-        n_hyper = w_old.shape[-1] - 3 if self.hyper_slice_method == 'bendy_sheet' else 0
-        ge = torch.is_grad_enabled() and w_old.requires_grad
-        call_old = self._template_reuse_call('fine', n_hyper, from_table, ge)
-        rgb_old, alpha_old = F.run_program(call_old, [w_old.reshape(b * nc, w_old.shape[-1]), vd, table], nc,
-                                           self.precision, gather_idx=idx)
-        # (ii) the new samples: warp field -> hyper sheet -> fine template, one launch
-        call_new = self._level_call('fine')
-        w_new, rgb_new, alpha_new = F.run_program(call_new, [pts_new.reshape(b * nf, 3), vd, table, None], nf,
-                                                  self.precision, gather_idx=idx)
+        w_old = coarse['warped_points']                                   # (B, Nc, 3 + H)
+        if how == 'fused':
+            idx = metadata[self.warp_embed_key]
+            if idx.shape[-1] == 1 and idx.dim() > 1:
+                idx = idx.squeeze(-1)
+            table = self.warp_embed.embed.weight
+            # (i) the coarse level's samples: their warped points exist (output of the coarse program) — the fine
+            # template alone
+            n_hyper = w_old.shape[-1] - 3 if self.hyper_slice_method == 'bendy_sheet' else 0
+            ge = torch.is_grad_enabled() and w_old.requires_grad
+            call_old = self._template_reuse_call('fine', n_hyper, from_table, ge)
+            rgb_old, alpha_old = F.run_program(call_old, [w_old.reshape(b * nc, w_old.shape[-1]), vd, table], nc,
+                                               self.precision, gather_idx=idx)
+            # (ii) the new samples: warp field -> hyper sheet -> fine template, one launch
+            call_new = self._level_call('fine')
+            w_new, rgb_new, alpha_new = F.run_program(call_new, [pts_new.reshape(b * nf, 3), vd, table, None], nf,
+                                                      self.precision, gather_idx=idx)
+        else:
+            # the warp field is a program of its own (SE3Field + exp-map launch): the fine template over the coarse
+            # level's warped xyz, then field + template over the new samples
+            st = self._level_state
+            emb_mod, key = st['tab']
+            idx = metadata[key]
+            if idx.shape[-1] == 1 and idx.dim() > 1:
+                idx = idx.squeeze(-1)
+            table = emb_mod.embed.weight
+            xyz_old = st['xyz']
+            ge = torch.is_grad_enabled() and xyz_old.requires_grad
+            rgb_old, alpha_old = F.run_program(self._template_gather_call('fine', from_table, ge),
+                                               [xyz_old.reshape(b * nc, 3), vd, table], nc, self.precision, gather_idx=idx)
+            xyz_new, rows_new = self._warp_outside(pts_new, metadata, idx, emb_mod, from_table, True, extra_params)
+            ge = torch.is_grad_enabled() and xyz_new.requires_grad
+            rgb_new, alpha_new = F.run_program(self._template_gather_call('fine', from_table, ge),
+                                               [xyz_new.reshape(b * nf, 3), vd, table], nf, self.precision, gather_idx=idx)
+            w_new = self._warped_of(xyz_new, rows_new, from_table, emb_mod, idx, b, nf)
+            self._level_state = None
         scale = 1.0
         if noise is None and (self.noise_std is not None) and self.noise_std > 0.0 and self.use_stratified_sampling:
             noise = getattr(self, '_auto_noise', {}).pop('fine', None)
@@ -710,6 +755,7 @@ class NerfModel(nn.Module):
                         self._auto_noise[name[6:]] = t
                     else:
                         rng[name] = t
+        self._level_state = None
         z_vals, points = model_utils.sample_along_rays(origins, directions, self.num_coarse_samples, near, far,
                                                        self.use_stratified_sampling, self.use_linear_disparity,
                                                        t_rand=rng.get('t_rand'))
@@ -732,14 +778,14 @@ class NerfModel(nn.Module):
                     if u is None:
                         u = torch.linspace(0, 1, self.num_fine_samples).to(origins.device).expand(b, -1).contiguous()
                         self._det_u[key] = u
-            self._reused_coarse = bool(self.REUSE_COARSE and not return_warp_jacobian
-                                       and self._can_fuse_level(use_warp, metadata_encoded, metadata))
-            if self._reused_coarse:
+            how = self._can_reuse_coarse(use_warp, metadata_encoded, metadata, return_warp_jacobian)
+            self._reused_coarse = how
+            if how is not None:
                 z_fine, pts_fine, inds, _, perm, pts_new = F.sample_pdf(coarse['weights'], z_vals, u, origins,
                                                                         directions, split=True)
                 fine = self._render_fine_reusing_coarse(coarse, pts_fine, z_fine, pts_new, perm, directions, viewdirs,
                                                         metadata, use_sample_at_infinity, render_opts,
-                                                        rng.get('noise_fine'))
+                                                        rng.get('noise_fine'), extra_params, how)
             else:
                 z_fine, pts_fine, inds, _ = F.sample_pdf(coarse['weights'], z_vals, u, origins, directions)
                 fine = self.render_samples('fine', pts_fine, z_fine, directions, viewdirs, metadata, extra_params,
@@ -750,4 +796,5 @@ class NerfModel(nn.Module):
             out['fine'] = fine
             # not part of the reference's return value: kept for tests / debugging
             self.last_sampling = {'z_coarse': z_vals, 'z_fine': z_fine, 'inds': inds, 'u': u}
+        self._level_state = None        # (holds the coarse level's warped xyz, i.e. its autograd graph)
         return out

@@ -913,7 +913,8 @@ def launch_resolved_wgrads(shares: Sequence[ResolvedWgrad]):
                 ids = np.concatenate([(k << 24) | np.arange(p.n_jobs, dtype=np.int64) for k, p in enumerate(grp)])
                 order = torch.from_numpy(ids[np.argsort(-w, kind="stable")].astype(np.int32)).to(grp[0].stash.device)
                 _ORDER_CACHE[key] = order
-            L.launch("hn_mlp_wgrad_batched", C.c_int(wgrad_mode_word(mode)), arr, C.c_int(len(grp)), L.ptr(order), L.stream_handle(),
+            L.launch("hn_mlp_wgrad_batched_t", C.c_int(wgrad_mode_word(mode)), arr, C.c_int(len(grp)), L.ptr(order),
+                     C.c_void_p(L.timeline_slot("hn_mlp_wgrad_batched", grp[0].stash.device)), L.stream_handle(),
                      tag="batched")
 
 
@@ -1004,7 +1005,7 @@ class MlpRunner:
         return d
 
     def _args(self, d, mode, n_points, samples_per_ray, training, ops, n_ops, wstream_ptr, n_chunks, srcs, dsts,
-              stash, masks, dsrc, embed=None):
+              stash, masks, dsrc, embed=None, kind="hn_mlp_forward"):
         a = L.HnMlpArgs()
         a.mode, a.n_points, a.samples_per_ray, a.training = mode, n_points, samples_per_ray, int(training)
         a.n_ops, a.n_chunks, a.n_dsrc = n_ops, n_chunks, self.prog.n_dsrc if dsrc is not None else 0
@@ -1012,6 +1013,7 @@ class MlpRunner:
         a.n_bias, a.n_feat = max(32, self.prog.bias_len), max(1, len(self.prog.feat_table))
         a.max_groups = max([ly.aux.groups for ly in self.prog.layers if ly.aux is not None], default=0)
         a.prof = L.PROF_BUFFER.data_ptr() if L.PROF_BUFFER is not None else 0
+        a.timeline = L.timeline_slot(f"{kind}[{self.prog.name}]", d.bias.device)
         a.comps, a.n_comps = d.comps.data_ptr(), len(self.prog.comp_map)
         # (HN_FORCE_WIDE=1: A/B knob — take the kernel build that carries the wide ops although the program has none)
         wide = any(ly.out is not None and ly.out.wide for ly in self.prog.layers) or _FORCE_WIDE
@@ -1120,7 +1122,7 @@ class MlpRunner:
             raise L.HnError("the in-kernel embedding gradient needs samples_per_ray % 32 == 0")
         a = self._args(d, mode, n_points, samples_per_ray, True, self._ops(device, mode, n_points)[1],
                        len(self.prog.bwd_ops), d.wstream.data_ptr() + d.n_fwd_units * 1024, d.bwd_chunks, srcs, [],
-                       stash, masks, dsrc, embed)
+                       stash, masks, dsrc, embed, kind="hn_mlp_backward")
         L.launch("hn_mlp_backward", C.byref(a), L.stream_handle(), tag=self.prog.name)
         goffs = tuple(grad_target[1]) if grad_target is not None else None
         deferred = defer and grad_target is not None

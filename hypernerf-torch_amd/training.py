@@ -163,12 +163,25 @@ class TrainStep:
         elif not collective_capturable(self.group):
             why = f"backend {dist.get_backend(self.group)} stages through the host"
         else:
+            g = None
             try:
                 g = self._capture(self._whole_dp)
-                self.dp_graph = "one graph: forward + backward + all-reduce + Adam"
-                return g
             except Exception as e:      # noqa: BLE001 (whatever the runtime says about capturing the collective)
                 why = f"capturing the all-reduce raised {type(e).__name__}: {str(e)[:120]}"
+                # a capture that died part-way may have queued weight-gradient shares whose stashes belong to the
+                # abandoned graph's pool: they must never be launched
+                F.drop_pending_wgrads()
+            # every rank takes the SAME form of the step (a rank replaying one graph next to a rank issuing an eager
+            # all-reduce would still match collective for collective, but time and behave differently): agree on it
+            ok = torch.tensor([1.0 if g is not None else 0.0], device=self.arena.data.device)
+            if self.world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if float(ok.item()) > 0.5:
+                self.dp_graph = "one graph: forward + backward + all-reduce + Adam"
+                return g
+            if g is not None:
+                why = "another rank could not capture the all-reduce"
+                g = None
         self.dp_graph = f"three pieces: graph | eager all-reduce | Adam ({why})"
         return self._capture_data_parallel()
 

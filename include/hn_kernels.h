@@ -187,6 +187,11 @@ typedef struct {
   int32_t trig_lo_planes; /* 1: the lo planes are staged (exactly reduced sine arguments); 0: hi only + one shared zero
                              plane (programs whose staging would not fit into LDS otherwise: hn_mlp_forward returns -6
                              when ring + tables + 8 waves x (n_comps + n_trig + (lo ? n_trig : 1)) x 128 B > 158 KiB) */
+  uint64_t* timeline;     /* optional (ABI 330), device uint64[8], zero-initialised by the caller once: the launch times
+                             itself — [4] += last workgroup's end - first workgroup's start in ticks of the 100 MHz
+                             wall clock, [5] += 1, [0]/[1] start / end of the last run, [6]/[7] first start / last end
+                             ever; [2], [3] are tickets the launch leaves at zero.  Lets a step that is replayed as one
+                             HIP graph report per-kernel durations of the timed replays themselves.  NULL = off. */
 } HnMlpArgs;
 
 /* weight packing: one descriptor per 1-KiB unit of a stream */
@@ -273,6 +278,9 @@ typedef struct {
 } HnDwBatch;
 int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches_host, int n_batches, const int32_t* order_dev,
                          hnStream_t stream);
+/* The same with a kernel timeline (HnMlpArgs.timeline; NULL = off). */
+int hn_mlp_wgrad_batched_t(int mode, const HnDwBatch* batches_host, int n_batches, const int32_t* order_dev,
+                           uint64_t* timeline_dev, hnStream_t stream);
 
 /* ---- per-ray kernels --------------------------------------------------------------------- */
 
@@ -451,6 +459,15 @@ int hn_se3_warp_forward(const float* w, int w_ld, const float* v, int v_ld, cons
 int hn_se3_warp_backward(const float* w, int w_ld, const float* v, int v_ld, const float* points, int p_ld,
                          const float* g_out, int g_ld, int n_points, float* d_w, int dw_ld, float* d_v, int dv_ld,
                          float* d_points, hnStream_t stream);
+
+/* Box calibration for a benchmark line (no reference counterpart: measurement infrastructure).  Both kernels time
+ * themselves into t_dev (device uint64[16], zeroed by the caller; layout of HnMlpArgs.timeline in [0..7]).
+ * hn_calib_mfma: every wave of 512 workgroups x 8 waves runs `iters` x 8 independent v_mfma_f32_32x32x16_bf16 from
+ * registers — FLOPs = 512 * 8 * iters * 8 * 32768; t[8] / t[9] = shader-clock (s_memtime) / 100 MHz wall-clock ticks of
+ * one wave's loop, i.e. the sustained shader clock = 1e8 * t[8] / t[9] Hz.
+ * hn_calib_stream: 256 workgroups stream n_bytes (a multiple of 64 KiB is read) once through LDS-DMA. */
+int hn_calib_mfma(int iters, float* sink_dev, uint64_t* t_dev, hnStream_t stream);
+int hn_calib_stream(const void* buf_dev, long long n_bytes, float* sink_dev, uint64_t* t_dev, hnStream_t stream);
 
 /* Debug/probe: runs one MFMA of each kind on identifiable data (layout self-test on real hardware). */
 int hn_probe_mfma(float* out_bf16_acc, float* out_f32_acc, float* out_glds, hnStream_t stream);

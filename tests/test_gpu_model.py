@@ -562,7 +562,8 @@ def test_per_network_launch_path_matches_fused_level(case):
         HN.set_precision("bf16")
 
 
-@pytest.mark.parametrize("case", ["bendy", "bendy_cond", "bendy_rgbcond", "warp_noslice", "axis"])
+@pytest.mark.parametrize("case", ["bendy", "bendy_cond", "bendy_rgbcond", "warp_noslice", "axis", "se3_axis", "se3_axis_cond",
+                                  "se3_noslice"])
 @pytest.mark.parametrize("sizes", [(32, 32, 24), (64, 128, 9), (8, 8, 16), (12, 20, 7)])
 def test_fine_level_reusing_coarse_warp_matches_full_fine_level(case, sizes):
     """NerfModel.REUSE_COARSE: the fine level runs the fine template alone over the coarse level's warped points and the
@@ -574,7 +575,9 @@ def test_fine_level_reusing_coarse_warp_matches_full_fine_level(case, sizes):
     loss on `warped_points` itself, a bounding box and a dust threshold (filter_sigma) and a white background."""
     HN.set_precision("fp32")
     try:
-        kw = CASES[case]
+        se3 = case.startswith("se3")
+        kw = {"se3_axis": CASES["axis"], "se3_axis_cond": dict(CASES["axis"], use_nerf_embed=True, use_alpha_cond=True),
+              "se3_noslice": CASES["warp_noslice"]}[case] if se3 else CASES[case]
         nc, nf, b = sizes
         seed = 97
         rays_cpu = rays_for(seed, b)
@@ -584,6 +587,8 @@ def test_fine_level_reusing_coarse_warp_matches_full_fine_level(case, sizes):
         res = {}
         for reuse in (True, False):
             m = models.NerfModel(EMB, n_samples_coarse=nc, n_samples_fine=nf, noise_std=0.5, **kw)
+            if se3:         # BASELINE config 5: the warp field is its own program in front of a gathered template
+                m.warp_field = warping.SE3Field(in_ch=3)
             load_hash(m, seed)
             m = m.to(DEV)
             m.REUSE_COARSE = reuse
@@ -606,12 +611,25 @@ def test_fine_level_reusing_coarse_warp_matches_full_fine_level(case, sizes):
                 L.KERNEL_TIMES = None
             res[reuse] = (out, {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None},
                           launches, m.last_sampling["inds"].clone(), m.compiled_programs(b))
-        assert sorted(res[True][2]) == ["hn_mlp_forward[level_coarse]", "hn_mlp_forward[level_fine]",
-                                        "hn_mlp_forward[template_fine_reuse]"], res[True][2]
-        assert sorted(res[False][2]) == ["hn_mlp_forward[level_coarse]", "hn_mlp_forward[level_fine]"], res[False][2]
-        pts = {name: n for name, _, n in res[True][4]}
-        assert pts == {"level_coarse": b * nc, "level_fine": b * nf, "level_fine_reuse": b * nc}, pts
-        assert {name: n for name, _, n in res[False][4]} == {"level_coarse": b * nc, "level_fine": b * (nc + nf)}
+        if case == "se3_noslice":
+            # no embedding reaches the template: the level runs through map_points / query_template network by network
+            # and the fine level is not split (REUSE_COARSE covers the fused and the gathered-template levels)
+            assert res[True][2] == res[False][2] and res[True][4][0][2] == res[False][4][0][2]
+        elif se3:
+            # field program: coarse + NEW samples only; the fine template still sees every fine sample, in two launches
+            assert res[True][2] == {"hn_mlp_forward[SE3Field]": 2, "hn_mlp_forward[template_coarse]": 1,
+                                    "hn_mlp_forward[template_fine]": 2}, res[True][2]
+            assert res[False][2] == {"hn_mlp_forward[SE3Field]": 2, "hn_mlp_forward[template_coarse]": 1,
+                                     "hn_mlp_forward[template_fine]": 1}, res[False][2]
+            assert {n for name, _, n in res[True][4] if name == "warp_field"} == {b * (nc + nf)}
+            assert {n for name, _, n in res[False][4] if name == "warp_field"} == {b * (2 * nc + nf)}
+        else:
+            assert sorted(res[True][2]) == ["hn_mlp_forward[level_coarse]", "hn_mlp_forward[level_fine]",
+                                            "hn_mlp_forward[template_fine_reuse]"], res[True][2]
+            assert sorted(res[False][2]) == ["hn_mlp_forward[level_coarse]", "hn_mlp_forward[level_fine]"], res[False][2]
+            pts = {name: n for name, _, n in res[True][4]}
+            assert pts == {"level_coarse": b * nc, "level_fine": b * nf, "level_fine_reuse": b * nc}, pts
+            assert {name: n for name, _, n in res[False][4]} == {"level_coarse": b * nc, "level_fine": b * (nc + nf)}
         assert torch.equal(res[True][3], res[False][3]), "fine sample indices"
         for lvl in ("coarse", "fine"):
             for k in ("points", "warped_points", "rgb", "depth", "med_depth", "acc", "weights", "med_points"):

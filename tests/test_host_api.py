@@ -311,14 +311,15 @@ def test_bench_launch_plan():
     for r, rk in enumerate(plan["ranks"]):
         e = rk["env"]
         assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"]) == (str(r), str(r), "4")
-        assert e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        # the IPC variable is INHERITED by the ranks, not written by the launcher (round 5: opt-in)
+        assert e["MASTER_ADDR"] == "127.0.0.1" and "HSA_ENABLE_IPC_MODE_LEGACY" not in e
         ports.add(e["MASTER_PORT"])
         assert rk["cmd"][1].endswith("bench.py") and "--launch-plan" not in rk["cmd"]
         assert rk["cmd"][2:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert len(ports) == 1
     # the 8-GPU node of BASELINE config 4: 8 commands, RANK == LOCAL_RANK == 0..7 (one rank per GPU, never two on one),
-    # one rendezvous port, the caller's MASTER_PORT honoured; the IPC variable is the caller's if set, and left alone
-    # entirely under HN_KEEP_IPC_ENV=1
+    # one rendezvous port, the caller's MASTER_PORT honoured; the IPC variable is written only on request
+    # (HN_SET_IPC_ENV: "1" = the pool's known-good 0, any other value verbatim) — the ranks inherit the caller's otherwise
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod_plan", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
@@ -328,10 +329,11 @@ def test_bench_launch_plan():
     assert [e["LOCAL_RANK"] for _, e in plan8] == [str(i) for i in range(8)] == [e["RANK"] for _, e in plan8]
     assert {e["MASTER_PORT"] for _, e in plan8} == {"29611"} and {e["WORLD_SIZE"] for _, e in plan8} == {"8"}
     assert all(c[2:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] for c, _ in plan8)
-    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for _, e in plan8)
-    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
-               for _, e in bench.launch_plan(2, [], env={"HSA_ENABLE_IPC_MODE_LEGACY": "1"}))
-    assert all("HSA_ENABLE_IPC_MODE_LEGACY" not in e for _, e in bench.launch_plan(2, [], env={"HN_KEEP_IPC_ENV": "1"}))
+    assert all("HSA_ENABLE_IPC_MODE_LEGACY" not in e for _, e in plan8)
+    assert all("HSA_ENABLE_IPC_MODE_LEGACY" not in e
+               for _, e in bench.launch_plan(2, [], env={"HSA_ENABLE_IPC_MODE_LEGACY": "1"}))      # inherited as it is
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for _, e in bench.launch_plan(2, [], env={"HN_SET_IPC_ENV": "1"}))
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "2" for _, e in bench.launch_plan(2, [], env={"HN_SET_IPC_ENV": "2"}))
     # a rank whose WORLD_SIZE disagrees with --gpus refuses to run (it would report a point of the wrong curve)
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
