@@ -225,6 +225,23 @@ class _ProgramFn(torch.autograd.Function):
                 src_grads.append(g.view(shp))
             except RuntimeError:
                 src_grads.append(g.reshape(shp))
+        # heads that ADD a source to their result (OutSpec.residual: TranslationField's p + delta, warping.py:90-96):
+        # the output gradient reaches that source directly as well
+        for ly in prog.layers:
+            o = ly.out
+            if o is None or o.residual is None or o.wide:
+                continue
+            rs, rc = o.residual
+            if rs >= len(src_grads) or ctx.src_shapes[rs] is None or not ctx.needs_input_grad[6 + rs] or gouts[o.dst] is None:
+                continue
+            n = prog._rows(ly)
+            g_res = gouts[o.dst].reshape(ctx.n_points, -1)[:, o.col:o.col + n]
+            width = ctx.src_shapes[rs][-1]
+            cur = src_grads[rs]
+            cur = torch.zeros(ctx.n_points, width, dtype=torch.float32, device=g_res.device) if cur is None \
+                else cur.reshape(ctx.n_points, width).clone()
+            cur[:, rc:rc + n] += g_res
+            src_grads[rs] = cur.view(ctx.src_shapes[rs])
         if flat is None:
             return (None, None, None, None, None, None, *src_grads, *([None] * len(prog.params)))
         pgrads = call.runner.split_grads(flat)

@@ -51,9 +51,9 @@ class TranslationField(nn.Module):
         key = (per_ray_embed, pts_grad, embed_grad)
         call = self._calls.get(key)
         if call is None:
-            if pts_grad:
-                raise NotImplementedError("gradient w.r.t. the input points of the warp field (residual path) "
-                                          "is not needed by the reference's training path and not implemented")
+            # pts_grad: d(p + delta(p)) / dp = the output gradient itself (the residual, added to the source's gradient
+            # by functional._ProgramFn.backward) + the encoder's share through the MLP (reference: autograd through
+            # warping.py:90-96; the render path never asks for it — sample points carry no gradient)
             layers = modules.mlp_layers(self.mlp, "mlp", self.input_aux(0, 1, pts_grad, embed_grad), None,
                                         OutSpec(0, 0, "none", residual=(0, 0)), GradIn(4, 0))
             call = F.ProgramCall(Program(layers, name="TranslationField"), [False, per_ray_embed], [3], [("g", 0)])

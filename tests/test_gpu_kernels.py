@@ -388,7 +388,7 @@ def test_ls_bench_handoff_pipeline_checks_out():
     (the timing is the tool's business, not this test's)."""
     import subprocess
     exe = os.path.join(ROOT, "tools", "ls_bench")
-    if not os.path.exists(exe):
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(exe + ".hip"):
         from hypernerf_torch_amd import _lib
         subprocess.run([_lib.hipcc_path(), "--offload-arch=gfx950", "-O3", "-o", exe, exe + ".hip"], check=True,
                        capture_output=True, timeout=300)

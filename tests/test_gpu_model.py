@@ -297,9 +297,24 @@ def test_model_vs_oracle_larger(case, precision):
         ra = torch.cat([p[k].grad.double().reshape(-1) for k in ks])
         tot = float(ra.norm())
         assert float((ga - ra).norm()) <= 0.2 * tot, f"{case}: whole-gradient rel L2 {float((ga - ra).norm()) / tot:.3f}"
+        # per tensor (round 5): against the fp32 oracle a bf16 gradient tensor is only good to ~0.2 — a bound that would
+        # not notice a wrong small layer.  Every tensor that carries >= 0.1 % of the gradient is therefore compared with
+        # the oracle under the SAME arithmetic contract (O.bf16_operands(): bf16 matmul operands, fp32 accumulate) at
+        # 6e-2; the old 0.25 stays for the tail below that only (0.01 % .. 0.1 % of the gradient).
+        pc = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        with O.bf16_operands():
+            O.mse_loss(O.nerf_model_forward(pc, cfg, o, d, idx, rng), gt).backward()
+        worst = 0.0
         for k in ks:
-            if float(p[k].grad.norm()) >= 1e-2 * tot:
-                assert_grad_close(named[k].grad, p[k].grad, 0.25, f"{case} d {k}", frobenius=True)
+            if float(p[k].grad.norm()) >= 1e-3 * tot:
+                assert_grad_close(named[k].grad, pc[k].grad, 6e-2, f"{case} d {k} (bf16 contract)", frobenius=True)
+                worst = max(worst, float((named[k].grad.detach().cpu().double() - pc[k].grad.double()).norm()
+                                         / (pc[k].grad.double().norm() + 1e-30)))
+            elif float(p[k].grad.norm()) >= 1e-4 * tot:
+                # the tail: sums of a few mixed-sign terms (single-element biases ...) whose relative error is large by
+                # nature; below 0.01 % of the gradient a tensor is covered by the whole-gradient bound only
+                assert_grad_close(named[k].grad, pc[k].grad, 0.25, f"{case} d {k} (tail, bf16 contract)", frobenius=True)
+        print(f"{case}: worst per-tensor rel L2 vs the bf16-operand oracle (tensors >= 0.1 % of the gradient): {worst:.3e}")
 
 
 @pytest.mark.parametrize("case,size", [("bendy_cond", (96, 32, 32)), ("axis", (96, 32, 32)), ("bendy_cond", (1024, 64, 64))],
@@ -356,12 +371,12 @@ def test_bf16_mode_vs_bf16_operand_oracle(case, size):
         from gpu_common import _record
         _record(f"bf16-contract {case}: whole gradient", "rel L2", rel, 2.5e-2)
         per = {k: float((named[k].grad.detach().cpu().double() - p[k].grad.double()).norm() / (p[k].grad.double().norm() + 1e-30))
-               for k in ks if float(p[k].grad.norm()) >= 1e-2 * tot}
+               for k in ks if float(p[k].grad.norm()) >= 1e-3 * tot}
         print(f"bf16-contract {case}: whole-gradient rel L2 {rel:.3e}; per tensor: " +
               ", ".join(f"{k.replace('.weight', '.w').replace('.bias', '.b')}={v:.3f}" for k, v in sorted(per.items())))
         assert rel <= 2.5e-2, f"{case}: whole-gradient rel L2 {rel:.3e} against the bf16-operand oracle"
         for k in ks:
-            if float(p[k].grad.norm()) >= 1e-2 * tot:
+            if float(p[k].grad.norm()) >= 1e-3 * tot:       # every tensor with >= 0.1 % of the gradient (round 5; 1 % before)
                 assert_grad_close(named[k].grad, p[k].grad, 0.06, f"bf16-contract {case} d {k}", frobenius=True)
     finally:
         HN.set_precision("bf16")
@@ -1268,6 +1283,78 @@ def test_g13_se3_transform_through_the_kernel(golden_dir):
     assert_close(R, T_ref[:3, :3], 1e-4, "g13 se3_T rotation through hn_se3_apply")
     assert_close(t, T_ref[:3, 3], 1e-4, "g13 se3_T translation through hn_se3_apply")
     assert torch.equal(T_ref[3], torch.tensor([0.0, 0.0, 0.0, 1.0]))
+
+
+def test_rigid_body_module_surface(golden_dir):
+    """`hypernerf.rigid_body` (round 5): the importable names of the reference's module (rigid_body.py:21-93) over the
+    SE(3) kernel.  The reference's own call — exp_se3(S (1,1,6), theta (1,1)) — against its recorded 4x4 (G13, the one
+    valid result upstream can produce), then batches against the oracle's restatement of the cited formulas: skew
+    (exact), exp_so3 / exp_se3 (1e-4), the homogeneous helpers (exact), the single-point layout upstream returns."""
+    from hypernerf_torch_amd.hypernerf import rigid_body as RB
+    g = np.load(os.path.join(golden_dir, "g13_misc.npz"))
+    T_ref = torch.from_numpy(g["se3_T"]).reshape(4, 4)
+    S = torch.tensor([[[0.0, 0.0, 1.0, 1.0, 0.0, 0.0]]], device=DEV)
+    T = RB.exp_se3(S, torch.full((1, 1), 0.5, device=DEV))
+    assert T.shape == (4, 4)
+    assert_close(T, T_ref, 1e-4, "rigid_body.exp_se3 vs the reference's own 4x4 (G13)")
+    n, seed = 257, 47
+    w = H.normal(seed, "rbw", (n, 3))
+    w = w / w.norm(dim=-1, keepdim=True)
+    v = H.normal(seed, "rbv", (n, 3))
+    th = H.uniform(seed, "rbt", (n,), 1e-3, 3.0)
+    assert torch.equal(RB.skew(w.to(DEV)).cpu(), O.skew(w))
+    x = H.normal(seed, "rbx", (n, 3))
+    assert_close((RB.skew(w.to(DEV)) @ x.to(DEV)[..., None])[..., 0], torch.cross(w, x, dim=-1), 1e-6, "skew(w) v == w x v")
+    R_ref, p_ref = O.exp_se3(torch.cat([w, v], -1), th)
+    assert_close(RB.exp_so3(w.to(DEV), th.to(DEV)), R_ref, 1e-4, "rigid_body.exp_so3 (batched)")
+    Tb = RB.exp_se3(torch.cat([w, v], -1).to(DEV), th.to(DEV))
+    assert Tb.shape == (n, 4, 4)
+    assert_close(Tb[:, :3, :3], R_ref, 1e-4, "rigid_body.exp_se3 rotation (batched)")
+    assert_close(Tb[:, :3, 3], p_ref, 1e-4, "rigid_body.exp_se3 translation (batched)")
+    assert torch.equal(Tb[:, 3].cpu(), torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(n, 4))
+    assert_close(RB.exp_so3(w[:1].reshape(3).to(DEV), th[:1].to(DEV)), R_ref[0], 1e-4, "exp_so3, the reference's (3,) call")
+    with pytest.raises(ValueError):
+        RB.exp_so3((2.0 * w).to(DEV), th.to(DEV))                     # not a unit axis
+    hom = RB.to_homogenous(x[:, None, :].to(DEV))                        # (N,1,3) -> (4,N)
+    assert hom.shape == (4, n) and torch.equal(hom[:3].T.cpu(), x) and bool((hom[3] == 1).all())
+    one = RB.to_homogenous(x[:1, None, :].to(DEV))                       # the only shape upstream handles: identical
+    assert torch.equal(one.cpu(), torch.cat([x[:1], torch.ones(1, 1)], -1).reshape(4, 1))
+    back = RB.from_homogenous((Tb @ hom.T[..., None])[..., 0])           # rigid transform of each point by its own T
+    assert_close(back, (R_ref @ x[..., None])[..., 0] + p_ref, 1e-4, "exp_se3 . to_homogenous . from_homogenous")
+    assert torch.equal(RB.rp_to_se3(Tb[:, :3, :3], Tb[:, :3, 3]), Tb)
+    with pytest.raises(L.HnError):
+        RB.skew(w)                                                       # CPU tensor: no fallback
+
+
+def test_translation_field_gradient_wrt_points():
+    """TranslationField.warp under autograd w.r.t. its INPUT points (reference: warping.py:90-96, p + mlp(posenc(p))):
+    the residual passes the output gradient through, the encoder adds its share through the MLP — against the oracle
+    (fp32: output 1e-4, d points and every parameter gradient 1e-3 of the tensor's largest entry), per-point and per-ray
+    embeddings."""
+    HN.set_precision("fp32")
+    try:
+        for per_ray in (False, True):
+            tf = warping.TranslationField(in_ch=3, in_ch_embed=8)
+            sd = load_hash(tf, 43)
+            tf = tf.to(DEV)
+            b, s_ = 7, 32
+            pts = H.uniform(43, "tfp", (b, s_, 3), -1.0, 1.0)
+            emb = H.normal(43, "tfe", (b, 8)) * 0.1
+            g = H.normal(43, "tfg", (b, s_, 3))
+            p = {"wf." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+            pr, er = pts.clone().requires_grad_(True), emb.clone().requires_grad_(True)
+            ref = O.translation_field(p, "wf", pr, er[:, None, :].expand(b, s_, 8))
+            (ref * g).sum().backward()
+            pd, ed = pts.clone().to(DEV).requires_grad_(True), emb.clone().to(DEV).requires_grad_(True)
+            out = tf.warp(pd, ed if per_ray else ed[:, None, :].expand(b, s_, 8), None)
+            (out * g.to(DEV)).sum().backward()
+            assert_close(out, ref, 1e-4, f"TranslationField.warp (per_ray={per_ray})")
+            assert_grad_close(pd.grad, pr.grad, 1e-3, "TranslationField d points")
+            assert_grad_close(ed.grad, er.grad, 1e-3, "TranslationField d embedding")
+            for k, prm in tf.named_parameters():
+                assert_grad_close(prm.grad, p["wf." + k].grad, 1e-3, f"TranslationField d {k}")
+    finally:
+        HN.set_precision("bf16")
 
 
 # ------------------------------------------------------------------------------------------------------------
