@@ -10,7 +10,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_c${cfg}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B=$GRAFT_REPO_ROOT/bench.py
-COMMON="--config $cfg --repeats 1 --no-cpu-baseline --no-roofline --no-graph"
+COMMON="--config $cfg --repeats 1 --no-cpu-baseline --no-roofline --no-calibration --no-graph"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 $B --steps 20 --warmup 3 $COMMON > $out/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python3 $B --steps 3 --warmup 2 $COMMON > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- python3 $B --steps 3 --warmup 2 $COMMON > $out/pmc_write.log 2>&1

@@ -4,7 +4,7 @@
 # runs it), the other configurations as full lines, the fp32 parity mode and the eval-loop bench.
 # Writes gpurun_out/<tag>_final_*.json ; copy what is to be judged into profiles/ (tools/finish_profiles.py).
 # (Round 3 also collected the opt-in 8-bit-stash mode here; that mode is frozen since round 4: FINAL_S8=1 brings it back.)
-tag=${1:-r04}
+tag=${1:-r05}
 o=$GRAFT_REPO_ROOT/gpurun_out
 cd $GRAFT_REPO_ROOT
 python3 bench.py 2>/dev/null | tail -1 > $o/${tag}_final_config2.json

@@ -6,7 +6,7 @@ stats passes are condensed into <tag>_traffic_config2_s8.json, <tag>_kernel_stat
 import collections, csv, glob, json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 from importlib import import_module
 L = import_module("hypernerf_torch_amd._lib")
 src = f"{R}/gpurun_out/prof_{tag}_c2s8"
