@@ -250,6 +250,107 @@ def test_fused_level_program_emulated(bf16):
 
 
 @pytest.mark.parametrize("bf16", [True, False])
+def test_fine_level_in_two_parts_emulated(bf16):
+    """Round 5, NerfModel.REUSE_COARSE on the host compiler + the lane-level emulation (no GPU): the fine level as
+    (i) the fine TEMPLATE alone over the coarse level's warped points (`_template_reuse_call`: source 0 = the coarse
+    program's `warped_points` output, GLO conditions gathered by ray) + (ii) the whole level program over the NEW samples
+    only, against the reference's structure — the level program over every fine sample.  Same rgb / alpha / warped
+    points for every sample; and with (i)'s source gradient handed to the coarse program as the external gradient on its
+    `warped_points` output, the SUM of the weight gradients and the GLO-table gradient equal the full path's."""
+    torch.manual_seed(0)
+    emb = {"warp": list(range(12)), "camera": [0], "appearance": list(range(12)), "time": list(range(12))}
+    m = models.NerfModel(emb, n_samples_coarse=8, n_samples_fine=8, hyper_slice_method="bendy_sheet",
+                         use_nerf_embed=True, use_alpha_cond=True, xyz_fourier_dim=2, hyper_fourier_dim=1,
+                         view_fourier_dim=1)
+    m.warp_field = warping.TranslationField(in_ch=3, in_ch_embed=8, depth=6, hidden_channels=32)
+    m.hyper_sheet_mlp = modules.HyperSheetMLP(out_ch=4, in_ch_embed=8, depth=6, width=32)
+    for lvl in ("coarse", "fine"):
+        setattr(m, f"nerf_mlps_{lvl}", modules.NerfMLP(
+            in_ch=27, trunk_depth=4, trunk_width=64, rgb_branch_depth=2, rgb_branch_width=32,
+            hidden_activation=torch.nn.ReLU(), skips=[2], rgb_activation=torch.nn.Sigmoid(), alpha_condition_dim=8,
+            rgb_condition_dim=9, alpha_brach_width=32))
+    sd = load_hash(m, 23)
+    b, s = 5, 8
+    n = b * s
+    old = H.uniform(9, "old", (b, s, 3), -1, 1).double()
+    new = H.uniform(9, "new", (b, s, 3), -1, 1).double()
+    dirs = H.uniform(9, "dirs", (b, 3), -1, 1).double()
+    idx = torch.tensor([3, 11, 0, 3, 7])
+    table = sd["warp_embed.embed.weight"].numpy()
+    mode = E.Mode(bf16)
+    mi = 1 if bf16 else 0
+    pc, pf, pr = (m._level_call("coarse").program, m._level_call("fine").program,
+                  m._template_reuse_call("fine", 4, False, True).program)
+    assert [len(c) for c in pr.chains()] == [10] and pr.n_src == 4
+    # source 0 of the reuse program: xyz then the sheet's 4 hyper coordinates, every one of them with a gradient row
+    assert sorted(c for (si, c) in pr.dsrc_map if si == 0) == list(range(7))
+    tabs = {id(p): p.host_tables(mi) for p in (pc, pf, pr)}
+    prm = {id(p): np_params(p) for p in (pc, pf, pr)}
+
+    def fwd(prog, pts, spr, widths, src0_is_warped=False):
+        k = pts.shape[0]
+        srcs = [(pts, False), (dirs.numpy(), True), (table, True, idx.numpy())] + ([] if src0_is_warped else [None])
+        outs, stash = E.run_forward(prog, mode, tabs[id(prog)], prm[id(prog)], srcs, k, spr, widths)
+        return srcs, outs, stash
+    g = {k_: H.uniform(10, k_, shp, -1, 1).double().numpy() for k_, shp in
+         (("c_rgb", (n, 3)), ("c_a", (n, 1)), ("o_rgb", (n, 3)), ("o_a", (n, 1)), ("n_rgb", (n, 3)), ("n_a", (n, 1)))}
+
+    def bwd(prog, srcs, outs, stash, g_rgb, g_a, g_warped, k, spr, rgb_i, warped_out):
+        bs = list(srcs[:3]) + [(outs[0], False) if warped_out else None, (g_rgb, False), (g_a, False), (outs[rgb_i], False),
+                               (g_warped, False) if g_warped is not None else None]
+        dsrc = E.run_backward(prog, mode, tabs[id(prog)], prm[id(prog)], bs, k, spr, stash)
+        _, gtot = prog.grad_offsets()
+        flat = E.run_wgrad(prog, mode, prog.wgrad_jobs(mi, k), stash, gtot)
+        cols = {c: sl for (si, c), sl in prog.dsrc_map.items() if si == 2}
+        d_tab = np.zeros(table.shape)
+        np.add.at(d_tab, idx.numpy(), np.stack([dsrc[:, cols[c]].reshape(-1, spr).sum(1) for c in range(8)], axis=1))
+        return dsrc, flat, d_tab
+
+    def by_param(prog, flat, acc):
+        offs, _ = prog.grad_offsets()
+        for p_, off in zip(prog.params, offs):
+            acc[id(p_)] = acc.get(id(p_), 0.0) + flat[off:off + p_.numel()]
+        return acc
+    # ---- the coarse level (both paths): forward once
+    sc, oc, stc = fwd(pc, old.reshape(n, 3).numpy(), s, [7, 3, 1])
+    # ---- reference structure: the fine program over [old | new] of every ray
+    both = torch.cat([old, new], 1).reshape(2 * n, 3).numpy()
+    sf, of_, stf = fwd(pf, both, 2 * s, [7, 3, 1])
+    g_rgb_f = np.concatenate([g["o_rgb"].reshape(b, s, 3), g["n_rgb"].reshape(b, s, 3)], 1).reshape(2 * n, 3)
+    g_a_f = np.concatenate([g["o_a"].reshape(b, s, 1), g["n_a"].reshape(b, s, 1)], 1).reshape(2 * n, 1)
+    _, flat_f, tab_f = bwd(pf, sf, of_, stf, g_rgb_f, g_a_f, None, 2 * n, 2 * s, 1, True)
+    _, flat_c, tab_c = bwd(pc, sc, oc, stc, g["c_rgb"], g["c_a"], None, n, s, 1, True)
+    full = by_param(pc, flat_c, by_param(pf, flat_f, {}))
+    # ---- two parts: (ii) the fine program over the new samples, (i) the fine template over the coarse warped points
+    sn, on, stn = fwd(pf, new.reshape(n, 3).numpy(), s, [7, 3, 1])
+    so, oo, sto = fwd(pr, oc[0], s, [3, 1], src0_is_warped=True)
+    fr = of_[1].reshape(b, 2 * s, 3)
+    np.testing.assert_allclose(oo[0].reshape(b, s, 3), fr[:, :s], rtol=1e-12, atol=1e-14)        # rgb of the old samples
+    np.testing.assert_allclose(on[1].reshape(b, s, 3), fr[:, s:], rtol=1e-12, atol=1e-14)        # ... of the new ones
+    fa = of_[2].reshape(b, 2 * s, 1)
+    np.testing.assert_allclose(oo[1].reshape(b, s, 1), fa[:, :s], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(on[2].reshape(b, s, 1), fa[:, s:], rtol=1e-12, atol=1e-14)
+    fw = of_[0].reshape(b, 2 * s, 7)
+    np.testing.assert_allclose(oc[0].reshape(b, s, 7), fw[:, :s], rtol=1e-12, atol=1e-14)        # the warp is the coarse level's
+    np.testing.assert_allclose(on[0].reshape(b, s, 7), fw[:, s:], rtol=1e-12, atol=1e-14)
+    _, flat_n, tab_n = bwd(pf, sn, on, stn, g["n_rgb"], g["n_a"], None, n, s, 1, True)
+    bs_o = list(so[:3]) + [None, (g["o_rgb"], False), (g["o_a"], False), (oo[0], False)]
+    dsrc_o = E.run_backward(pr, mode, tabs[id(pr)], prm[id(pr)], bs_o, n, s, sto)
+    _, gt_o = pr.grad_offsets()
+    flat_o = E.run_wgrad(pr, mode, pr.wgrad_jobs(mi, n), sto, gt_o)
+    cols_o = {c: sl for (si, c), sl in pr.dsrc_map.items() if si == 2}
+    tab_o = np.zeros(table.shape)
+    np.add.at(tab_o, idx.numpy(), np.stack([dsrc_o[:, cols_o[c]].reshape(-1, s).sum(1) for c in range(8)], axis=1))
+    g_warped = np.stack([dsrc_o[:, pr.dsrc_map[(0, c)]] for c in range(7)], axis=1)              # d L / d warped_points (old)
+    _, flat_c2, tab_c2 = bwd(pc, sc, oc, stc, g["c_rgb"], g["c_a"], g_warped, n, s, 1, True)
+    parts = by_param(pc, flat_c2, by_param(pf, flat_n, by_param(pr, flat_o, {})))
+    assert parts.keys() == full.keys()
+    for k_ in full:
+        np.testing.assert_allclose(parts[k_], full[k_], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(tab_c2 + tab_n + tab_o, tab_c + tab_f, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("bf16", [True, False])
 def test_axis_aligned_level_and_gathered_template_emulated(bf16):
     """axis_aligned_plane (models.py:533-534): the hyper coordinates are the ray's GLO row.  (a) the fused level
     [warp | template] encodes them from the gathered source, (b) the stand-alone template program with the table
@@ -500,6 +601,15 @@ def test_wgrad_job_tables_cover_every_tile_product_once(launch_bytes):
                 stage_kib = 48 if mode == L.HN_MODE_BF16_S8 else 32
                 jobs = prog.wgrad_jobs(mode, n_points, job_bytes=machine.WGRAD_JOB_BYTES, launch_bytes=launch_bytes)
                 assert len(jobs) > 0
+                # what the jobs stream == what resolve_pending sizes a launch by (round 5: the launch's bytes are computed
+                # from the programs of the pass, not carried over from the previous launch)
+                streamed = int(((jobs["n_nt"] + jobs["n_kt"]).astype(np.int64) * (jobs["blk1"] - jobs["blk0"])).sum())
+                assert streamed * tile_kib * 1024 == prog.wgrad_stream_bytes(mode, n_points)
+                goffs0, _ = prog.grad_offsets()
+                cut = sorted(goffs0)[len(goffs0) // 2]
+                head = jobs[jobs["w_off"] >= cut]
+                assert int(((head["n_nt"] + head["n_kt"]).astype(np.int64) * (head["blk1"] - head["blk0"])).sum()) \
+                    * tile_kib * 1024 == prog.wgrad_stream_bytes(mode, n_points, goffs0, cut)
                 slot_of = {int(o[0]): i for i, o in enumerate(offs)}
                 seen, bias_seen = {}, {}
                 for jb in jobs:
