@@ -441,11 +441,12 @@ def main():
         except OSError:
             pass
     calibration = None
-    if rank == 0 and not a.no_calibration:
+    if not a.no_calibration:
         from hypernerf_torch_amd import calibration as CAL
-        calibration = CAL.probes(dev)
-        for _ in range(2):                  # back into the step's own thermal / clock state
-            step()
+        if rank == 0:
+            calibration = CAL.probes(dev)
+        for _ in range(2):                  # back into the step's own thermal / clock state — on EVERY rank: with N > 1
+            step()                          # a step holds collectives, the ranks must run the same number of them
     if L.TIMELINE is not None:
         L.timeline_reset()
     sampler = None
@@ -470,14 +471,17 @@ def main():
         calibration["timed_region"] = sampler.summary()
         # hwmon's power figure is a running average over roughly a second: the timed region (steps x repeats, often
         # < 0.2 s) is too short for it to settle, so the same step is replayed for another second, untimed, and sampled
-        with CAL.PowerSampler(dev) as soak:
-            t_soak = time.perf_counter()
-            while time.perf_counter() - t_soak < CALIB_SOAK_S:
-                for _ in range(20):
-                    step()
-                torch.cuda.synchronize()
-        calibration["soak"] = dict(soak.summary(), seconds=CALIB_SOAK_S,
-                                   what="the same step replayed back to back right after the timed region (untimed)")
+    if not a.no_calibration:
+        # ... on every rank, the same number of steps (fixed from the max-over-ranks step time: collectives inside)
+        n_soak = max(20, int(CALIB_SOAK_S / max(1e-6, statistics.median(reps) / a.steps)))
+        soak = CAL.PowerSampler(dev).__enter__() if rank == 0 else None
+        for _ in range(n_soak):
+            step()
+        barrier()
+        if soak is not None:
+            soak.__exit__(None, None, None)
+            calibration["soak"] = dict(soak.summary(), seconds=CALIB_SOAK_S, steps=n_soak,
+                                       what="the same step replayed back to back right after the timed region (untimed)")
     ranks_seen = world
     if dp:
         all_gather_pixels(out['fine']['rgb'].detach())     # eval-style pixel assembly works on this topology

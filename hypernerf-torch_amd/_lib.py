@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libhn_hip.so")
 SOURCES = ["hn_mlp.hip", "hn_render.hip", "hn_calib.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hn_kernels.h")
-BUILD_MACROS = ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX")     # build-time tuning knobs (A/B experiments)
+BUILD_MACROS = ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX", "HN_WGRAD_EXP", "HN_WGRAD_BIAS_MFMA")     # build-time tuning knobs (A/B experiments)
 
 HN_MODE_F32, HN_MODE_BF16, HN_MODE_BF16_S8 = 0, 1, 2
 HN_MAX_SRC, HN_MAX_DST, HN_MAX_SLOTS = 8, 4, 128
@@ -63,7 +63,7 @@ class HnMlpArgs(C.Structure):
 
 class HnDwBatch(C.Structure):
     _fields_ = [("jobs", C.c_void_p), ("stash", C.c_void_p), ("grads", C.c_void_p), ("n_jobs", C.c_int32),
-                ("pad", C.c_int32)]
+                ("pad", C.c_int32), ("partials", C.c_void_p)]
 
 
 HN_MAX_WGRAD_BATCH = 8
@@ -99,10 +99,12 @@ DWJOB_DT = np.dtype([("z_off", "<u8"), ("x_off", "<u8"), ("z_nt", "<i4"), ("x_nt
                      ("x_t0", "<i4"), ("n_nt", "<i4"), ("n_kt", "<i4"), ("blk0", "<i4"), ("blk1", "<i4"),
                      ("w_off", "<i4"), ("ld", "<i4"), ("r0", "<i4"), ("c0", "<i4"), ("r_end", "<i4"),
                      ("c_end", "<i4"), ("b_off", "<i4"), ("pad", "<i4"), ("x2_off", "<u8"), ("x2_nt", "<i4"),
-                     ("x2_t0", "<i4"), ("n_kt1", "<i4"), ("pad2", "<i4")])
+                     ("x2_t0", "<i4"), ("n_kt1", "<i4"), ("p_tile", "<i4")])
+DWREDUCE_DT = np.dtype([("batch", "<i4"), ("w_off", "<i4"), ("ld", "<i4"), ("row0", "<i4"), ("col0", "<i4"),
+                        ("r_end", "<i4"), ("c_end", "<i4"), ("first", "<i4"), ("count", "<i4")])
 
 EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
-           "hn_mlp_wgrad_batched", "hn_mlp_wgrad_batched_t", "hn_mlp_workspace_bytes",
+           "hn_mlp_wgrad_batched", "hn_mlp_wgrad_batched_t", "hn_mlp_wgrad_reduce", "hn_mlp_workspace_bytes",
            "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf", "hn_sample_pdf_split",
            "hn_embed_gather", "hn_embed_backward", "hn_se3_apply_forward", "hn_se3_apply_backward", "hn_se3_warp_forward", "hn_se3_warp_backward", "hn_generate_rays", "hn_adam_step",
            "hn_mse_loss_forward", "hn_mse_loss_backward", "hn_depth_index", "hn_random_fill",

@@ -1160,6 +1160,19 @@ struct DwFrag<true> {
     acc = hn_mfma_bf16(a.v[0], one, acc);
     acc = hn_mfma_bf16(a.v[1], one, acc);
   }
+  // bias gradient on the vector pipe (round 5): s + the sum of this lane's 16 values — feature (lane & 31) of the dZ
+  // tile at the 16 points of the lane's half — as eight v_dot2c_f32_bf16 with a (1, 1) operand.  The all-ones MFMAs it
+  // replaces (2 per dZ tile and block, 64 more accumulator registers, and waves that own more bias tiles than their
+  // SIMD partner reach every stage barrier late) cost 7 % of the launch: timing builds, profiles/r05_wgrad_end_of_job.log
+  HN_DEV float add_point_sum(float s) const {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) s = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{v[u][j], v[u][j + 1]}, one, s, false);
+    return s;
+  }
 };
 template <>
 struct DwFrag<false> {
@@ -1181,6 +1194,13 @@ struct DwFrag<false> {
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = hn_mfma_f32(a.v[g][e], 1.0f, acc);
+  }
+  HN_DEV float add_point_sum(float s) const {       // the lane's 16 points of feature (lane & 31)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += v[g][e];
+    return s;
   }
 };
 
@@ -1217,6 +1237,7 @@ struct DwFrag8 {
   }
   // bias gradient of tile `col` (0..3) into COLUMN `col` of the one shared accumulator: the B operand is all ones on the
   // lanes of that column and zero elsewhere, so four tiles' row sums live side by side in 16 registers instead of 64
+  HN_DEV float add_point_sum(float s) const { return s; }      // (the 8-bit stash keeps the all-ones MFMA)
   HN_DEV static void mma_ones(f32x16& acc, const DwFrag8& a, int col, int lane) {
     const long one = ((lane & 31) == col) ? 0x3838383838383838L : 0L;       // e4m3 1.0 in every byte of column `col`
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a.v[0], one, acc, 0, 0, 0);
@@ -1307,10 +1328,11 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   const HnDwJob* jobs = tab.b[0].jobs;
   const char* stash = reinterpret_cast<const char*>(tab.b[0].stash);
   float* grads = tab.b[0].grads;
+  float* partials = tab.b[0].partials;
   int n_jobs = tab.b[0].n_jobs;
 #pragma unroll
   for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
-    if (which == i) { jobs = tab.b[i].jobs; stash = reinterpret_cast<const char*>(tab.b[i].stash); grads = tab.b[i].grads; n_jobs = tab.b[i].n_jobs; }
+    if (which == i) { jobs = tab.b[i].jobs; stash = reinterpret_cast<const char*>(tab.b[i].stash); grads = tab.b[i].grads; partials = tab.b[i].partials; n_jobs = tab.b[i].n_jobs; }
   using M = ModeT<BF16>;
   using Fr = std::conditional_t<S8, DwFrag8, DwFrag<BF16>>;
   constexpr int TU = S8 ? 1 : M::TILE_UNITS;
@@ -1338,8 +1360,16 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   const int nstage = (nb + bps - 1) / bps;
 
   f32x16 acc[4][2];
-  constexpr int NB = S8 ? 1 : 4;        // 8-bit stash: ONE bias accumulator, tile i in its column i (DwFrag8::mma_ones)
+  // bias gradient db[n] = sum_p dZ[p][n].  bf16 / fp32: a running sum per dZ tile on the vector pipe (bsum[i]: this
+  // lane's feature over the points of its half, DwFrag::add_point_sum).  8-bit stash: ONE all-ones MFMA accumulator,
+  // tile i in its column i (DwFrag8::mma_ones).
+#ifndef HN_WGRAD_BIAS_MFMA
+#define HN_WGRAD_BIAS_MFMA 0      /* 1: rounds 1-4, an all-ones MFMA accumulator per dZ tile (A/B knob) */
+#endif
+  constexpr bool BM = S8 || (HN_WGRAD_BIAS_MFMA != 0);
+  constexpr int NB = S8 ? 1 : (BM ? 4 : 1);
   f32x16 accb[NB];
+  float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -1490,7 +1520,10 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             if (j < my_k) Fr::mma(acc[i][j], za, xb[j]);
-          if (bias_mask & (1u << i)) Fr::mma_ones(accb[i % NB], za, i, lane);
+          if (bias_mask & (1u << i)) {
+            if constexpr (BM) Fr::mma_ones(accb[i % NB], za, i, lane);
+            else bsum[i] = za.add_point_sum(bsum[i]);
+          }
         }
       });
     }
@@ -1505,8 +1538,58 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     o[5] = jb.n_nt * 16 + jb.n_kt; o[6] = bps; o[7] = blockIdx.x;
   }
 #endif
+#if defined(HN_WGRAD_EXP) && (HN_WGRAD_EXP == 1 || HN_WGRAD_EXP == 3)   // timing-only experiments (results are WRONG):
+  {                                                                     // 1 = no flush at all, 3 = no dW flush
+    float z = 0.0f;                                                     // (every accumulator stays live)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) z += acc[i][j][q];
+#if HN_WGRAD_EXP == 1
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) z += accb[i][q] + bsum[q & 3];
+#endif
+    if (z == 123.456f) grads[0] = z;
+  }
+#if HN_WGRAD_EXP == 1
+  hn_timeline_end(tab.timeline);
+  return;
+#endif
+#endif
   // D[n][k]: lane = column k (c), register q -> row rho(q,h)
-  if (jb.w_off >= 0) {
+#if defined(HN_WGRAD_EXP) && HN_WGRAD_EXP == 3      // timing-only experiment: no dW flush (weight gradients are WRONG)
+  if (false) {
+#else
+  if (jb.w_off >= 0 && partials != nullptr) {
+#endif
+    // the rectangle leaves as raw accumulator tiles, 16 coalesced 256-B stores per tile (hn_mlp_wgrad_reduce sums the
+    // jobs' slabs and adds every element to the gradient once): a CU retires float atomics at ~5 GB/s, plain stores
+    // at its full store rate — the atomic flush was 100 us of a 650-us launch at config 2
+    float* P = partials + (size_t)jb.p_tile * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < my_n)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (j < my_k) {
+            // tile = [register quad (4)][lane (64)][4 floats]: four 1-KiB store instructions per tile and wave
+            float* T = P + (size_t)((n0 + i) * jb.n_kt + (k0 + j)) * 1024 + lane * 4;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+              if (S8) v *= tab.unscale;
+              *reinterpret_cast<f32x4*>(T + q4 * 256) = v;
+            }
+          }
+#if defined(HN_WGRAD_EXP) && HN_WGRAD_EXP == 3
+  } else if (false) {
+#else
+  } else if (jb.w_off >= 0) {
+#endif
     float* G = grads + jb.w_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1522,7 +1605,26 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
                 atomicAdd(G + (size_t)row * jb.ld + col, S8 ? acc[i][j][q] * tab.unscale : acc[i][j][q]);
             }
   }
-  if (bias_mask != 0 && c < 4) {
+#if defined(HN_WGRAD_EXP) && HN_WGRAD_EXP == 2      // timing-only experiment: no bias flush (bias gradients are WRONG)
+  bias_mask = 0;
+#endif
+  if (!BM && bias_mask != 0) {
+    // the two halves of the wave hold the sums over the two halves of every block's points: add them, lanes 0-31 hold
+    // db of row (lane) of each dZ tile
+    float* Bp = partials != nullptr ? partials + (size_t)(jb.p_tile + jb.n_nt * jb.n_kt) * 1024 : nullptr;
+    float* gb = grads + jb.b_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (bias_mask & (1u << i)) {
+        const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+        const int row = jb.r0 + 32 * (n0 + i) + c;
+        if (h == 0) {
+          // bias partials: one more slab tile behind the job's dW tiles, 32 floats (rows in natural order) per dZ tile
+          if (Bp != nullptr) Bp[(n0 + i) * 32 + c] = v;
+          else if (row >= 0 && row < jb.r_end) atomicAdd(gb + row, v);
+        }
+      }
+  } else if (bias_mask != 0 && c < 4) {
     float* gb = grads + jb.b_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1551,7 +1653,7 @@ extern "C" int hn_abi_sizes(int32_t* out, int n) {
   const int32_t v[8] = {(int32_t)sizeof(HnMlpArgs),      (int32_t)sizeof(HnPackUnit), (int32_t)sizeof(HnPackBias),
                         (int32_t)sizeof(HnDwJob),        (int32_t)sizeof(HnCompositeArgs), (int32_t)sizeof(HnFeat),
                         (int32_t)sizeof(HnSlot),         (int32_t)sizeof(HnSrc)};
-  static_assert(sizeof(HnDwBatch) == 32, "HnDwBatch layout");
+  static_assert(sizeof(HnDwBatch) == 40, "HnDwBatch layout");
   static_assert(sizeof(HnSrc) == 32, "HnSrc layout");
   for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   return 8;
@@ -1720,6 +1822,98 @@ extern "C" int hn_mlp_backward(const HnMlpArgs* a, hnStream_t stream) {
     hipLaunchKernelGGL((hn_mlp_bwd_kernel<false, true>), dim3(hn_grid_for(a->n_points, 128)), dim3(256), lds,
                        (hipStream_t)stream, *a);
   }
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// second half of a batched weight-gradient launch that flushed to partial slabs: one workgroup per destination tile
+// ------------------------------------------------------------------------------------------------
+struct HnDwReduceTable {
+  float* partials[HN_MAX_WGRAD_BATCH];
+  float* grads[HN_MAX_WGRAD_BATCH];
+};
+template <bool S8>
+__global__ __launch_bounds__(256) void hn_wgrad_reduce_kernel(const HnDwReduceTile* __restrict__ tiles,
+                                                              const uint32_t* __restrict__ list, const HnDwReduceTable tab) {
+  const HnDwReduceTile t = tiles[blockIdx.x];
+  if (t.ld == 0) {
+    // bias record: col0 = dZ tiles of the rectangle; thread x = row 32 (x >> 5) + (x & 31) of it.  A job's bias slab
+    // holds 32 floats per dZ tile, rows in natural order
+    const int i_n = threadIdx.x >> 5, rr = threadIdx.x & 31;
+    const int row = t.row0 + 32 * i_n + rr;
+    if (i_n >= t.col0 || row < 0 || row >= t.r_end) return;
+    const int off = i_n * 32 + rr;
+    float sb = 0.0f;
+    for (int k = 0; k < t.count; ++k) {
+      const uint32_t e = list[t.first + k];
+      float* P = tab.partials[0];
+#pragma unroll
+      for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
+        if ((int)(e >> 28) == i) P = tab.partials[i];
+      sb += P[(size_t)(e & 0x0fffffffu) * 1024 + off];
+    }
+    float* Gb = tab.grads[0];
+#pragma unroll
+    for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
+      if (t.batch == i) Gb = tab.grads[i];
+    atomicAdd(Gb + t.w_off + row, sb);
+    return;
+  }
+  // a slab tile is [register quad q4 (4)][lane (64)][4 floats]; thread x sums the float4 at x: registers 4 q4 .. 4 q4 + 3
+  // of one lane.  The slab loads are issued eight at a time (a dependent load-add chain pays one memory latency per slab).
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < t.count; k0 += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (k0 + u < t.count) {
+        const uint32_t e = list[t.first + k0 + u];
+        float* P = tab.partials[0];
+#pragma unroll
+        for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
+          if ((int)(e >> 28) == i) P = tab.partials[i];
+        v[u] = *reinterpret_cast<const f32x4*>(P + (size_t)(e & 0x0fffffffu) * 1024 + threadIdx.x * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];          // fixed order: slab k0, k0 + 1, ...
+  }
+  float* G = tab.grads[0];
+#pragma unroll
+  for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
+    if (t.batch == i) G = tab.grads[i];
+  G += t.w_off;
+  const int q4 = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+  const int col = t.col0 + (S8 ? hn_dw8_feature(c) : c);
+  if (col < 0 || col >= t.c_end) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int rr = hn_rho(4 * q4 + e, h);
+    const int row = t.row0 + (S8 ? hn_dw8_feature(rr) : rr);
+    if (row >= 0 && row < t.r_end) atomicAdd(G + (size_t)row * t.ld + col, s[e]);
+  }
+}
+
+extern "C" int hn_mlp_wgrad_reduce(int mode, const HnDwReduceTile* tiles, int n_tiles, const uint32_t* list,
+                                   const HnDwBatch* batches, int n_batches, hnStream_t stream) {
+  if (n_tiles < 0 || n_batches < 1 || n_batches > HN_MAX_WGRAD_BATCH) return -1;
+  if (n_tiles == 0) return 0;
+  if (tiles == nullptr || list == nullptr || batches == nullptr) return -3;
+  HnDwReduceTable tab = {};
+  for (int i = 0; i < n_batches; ++i) {
+    if (batches[i].partials == nullptr || batches[i].grads == nullptr) return -3;
+    tab.partials[i] = batches[i].partials;
+    tab.grads[i] = batches[i].grads;
+  }
+  const int m = mode & 255;
+  if (m == HN_MODE_BF16_S8)
+    hipLaunchKernelGGL(hn_wgrad_reduce_kernel<true>, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, tiles, list, tab);
+  else if (m == HN_MODE_BF16 || m == HN_MODE_F32)
+    hipLaunchKernelGGL(hn_wgrad_reduce_kernel<false>, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, tiles, list, tab);
+  else
+    return -2;
   HN_CHECK_LAUNCH();
   return 0;
 }

@@ -808,6 +808,9 @@ class Program:
         arr = np.zeros(len(jobs), dtype=L.DWJOB_DT)
         for i, j in enumerate(jobs):
             arr[i] = j
+        # slab of every job in the launch's partials workspace (HnDwBatch.partials): its n_nt x n_kt accumulator tiles
+        tiles = slab_tiles(arr)
+        arr["p_tile"] = np.cumsum(tiles) - tiles
         return arr
 
 
@@ -853,13 +856,64 @@ class PendingWgrad:
                                                    self.split if first_bucket_only else None)
 
 
+def slab_tiles(jobs: np.ndarray) -> np.ndarray:
+    """4-KiB slab tiles of every job in a partials workspace: its n_nt x n_kt dW tiles + one for its bias sums."""
+    return jobs["n_nt"].astype(np.int64) * jobs["n_kt"] + (jobs["b_off"] >= 0)
+
+
 class ResolvedWgrad:
     """A PendingWgrad cut into jobs (device table cached by the program's runner)."""
 
-    def __init__(self, mode, jobs_dev, n_jobs, stash, grads, weights, bucket=0):
+    def __init__(self, mode, jobs_dev, n_jobs, stash, grads, weights, bucket=0, jobs_host=None):
         self.mode, self.jobs_dev, self.n_jobs, self.stash, self.grads = mode, jobs_dev, n_jobs, stash, grads
         self.weights = weights          # per job: stash tiles it streams (host numpy, for the global order)
         self.bucket = bucket            # 0 = launched at the end of backward, 1 = held (see WGRAD_SPLIT_OFFSET)
+        self.jobs_host = jobs_host      # the job table (numpy): what the reduce tables of a partials launch are built from
+
+
+# A job ends with the flush of its dW rectangle.  Float atomics leave a CU at ~5 GB/s (one 256-B wave-instruction per
+# ~50 ns): 100 us of a 650-us launch at config 2 (measured with a build that skips the flush: 0.648 -> 0.548 ms), during
+# which the CU streams nothing.  With WGRAD_PARTIALS the jobs store their raw accumulator tiles into a workspace
+# (HnDwBatch.partials) and ONE more launch (hn_mlp_wgrad_reduce, a workgroup per destination tile) sums the slabs and adds
+# every gradient element once: 1/12 of the atomics, and sums whose order no longer depends on which job finished first.
+WGRAD_PARTIALS = int(os.environ.get("HN_WGRAD_PARTIALS", 1))
+BIAS_MFMA_BUILD = os.environ.get("HN_WGRAD_BIAS_MFMA", "0") not in ("", "0")      # A/B build: bias by all-ones MFMAs + atomics
+_REDUCE_CACHE: Dict[tuple, tuple] = {}
+
+
+def _reduce_tables(grp: Sequence["ResolvedWgrad"], device):
+    """(tiles table, slab list, tiles) on the device for one batched launch: every destination tile (32 x 32 elements
+    of one gradient matrix, across ALL programs of the launch that write it) with the slabs that hold a partial of it,
+    in (program, job) order."""
+    dest: Dict[tuple, list] = {}
+    for k, p in enumerate(grp):
+        jb = p.jobs_host
+        gptr = p.grads.data_ptr()
+        for ji in range(len(jb)):
+            j = jb[ji]
+            n_nt, n_kt = int(j["n_nt"]), int(j["n_kt"])
+            if j["b_off"] >= 0 and p.mode != L.HN_MODE_BF16_S8 and not BIAS_MFMA_BUILD:     # bias record (ld = 0): the job's extra slab tile
+                key = (gptr, int(j["b_off"]), 0, int(j["r0"]), n_nt, int(j["r_end"]), 0)
+                dest.setdefault(key, [k]).append((k << 28) | (int(j["p_tile"]) + n_nt * n_kt))
+            if j["w_off"] < 0:
+                continue
+            for i in range(n_nt):
+                row = int(j["r0"]) + 32 * i
+                if row >= j["r_end"] or row + 32 <= 0:
+                    continue
+                for jj in range(n_kt):
+                    col = int(j["c0"]) + 32 * jj
+                    if col >= j["c_end"] or col + 32 <= 0:
+                        continue
+                    key = (gptr, int(j["w_off"]), int(j["ld"]), row, col, int(j["r_end"]), int(j["c_end"]))
+                    dest.setdefault(key, [k]).append((k << 28) | (int(j["p_tile"]) + i * n_kt + jj))
+    tiles = np.zeros(len(dest), dtype=L.DWREDUCE_DT)
+    lst: List[int] = []
+    # heaviest first (most slabs): the tail of the launch is then made of short tiles
+    for t, (key, v) in enumerate(sorted(dest.items(), key=lambda kv: -len(kv[1]))):
+        tiles[t] = (v[0], key[1], key[2], key[3], key[4], key[5], key[6], len(lst), len(v) - 1)
+        lst.extend(v[1:])
+    return (L.to_device_bytes(tiles, device), L.to_device_bytes(np.asarray(lst, dtype=np.uint32), device), len(tiles))
 
 
 # Data-parallel overlap (training.TrainStep / bench.py with more than one rank): when set to an offset (floats) into
@@ -882,9 +936,9 @@ def resolve_pending(pending: Sequence[PendingWgrad]) -> List[ResolvedWgrad]:
     total = float(sum(p.stream_bytes() for p in pending))
     out: List[ResolvedWgrad] = []
     for p in pending:
-        for b, (jd, nj, w) in enumerate(p.runner.wgrad_tables(p.stash.device, p.mode, p.n_points, p.goffs, p.split, total)):
+        for b, (jd, nj, w, jh) in enumerate(p.runner.wgrad_tables(p.stash.device, p.mode, p.n_points, p.goffs, p.split, total)):
             if nj > 0:
-                out.append(ResolvedWgrad(p.mode, jd, nj, p.stash, p.grads, w, bucket=b))
+                out.append(ResolvedWgrad(p.mode, jd, nj, p.stash, p.grads, w, bucket=b, jobs_host=jh))
     return out
 
 
@@ -900,9 +954,17 @@ def launch_resolved_wgrads(shares: Sequence[ResolvedWgrad]):
         for i in range(0, len(lst), L.HN_MAX_WGRAD_BATCH):
             grp = lst[i:i + L.HN_MAX_WGRAD_BATCH]
             arr = (L.HnDwBatch * len(grp))()
+            use_partials = bool(WGRAD_PARTIALS) and all(p.jobs_host is not None for p in grp)
+            slabs = []
             for k, p in enumerate(grp):
                 arr[k].jobs, arr[k].stash, arr[k].grads = p.jobs_dev.data_ptr(), p.stash.data_ptr(), p.grads.data_ptr()
                 arr[k].n_jobs = p.n_jobs
+                if use_partials:
+                    n_tiles = int(slab_tiles(p.jobs_host).sum())
+                    if n_tiles >= 1 << 28:
+                        raise L.HnError("weight-gradient partials: more than 2^28 slab tiles in one program")
+                    slabs.append(torch.empty(max(1, n_tiles) * 1024, dtype=torch.float32, device=p.stash.device))
+                    arr[k].partials = slabs[-1].data_ptr()
             key = tuple((p.jobs_dev.data_ptr(), p.n_jobs) for p in grp)
             order = _ORDER_CACHE.get(key)
             if order is None:
@@ -913,9 +975,21 @@ def launch_resolved_wgrads(shares: Sequence[ResolvedWgrad]):
                 ids = np.concatenate([(k << 24) | np.arange(p.n_jobs, dtype=np.int64) for k, p in enumerate(grp)])
                 order = torch.from_numpy(ids[np.argsort(-w, kind="stable")].astype(np.int32)).to(grp[0].stash.device)
                 _ORDER_CACHE[key] = order
+            red = None
+            if use_partials:
+                rkey = key + tuple(p.grads.data_ptr() for p in grp)
+                red = _REDUCE_CACHE.get(rkey)
+                if red is None:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise L.HnError("weight-gradient reduce tables: first use of this set of programs inside a stream "
+                                        "capture (run one warm-up step of the same shapes first)")
+                    red = _REDUCE_CACHE[rkey] = _reduce_tables(grp, grp[0].stash.device)
             L.launch("hn_mlp_wgrad_batched_t", C.c_int(wgrad_mode_word(mode)), arr, C.c_int(len(grp)), L.ptr(order),
                      C.c_void_p(L.timeline_slot("hn_mlp_wgrad_batched", grp[0].stash.device)), L.stream_handle(),
                      tag="batched")
+            if red is not None and red[2] > 0:
+                L.launch("hn_mlp_wgrad_reduce", C.c_int(wgrad_mode_word(mode)), L.ptr(red[0]), C.c_int(red[2]), L.ptr(red[1]),
+                         arr, C.c_int(len(grp)), L.stream_handle())
 
 
 _OPT_STEPS = [0]
@@ -1128,7 +1202,7 @@ class MlpRunner:
         deferred = defer and grad_target is not None
         if deferred:        # the caller launches it together with the other programs of this backward pass
             return dsrc, [PendingWgrad(self, mode, n_points, stash, grad_target[0], goffs, WGRAD_SPLIT_OFFSET)]
-        jobs_dev, n_jobs, weights = self.wgrad_tables(device, mode, n_points, goffs, None, None)[0]
+        jobs_dev, n_jobs, weights, _ = self.wgrad_tables(device, mode, n_points, goffs, None, None)[0]
         if grad_target is not None:
             grads, ret = grad_target[0], None
         else:
@@ -1167,7 +1241,10 @@ class MlpRunner:
             for part in parts:
                 part = np.ascontiguousarray(part)
                 weights = ((part["n_nt"] + part["n_kt"]).astype(np.int64) * (part["blk1"] - part["blk0"]))
-                entry.append((L.to_device_bytes(part, device) if len(part) else None, len(part), weights))
+                if len(part):       # a bucket's slabs are numbered from 0 in its own workspace
+                    tl = slab_tiles(part)
+                    part["p_tile"] = np.cumsum(tl) - tl
+                entry.append((L.to_device_bytes(part, device) if len(part) else None, len(part), weights, part))
             self._jobs[jkey] = entry
         return entry
 

@@ -29,8 +29,9 @@ extern "C" {
 
 typedef void* hnStream_t; /* hipStream_t */
 
-#define HN_VERSION 330   /* 320: HnDwJob carries a second X slot; 321: HN_BOP_AUX w2 = tile word; 330: a level composited
-                            from two parts through a merge permutation (HnCompositeArgs.perm, hn_sample_pdf_split) */
+#define HN_VERSION 331   /* 320: HnDwJob carries a second X slot; 321: HN_BOP_AUX w2 = tile word; 330: a level composited
+                            from two parts through a merge permutation (HnCompositeArgs.perm, hn_sample_pdf_split); 331: weight-gradient
+                            jobs flush to partial slabs + hn_mlp_wgrad_reduce (HnDwBatch.partials, HnDwJob.p_tile) */
 
 /* numeric modes of the MLP machine */
 #define HN_MODE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode (<=1e-4 vs oracle) */
@@ -235,7 +236,10 @@ typedef struct {
   uint64_t x2_off;        /* second X slot: stash byte offset (block 0) */
   int32_t x2_nt, x2_t0;   /* its tiles per block, first tile used */
   int32_t n_kt1;          /* k-tiles taken from the first X slot (the remaining n_kt - n_kt1 from the second) */
-  int32_t pad2;
+  int32_t p_tile;         /* batched launches with HnDwBatch.partials (ABI 331): the job writes its n_nt x n_kt dW tiles —
+                             raw accumulators, tile (i, j) at partials + (p_tile + i * n_kt + j) * 1024 floats, element
+                             [register quad][lane][4]; bias sums in tile p_tile + n_nt * n_kt — with plain stores instead of adding them to the gradient by float
+                             atomics; hn_mlp_wgrad_reduce sums the jobs' slabs and adds each element ONCE */
 } HnDwJob;
 
 int hn_version(void);
@@ -275,12 +279,34 @@ typedef struct {
   float* grads;        /* device: base the jobs' w_off / b_off refer to */
   int32_t n_jobs;
   int32_t pad;
+  float* partials;     /* device or NULL: workspace of the jobs' dW slabs (HnDwJob.p_tile), 4 KiB per tile; NULL = the
+                          jobs add their tiles to `grads` themselves (float atomics) */
 } HnDwBatch;
 int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches_host, int n_batches, const int32_t* order_dev,
                          hnStream_t stream);
 /* The same with a kernel timeline (HnMlpArgs.timeline; NULL = off). */
 int hn_mlp_wgrad_batched_t(int mode, const HnDwBatch* batches_host, int n_batches, const int32_t* order_dev,
                            uint64_t* timeline_dev, hnStream_t stream);
+
+/* Second half of a batched launch whose batches carry `partials` (ABI 331).  A job ends with the flush of its dW
+ * rectangle; by float atomics one CU retires ~5 GB/s of them (one 256-B wave-instruction per ~50 ns), 100 us of a
+ * 650-us launch at BASELINE config 2 during which the CU streams nothing.  With partials the jobs store their raw
+ * accumulator tiles (plain 256-B stores) and this launch — one workgroup per DESTINATION tile (32 x 32 elements of
+ * one gradient matrix) — sums the tile over every job that produced a slab for it, in the order of `list`, and adds
+ * the sum to the gradient once: 1/12 of the atomics, and a summation order that does not depend on which job finished
+ * first.  tiles_dev[t]: destination; its slabs are list_dev[first .. first + count): batch << 28 | slab tile index
+ * (tile k of batch b starts at batches[b].partials + k * 1024 floats).  A record with ld == 0 is a BIAS record: w_off =
+ * offset of the bias gradient, row0 = its first row, col0 = dZ tiles of the rectangle; a job with b_off >= 0 owns one
+ * more slab tile behind its n_nt * n_kt dW tiles, 32 floats per dZ tile (HN_MODE_BF16_S8 keeps its bias atomics). */
+typedef struct {
+  int32_t batch;         /* whose `grads` receives the tile */
+  int32_t w_off, ld;     /* gradient matrix (row-major (out, in)) in that buffer */
+  int32_t row0, col0;    /* destination of accumulator element (row 0, col 0) of the tile */
+  int32_t r_end, c_end;  /* valid bounds */
+  int32_t first, count;  /* slice of list_dev */
+} HnDwReduceTile;
+int hn_mlp_wgrad_reduce(int mode, const HnDwReduceTile* tiles_dev, int n_tiles, const uint32_t* list_dev,
+                        const HnDwBatch* batches_host, int n_batches, hnStream_t stream);
 
 /* ---- per-ray kernels --------------------------------------------------------------------- */
 

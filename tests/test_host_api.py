@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hn_version() == 330
+    assert lib.hn_version() == 331
 
 
 def test_abi_struct_sizes_match_c():

@@ -1,0 +1,13 @@
+#!/bin/bash
+# same-box A/B of two BUILD-macro settings, alternating, 3 pairs: tools/ab_build2.sh "MACRO=a" "MACRO=b"
+A=$1; B=$2; shift 2
+for r in 1 2 3; do
+for cfg in "$A" "$B"; do
+  echo "=== cfg: $cfg"
+  env $cfg python -c "import hypernerf_torch_amd._lib as L; L.build(force=True)" || continue
+  env $cfg timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-also --no-calibration "$@" 2>&1 | tail -1 | python -c "
+import json,sys
+r=json.loads(sys.stdin.read()); print('ms/step', round(r['ms_per_step'],4), round(r['value']/1e6,2), {k: round(v,4) for k,v in r['roofline']['machine_kernel_ms_per_step'].items()}, 'other', round(r['roofline']['other_ms_per_step'],4))"
+done
+done
+python -c "import hypernerf_torch_amd._lib as L; L.build(force=True)"
