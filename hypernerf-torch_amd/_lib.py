@@ -57,7 +57,7 @@ class HnMlpArgs(C.Structure):
         ("prof", C.c_void_p), ("comps", C.c_void_p), ("n_comps", C.c_int32), ("embed_reg_mask", C.c_int32),
         ("embed_grad", C.c_void_p), ("embed_idx", C.c_void_p), ("embed_rows", C.c_int32), ("embed_dim", C.c_int32),
         ("embed_col", C.c_int8 * 32), ("n_trig_comps", C.c_int32), ("wide_ops", C.c_int32), ("dz_scale_log2", C.c_int32), ("trig_lo_planes", C.c_int32),
-        ("timeline", C.c_void_p),
+        ("timeline", C.c_void_p), ("embed_partial", C.c_void_p),
     ]
 
 
@@ -68,6 +68,12 @@ class HnDwBatch(C.Structure):
 
 HN_MAX_WGRAD_BATCH = 8
 HN_MAX_DRAWS = 8
+
+
+class HnEmbedReduce(C.Structure):
+    _fields_ = [("grad", C.c_void_p), ("rows", C.c_int32), ("dim", C.c_int32), ("col_mask", C.c_uint32), ("n_src", C.c_int32),
+                ("partial", C.c_void_p * HN_MAX_WGRAD_BATCH), ("idx", C.c_void_p * HN_MAX_WGRAD_BATCH),
+                ("n_blocks", C.c_int32 * HN_MAX_WGRAD_BATCH), ("samples_per_ray", C.c_int32 * HN_MAX_WGRAD_BATCH)]
 
 
 class HnDraw(C.Structure):

@@ -1046,8 +1046,10 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 #pragma unroll
           for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
           const int col = a.embed_col[hn_rho(i, h)];
-          if (r == 0 && col >= 0 && erow >= 0 && erow < a.embed_rows)
-            atomicAdd(a.embed_grad + (size_t)erow * a.embed_dim + col, v);
+          if (r == 0 && col >= 0) {
+            if (a.embed_partial != nullptr) a.embed_partial[(size_t)blk * a.embed_dim + col] = v;
+            else if (erow >= 0 && erow < a.embed_rows) atomicAdd(a.embed_grad + (size_t)erow * a.embed_dim + col, v);
+          }
         }
       }
     }
@@ -1834,9 +1836,46 @@ struct HnDwReduceTable {
   float* grads[HN_MAX_WGRAD_BATCH];
 };
 template <bool S8>
-__global__ __launch_bounds__(256) void hn_wgrad_reduce_kernel(const HnDwReduceTile* __restrict__ tiles,
-                                                              const uint32_t* __restrict__ list, const HnDwReduceTable tab) {
-  const HnDwReduceTile t = tiles[blockIdx.x];
+__global__ __launch_bounds__(256) void hn_wgrad_reduce_kernel(const HnDwReduceTile* __restrict__ tiles, int n_tiles,
+                                                              const uint32_t* __restrict__ list, const HnDwReduceTable tab,
+                                                              const HnEmbedReduce em) {
+  if ((int)blockIdx.x < em.rows) {
+    // one table row (these workgroups come FIRST in the grid: they are the long ones).  Thread x takes blocks x, x + 256,
+    // ... of every program in turn (a fixed order); the 256 partial sums are added by a fixed shuffle tree per wave, the
+    // four waves' sums in wave order by threads 0 .. dim-1, which add the row to the gradient (one writer per element)
+    __shared__ float red[4][32];
+    const long long row = blockIdx.x;
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = 0.0f;
+    for (int sIdx = 0; sIdx < em.n_src; ++sIdx) {
+      const float* P = em.partial[sIdx];
+      const int64_t* idx = em.idx[sIdx];
+      const int nb = em.n_blocks[sIdx], spr = em.samples_per_ray[sIdx];
+      for (int b = threadIdx.x; b < nb; b += 256) {
+        if (idx[(b * 32) / spr] != row) continue;
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+          if (c < em.dim && ((em.col_mask >> c) & 1u)) acc[c] += P[(size_t)b * em.dim + c];
+      }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      if (c < em.dim && ((em.col_mask >> c) & 1u)) {
+        float v = acc[c];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0) red[wave][c] = v;
+      }
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < em.dim && ((em.col_mask >> c) & 1u))
+      em.grad[row * em.dim + c] += ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    return;
+  }
+  const HnDwReduceTile t = tiles[blockIdx.x - em.rows];
   if (t.ld == 0) {
     // bias record: col0 = dZ tiles of the rectangle; thread x = row 32 (x >> 5) + (x & 31) of it.  A job's bias slab
     // holds 32 floats per dZ tile, rows in natural order
@@ -1897,21 +1936,34 @@ __global__ __launch_bounds__(256) void hn_wgrad_reduce_kernel(const HnDwReduceTi
 }
 
 extern "C" int hn_mlp_wgrad_reduce(int mode, const HnDwReduceTile* tiles, int n_tiles, const uint32_t* list,
-                                   const HnDwBatch* batches, int n_batches, hnStream_t stream) {
-  if (n_tiles < 0 || n_batches < 1 || n_batches > HN_MAX_WGRAD_BATCH) return -1;
-  if (n_tiles == 0) return 0;
-  if (tiles == nullptr || list == nullptr || batches == nullptr) return -3;
+                                   const HnDwBatch* batches, int n_batches, const HnEmbedReduce* embed,
+                                   hnStream_t stream) {
+  if (n_tiles < 0 || n_batches < 0 || n_batches > HN_MAX_WGRAD_BATCH) return -1;
+  HnEmbedReduce em = {};
+  if (embed != nullptr) {
+    em = *embed;
+    if (em.n_src < 0 || em.n_src > HN_MAX_WGRAD_BATCH || em.rows < 0 || em.dim < 1 || em.dim > 32) return -2;
+    if (em.n_src > 0 && em.grad == nullptr) return -3;
+    for (int i = 0; i < em.n_src; ++i)
+      if (em.partial[i] == nullptr || em.idx[i] == nullptr || em.n_blocks[i] < 0 || em.samples_per_ray[i] < 32) return -3;
+    if (em.n_src == 0) em.rows = 0;
+  }
+  const int total = n_tiles + em.rows;
+  if (total == 0) return 0;
+  if (n_tiles > 0 && (tiles == nullptr || list == nullptr || batches == nullptr || n_batches < 1)) return -3;
   HnDwReduceTable tab = {};
   for (int i = 0; i < n_batches; ++i) {
-    if (batches[i].partials == nullptr || batches[i].grads == nullptr) return -3;
+    if (n_tiles > 0 && (batches[i].partials == nullptr || batches[i].grads == nullptr)) return -3;
     tab.partials[i] = batches[i].partials;
     tab.grads[i] = batches[i].grads;
   }
   const int m = mode & 255;
   if (m == HN_MODE_BF16_S8)
-    hipLaunchKernelGGL(hn_wgrad_reduce_kernel<true>, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, tiles, list, tab);
+    hipLaunchKernelGGL(hn_wgrad_reduce_kernel<true>, dim3(total), dim3(256), 0, (hipStream_t)stream, tiles, n_tiles, list,
+                       tab, em);
   else if (m == HN_MODE_BF16 || m == HN_MODE_F32)
-    hipLaunchKernelGGL(hn_wgrad_reduce_kernel<false>, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, tiles, list, tab);
+    hipLaunchKernelGGL(hn_wgrad_reduce_kernel<false>, dim3(total), dim3(256), 0, (hipStream_t)stream, tiles, n_tiles, list,
+                       tab, em);
   else
     return -2;
   HN_CHECK_LAUNCH();

@@ -166,6 +166,15 @@ class _ProgramFn(torch.autograd.Function):
                 d_table = table_ret = torch.zeros(table.shape, dtype=torch.float32, device=table.device)
             if ctx.spr % 32 == 0:
                 embed = (d_table, ctx.flat_srcs[gs][2], gs)
+                # batched weight gradient with partial slabs: the table's gradient goes the same way — per-block rows
+                # stored by the backward machine, summed per table row in a fixed order by the reduce launch
+                # (machine.WGRAD_PARTIALS): with it the whole gradient of a step is bit-reproducible
+                from . import machine as _M
+                if (BATCH_WGRADS and target is not None and table_ret is None and _M.WGRAD_PARTIALS and table.shape[1] <= 32
+                        and call.runner.effective_mode(ctx.mode) != L.HN_MODE_BF16_S8):
+                    nblk = (ctx.n_points + 31) // 32
+                    part = torch.empty(nblk * table.shape[1], dtype=torch.float32, device=table.device)
+                    embed = embed + (part,)
         others = [i for i, shp in enumerate(ctx.src_shapes)
                   if shp is not None and i != gs and ctx.needs_input_grad[6 + i]
                   and any(si == i for (si, _c) in prog.dsrc_map)]
@@ -174,6 +183,12 @@ class _ProgramFn(torch.autograd.Function):
                                           grad_target=(target[0].grad, target[1]) if target else None,
                                           defer=BATCH_WGRADS, embed=embed, want_dsrc=want_dsrc)
         if isinstance(flat, list):          # deferred: this program's share(s) of the batched weight-gradient launch
+            if embed is not None and len(embed) > 3:
+                mask = 0
+                for c_ in gather_cols:
+                    mask |= 1 << c_
+                flat[0].embed = {"partial": embed[3], "idx": embed[1], "grad": d_table, "n_blocks": (ctx.n_points + 31) // 32,
+                                 "spr": ctx.spr, "col_mask": mask}
             for pend in flat:
                 _defer_wgrad(pend)
             flat = None

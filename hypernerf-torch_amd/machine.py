@@ -850,6 +850,9 @@ class PendingWgrad:
     def __init__(self, runner: "MlpRunner", mode: int, n_points: int, stash, grads, goffs, split):
         self.runner, self.mode, self.n_points, self.stash, self.grads = runner, mode, n_points, stash, grads
         self.goffs, self.split = goffs, split
+        # per-block partial rows of a gathered GLO table's gradient that the backward machine STORED instead of adding
+        # them by atomics (HnMlpArgs.embed_partial): {partial, idx, grad, n_blocks, spr, col_mask}; reduced with the slabs
+        self.embed: Optional[dict] = None
 
     def stream_bytes(self, first_bucket_only: bool = True) -> float:
         return self.runner.prog.wgrad_stream_bytes(self.mode, self.n_points, self.goffs,
@@ -869,6 +872,7 @@ class ResolvedWgrad:
         self.weights = weights          # per job: stash tiles it streams (host numpy, for the global order)
         self.bucket = bucket            # 0 = launched at the end of backward, 1 = held (see WGRAD_SPLIT_OFFSET)
         self.jobs_host = jobs_host      # the job table (numpy): what the reduce tables of a partials launch are built from
+        self.embed: Optional[dict] = None      # see PendingWgrad.embed (rides on the program's first share)
 
 
 # A job ends with the flush of its dW rectangle.  Float atomics leave a CU at ~5 GB/s (one 256-B wave-instruction per
@@ -879,6 +883,27 @@ class ResolvedWgrad:
 WGRAD_PARTIALS = int(os.environ.get("HN_WGRAD_PARTIALS", 1))
 BIAS_MFMA_BUILD = os.environ.get("HN_WGRAD_BIAS_MFMA", "0") not in ("", "0")      # A/B build: bias by all-ones MFMAs + atomics
 _REDUCE_CACHE: Dict[tuple, tuple] = {}
+
+
+def _embed_struct(embeds: Sequence[dict]) -> "L.HnEmbedReduce":
+    """HnEmbedReduce over the programs of one launch that gathered the SAME table."""
+    e0 = embeds[0]
+    em = L.HnEmbedReduce()
+    em.grad, em.rows, em.dim = e0["grad"].data_ptr(), e0["grad"].shape[0], e0["grad"].shape[1]
+    mask = 0
+    for e in embeds:
+        mask |= e["col_mask"]
+    em.col_mask, em.n_src = mask, len(embeds)
+    for i, e in enumerate(embeds):
+        em.partial[i], em.idx[i] = e["partial"].data_ptr(), e["idx"].data_ptr()
+        em.n_blocks[i], em.samples_per_ray[i] = e["n_blocks"], e["spr"]
+    return em
+
+
+def _launch_embed_reduce(mode: int, embeds: Sequence[dict]):
+    em = _embed_struct(embeds)
+    L.launch("hn_mlp_wgrad_reduce", C.c_int(wgrad_mode_word(mode)), None, C.c_int(0), None, None, C.c_int(0), C.byref(em),
+             L.stream_handle())
 
 
 def _reduce_tables(grp: Sequence["ResolvedWgrad"], device):
@@ -936,9 +961,14 @@ def resolve_pending(pending: Sequence[PendingWgrad]) -> List[ResolvedWgrad]:
     total = float(sum(p.stream_bytes() for p in pending))
     out: List[ResolvedWgrad] = []
     for p in pending:
+        first = True
         for b, (jd, nj, w, jh) in enumerate(p.runner.wgrad_tables(p.stash.device, p.mode, p.n_points, p.goffs, p.split, total)):
             if nj > 0:
                 out.append(ResolvedWgrad(p.mode, jd, nj, p.stash, p.grads, w, bucket=b, jobs_host=jh))
+                if first:
+                    out[-1].embed, first = p.embed, False
+        if first and p.embed is not None:           # no job at all (cannot happen for a program with parameters)
+            _launch_embed_reduce(p.mode, [p.embed])
     return out
 
 
@@ -987,9 +1017,17 @@ def launch_resolved_wgrads(shares: Sequence[ResolvedWgrad]):
             L.launch("hn_mlp_wgrad_batched_t", C.c_int(wgrad_mode_word(mode)), arr, C.c_int(len(grp)), L.ptr(order),
                      C.c_void_p(L.timeline_slot("hn_mlp_wgrad_batched", grp[0].stash.device)), L.stream_handle(),
                      tag="batched")
+            embeds = [p.embed for p in grp if p.embed is not None]
+            by_table: Dict[int, list] = {}
+            for e in embeds:
+                by_table.setdefault(e["grad"].data_ptr(), []).append(e)
+            tables = list(by_table.values())
             if red is not None and red[2] > 0:
+                em = _embed_struct(tables.pop(0)) if tables else None
                 L.launch("hn_mlp_wgrad_reduce", C.c_int(wgrad_mode_word(mode)), L.ptr(red[0]), C.c_int(red[2]), L.ptr(red[1]),
-                         arr, C.c_int(len(grp)), L.stream_handle())
+                         arr, C.c_int(len(grp)), C.byref(em) if em is not None else None, L.stream_handle())
+            for tb in tables:           # a second table in one launch, or no slabs at all: a reduce of its own
+                _launch_embed_reduce(mode, tb)
 
 
 _OPT_STEPS = [0]
@@ -1118,8 +1156,10 @@ class MlpRunner:
                 if idx.dtype != torch.int64 or not idx.is_contiguous():
                     raise L.HnError("gather indices must be contiguous int64")
                 a.src[i].gather_idx, a.src[i].gather_rows = idx.data_ptr(), t.shape[0]
-        if embed is not None:       # (gradient table, indices, source index): GLOEmbed's backward inside the machine
-            g_tab, idx, src_i = embed
+        if embed is not None:       # (gradient table, indices, source index[, partial rows]): GLOEmbed's backward inside the machine
+            g_tab, idx, src_i = embed[:3]
+            if len(embed) > 3 and embed[3] is not None:
+                a.embed_partial = embed[3].data_ptr()
             mask, col = self.prog.embed_fold(src_i)
             a.embed_reg_mask, a.embed_grad, a.embed_idx = mask, g_tab.data_ptr(), idx.data_ptr()
             a.embed_rows, a.embed_dim = g_tab.shape[0], g_tab.shape[1]

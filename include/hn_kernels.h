@@ -193,6 +193,10 @@ typedef struct {
                              wall clock, [5] += 1, [0]/[1] start / end of the last run, [6]/[7] first start / last end
                              ever; [2], [3] are tickets the launch leaves at zero.  Lets a step that is replayed as one
                              HIP graph report per-kernel durations of the timed replays themselves.  NULL = off. */
+  float* embed_partial;   /* backward, optional (ABI 331): with embed_reg_mask set, the per-block sums of the gathered
+                             row's gradient are STORED to embed_partial[block][embed_dim] (columns without a gradient
+                             slot are left untouched) instead of added to embed_grad by float atomics;
+                             hn_mlp_wgrad_reduce (HnEmbedReduce) then sums them per table row in a fixed order */
 } HnMlpArgs;
 
 /* weight packing: one descriptor per 1-KiB unit of a stream */
@@ -305,8 +309,24 @@ typedef struct {
   int32_t r_end, c_end;  /* valid bounds */
   int32_t first, count;  /* slice of list_dev */
 } HnDwReduceTile;
+/* Optional third kind of work of the same launch: the gradient of ONE gathered GLO table (modules.GLOEmbed's backward,
+ * hypernerf/modules.py:155-167) from the per-block partial rows the backward machines of up to HN_MAX_WGRAD_BATCH
+ * programs stored (HnMlpArgs.embed_partial): one workgroup per table row sums, program by program and block by block,
+ * the rows of the blocks whose ray carries that index and adds the total to `grad` — a single writer per element, a
+ * fixed order: with the slabs above the whole gradient of a step is bit-reproducible. */
+typedef struct {
+  float* grad;          /* (rows, dim) gradient of the table */
+  int32_t rows, dim;
+  uint32_t col_mask;    /* columns that carry a gradient (bit c = column c); dim <= 32 */
+  int32_t n_src;
+  const float* partial[HN_MAX_WGRAD_BATCH];   /* [n_blocks][dim] */
+  const int64_t* idx[HN_MAX_WGRAD_BATCH];     /* ray -> table row */
+  int32_t n_blocks[HN_MAX_WGRAD_BATCH];
+  int32_t samples_per_ray[HN_MAX_WGRAD_BATCH];
+} HnEmbedReduce;
 int hn_mlp_wgrad_reduce(int mode, const HnDwReduceTile* tiles_dev, int n_tiles, const uint32_t* list_dev,
-                        const HnDwBatch* batches_host, int n_batches, hnStream_t stream);
+                        const HnDwBatch* batches_host, int n_batches, const HnEmbedReduce* embed_host,
+                        hnStream_t stream);
 
 /* ---- per-ray kernels --------------------------------------------------------------------- */
 

@@ -889,10 +889,12 @@ def test_forked_weight_gradient_schedule_matches_serial(use_graph):
 def test_weight_gradients_through_partial_slabs_are_reproducible_and_equal_the_atomic_flush(precision, size):
     """Round 5 (machine.WGRAD_PARTIALS, hn_mlp_wgrad_reduce): the jobs of the batched weight-gradient launch store their
     dW rectangles and bias sums as partial slabs and ONE reduce launch adds every gradient element once, in a fixed order.
-    (1) Against the rounds-1-4 flush (every job adds its rectangle with float atomics): the same gradients to 1e-5 of the
-    buffer's scale.  (2) Run to run: every MLP weight and bias gradient BIT-identical (the atomic flush differs in about
-    half of the elements from run to run); only the GLO table, which the backward machine scatters with atomics, may
-    differ in the last bits."""
+    The GLO table's gradient goes the same way (per-block rows stored by the backward machine, summed per table row).
+    (1) Against the rounds-1-4 flush (every job adds its rectangle, every block its table row, with float atomics): the
+    same gradients to 1e-5 of the buffer's scale.  (2) Run to run: the WHOLE gradient buffer BIT-identical (the atomic
+    flush differs in about half of the elements from run to run) — the opt-in 8-bit stash excepted, which keeps the
+    atomics of its bias sums and of the table, and sample counts that are not multiples of 32 (blocks spanning rays),
+    whose table gradient takes the two-launch hn_embed_backward path."""
     from hypernerf_torch_amd import machine
     from hypernerf_torch_amd.hypernerf import model_utils
     from hypernerf_torch_amd.losses import MSELoss
@@ -924,8 +926,9 @@ def test_weight_gradients_through_partial_slabs_are_reproducible_and_equal_the_a
     for name, p in m.named_parameters():
         off = (p.grad.data_ptr() - arena.grad.data_ptr()) // 4
         sl = slice(off, off + p.numel())
-        if name.endswith("embed.weight") or (precision == "bf16s8" and name.endswith(".bias")):
-            # (the opt-in 8-bit stash keeps its bias sums on the matrix pipe and their atomic flush)
+        ragged = nc % 32 != 0 or nf % 32 != 0      # blocks that span rays: the table's gradient takes hn_embed_backward (atomics)
+        if (precision == "bf16s8" and (name.endswith("embed.weight") or name.endswith(".bias"))) or \
+                (ragged and name.endswith("embed.weight")):
             assert float((runs[1][sl] - runs[0][sl]).abs().max()) <= 1e-5 * scale, name
         else:
             assert torch.equal(runs[1][sl], runs[0][sl]) and torch.equal(runs[2][sl], runs[0][sl]), name
