@@ -43,20 +43,24 @@ def mfma_probe(device, target_ms: float = 50.0) -> Dict[str, float]:
             "sclk_mhz": 100.0 * sclk_ticks / max(1, wall_ticks)}
 
 
-def stream_probe(device, gib: float = 4.0, target_ms: float = 40.0) -> Dict[str, float]:
-    """HBM rate of an LDS-DMA stream over a buffer far larger than the 256 MB Infinity Cache (hn_calib_stream)."""
+def stream_probe(device, gib: float = 4.0, target_ms: float = 40.0, pattern: int = 0) -> Dict[str, float]:
+    """HBM rate of an LDS-DMA stream over a buffer far larger than the 256 MB Infinity Cache (hn_calib_stream).
+    pattern 0: the workgroups share one moving window; 1: a contiguous region per workgroup (the weight-gradient jobs)."""
     L.load()
     n = int(gib * (1 << 30)) // 65536 * 65536
     buf = torch.empty(n, dtype=torch.uint8, device=device)
     buf.zero_()
     sink = torch.zeros(4, dtype=torch.float32, device=device)
     t = torch.zeros(16, dtype=torch.int64, device=device)
-    L.launch("hn_calib_stream", L.ptr(buf), C.c_longlong(n), L.ptr(sink), L.ptr(t), L.stream_handle())
+    def go():
+        L.launch("hn_calib_stream_pattern", L.ptr(buf), C.c_longlong(n), C.c_int(pattern), L.ptr(sink), L.ptr(t),
+                 L.stream_handle())
+    go()
     first = _ticks(t)[4] * L.TIMELINE_TICK_S
     reps = max(2, min(200, int(target_ms * 1e-3 / max(first, 1e-6))))
     t.zero_()
     for _ in range(reps):
-        L.launch("hn_calib_stream", L.ptr(buf), C.c_longlong(n), L.ptr(sink), L.ptr(t), L.stream_handle())
+        go()
     v = _ticks(t)
     s = v[4] * L.TIMELINE_TICK_S
     del buf

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(512, 2) void hn_calib_mfma_kernel(int iters, float*
   hn_timeline_end(t);
 }
 
+template <int PATTERN>
 __global__ __launch_bounds__(512, 2) void hn_calib_stream_kernel(const char* __restrict__ buf, long long n_kib,
                                                                  float* sink, uint64_t* t) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,9 +53,14 @@ __global__ __launch_bounds__(512, 2) void hn_calib_stream_kernel(const char* __r
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // a workgroup takes 64-KiB pieces round-robin; each wave moves 8 consecutive 1-KiB units of a piece per pass into
   // its own slice of a 2 x 64 KiB ring (nothing reads the LDS: the probe measures the fetch path only)
+  // PATTERN 0: the workgroups share one moving window (piece = blockIdx + k * grid): every CU reads next to every other.
+  // PATTERN 1: each workgroup streams a region of its own (1/grid of the buffer, front to back), as the jobs of
+  //            hn_wgrad_kernel do: 256 far-apart sequential streams.
   const long long pieces = n_kib / 64;
+  const long long per_wg = pieces / gridDim.x;
   int flip = 0;
-  for (long long pc = blockIdx.x; pc < pieces; pc += gridDim.x) {
+  for (long long k = 0; k < (PATTERN == 0 ? (pieces - blockIdx.x + gridDim.x - 1) / gridDim.x : per_wg); ++k) {
+    const long long pc = PATTERN == 0 ? blockIdx.x + k * gridDim.x : blockIdx.x * per_wg + k;
     const char* src = buf + pc * 65536 + (long long)wave * 8192;
     char* dst = smem + flip * 65536 + wave * 8192;
 #pragma unroll
@@ -81,16 +87,27 @@ extern "C" int hn_calib_mfma(int iters, float* sink_dev, uint64_t* t_dev, hnStre
 
 extern "C" int hn_calib_stream(const void* buf_dev, long long n_bytes, float* sink_dev, uint64_t* t_dev,
                                hnStream_t stream) {
-  if (n_bytes < 65536) return -2;
+  return hn_calib_stream_pattern(buf_dev, n_bytes, 0, sink_dev, t_dev, stream);
+}
+
+extern "C" int hn_calib_stream_pattern(const void* buf_dev, long long n_bytes, int pattern, float* sink_dev,
+                                       uint64_t* t_dev, hnStream_t stream) {
+  if (n_bytes < 65536 * 256 || (pattern != 0 && pattern != 1)) return -2;
   if (buf_dev == nullptr || sink_dev == nullptr || t_dev == nullptr) return -3;
   static bool allowed = false;
   if (!allowed) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hn_calib_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hn_calib_stream_kernel<0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hn_calib_stream_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     allowed = true;
   }
-  hipLaunchKernelGGL(hn_calib_stream_kernel, dim3(256), dim3(512), 128 * 1024, (hipStream_t)stream,
-                     (const char*)buf_dev, n_bytes / 1024, sink_dev, t_dev);
+  if (pattern == 0)
+    hipLaunchKernelGGL(hn_calib_stream_kernel<0>, dim3(256), dim3(512), 128 * 1024, (hipStream_t)stream,
+                       (const char*)buf_dev, n_bytes / 1024, sink_dev, t_dev);
+  else
+    hipLaunchKernelGGL(hn_calib_stream_kernel<1>, dim3(256), dim3(512), 128 * 1024, (hipStream_t)stream,
+                       (const char*)buf_dev, n_bytes / 1024, sink_dev, t_dev);
   HN_CHECK_LAUNCH();
   return 0;
 }

@@ -514,6 +514,10 @@ int hn_se3_warp_backward(const float* w, int w_ld, const float* v, int v_ld, con
  * hn_calib_stream: 256 workgroups stream n_bytes (a multiple of 64 KiB is read) once through LDS-DMA. */
 int hn_calib_mfma(int iters, float* sink_dev, uint64_t* t_dev, hnStream_t stream);
 int hn_calib_stream(const void* buf_dev, long long n_bytes, float* sink_dev, uint64_t* t_dev, hnStream_t stream);
+/* pattern 0: as hn_calib_stream (the workgroups share one moving window); 1: every workgroup streams a contiguous region
+ * of its own, front to back — 256 far-apart sequential streams, the pattern of hn_wgrad_kernel's jobs. */
+int hn_calib_stream_pattern(const void* buf_dev, long long n_bytes, int pattern, float* sink_dev, uint64_t* t_dev,
+                            hnStream_t stream);
 
 /* Debug/probe: runs one MFMA of each kind on identifiable data (layout self-test on real hardware). */
 int hn_probe_mfma(float* out_bf16_acc, float* out_f32_acc, float* out_glds, hnStream_t stream);
