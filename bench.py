@@ -555,6 +555,7 @@ def main():
         print(json.dumps(res), flush=True)
 
 
+CHECK_BOUND = {"fp32": 1e-4, "bf16": 2e-2, "bf16s8": 2e-2}      # cpu_baseline.check, see its note
 CALIB_SOAK_S = 1.2
 ALSO_BUDGET_S = 60.0        # the whole block; a child that would start later is recorded as skipped
 
@@ -687,8 +688,8 @@ def roofline(a, L, fwd_bwd, opt, progs, ref_progs, step_s, b, timeline, n_timed,
         traffic, traffic_note = _pmc_traffic(a)
         # rays 36 B + target 12 B + outputs 20 B per ray; weights read once forward and once backward
         # in the operand dtype; fp32 gradients written once
-        uniq = {id(p): p for p, _ in progs.values()}
-        n_params = sum(sum(q.numel() for q in p.params) for p in uniq.values())
+        uniq = {id(q): q for p, _ in progs.values() for q in p.params}     # a parameter shared by two programs counts once
+        n_params = sum(q.numel() for q in uniq.values())
         alg_bytes = b * 68.0 + 2.0 * n_params * (2 if prec_key == "bf16" else 4) + 4.0 * n_params
         machine_ms = sum(v[0] for v in kern.values())
         rl = {"kernel": sym[dom] + ("<true>" if prec_key == "bf16" else "<false>"),
@@ -874,10 +875,14 @@ def cpu_baseline(a, model, data, dev):
                       f"{len(times)} timed iterations after a 64-ray warm-up",
             "s_per_iteration": times,
             "check": {"gpu_vs_cpu_rgb_max_abs_diff": diff, "gpu_vs_cpu_rgb_mean_abs_diff": diff_mean,
-                      "gpu_precision": a.precision,
-                      "note": "the GPU model (in the run's precision mode, after the timed training steps) rendered the "
-                              "baseline's rays with the baseline's draws; fp32 mode agrees to ~1e-7, bf16 mode to its "
-                              "forward tolerance (1e-2 of the [0,1] colour range)"}}
+                      "gpu_precision": a.precision, "bound": CHECK_BOUND[a.precision],
+                      "within_bound": bool(diff <= CHECK_BOUND[a.precision]),
+                      "note": "the GPU model (in the run's precision mode, AFTER the timed training steps: lr 5e-4 has moved "
+                              "the weights away from their initialisation) rendered the baseline's rays with the baseline's "
+                              "draws.  `bound` is what this check holds the run to: 1e-4 in fp32 mode (the parity tests' "
+                              "element-wise bound; measured ~1e-7), 2e-2 of the [0,1] colour range in the bf16 modes (the "
+                              "parity tests bound the bf16 forward at 1e-2 of the tensor scale on freshly initialised weights, "
+                              "tests/test_gpu_model.py; after ~130 training steps 8e-3 ... 1.0e-2 is measured here)"}}
 
 
 if __name__ == "__main__":
