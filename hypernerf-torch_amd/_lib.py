@@ -70,6 +70,14 @@ HN_MAX_WGRAD_BATCH = 8
 HN_MAX_DRAWS = 8
 
 
+HN_MAX_PACK_JOBS = 8
+
+
+class HnPackJob(C.Structure):
+    _fields_ = [("units", C.c_void_p), ("ptrs", C.c_void_p), ("wstream", C.c_void_p), ("bias", C.c_void_p),
+                ("bias_out", C.c_void_p), ("n_units", C.c_int32), ("n_bias", C.c_int32)]
+
+
 class HnEmbedReduce(C.Structure):
     _fields_ = [("grad", C.c_void_p), ("rows", C.c_int32), ("dim", C.c_int32), ("col_mask", C.c_uint32), ("n_src", C.c_int32),
                 ("partial", C.c_void_p * HN_MAX_WGRAD_BATCH), ("idx", C.c_void_p * HN_MAX_WGRAD_BATCH),
@@ -109,7 +117,7 @@ DWJOB_DT = np.dtype([("z_off", "<u8"), ("x_off", "<u8"), ("z_nt", "<i4"), ("x_nt
 DWREDUCE_DT = np.dtype([("batch", "<i4"), ("w_off", "<i4"), ("ld", "<i4"), ("row0", "<i4"), ("col0", "<i4"),
                         ("r_end", "<i4"), ("c_end", "<i4"), ("first", "<i4"), ("count", "<i4")])
 
-EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
+EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_pack_units_multi", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
            "hn_mlp_wgrad_batched", "hn_mlp_wgrad_batched_t", "hn_mlp_wgrad_reduce", "hn_mlp_workspace_bytes",
            "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf", "hn_sample_pdf_split",
            "hn_embed_gather", "hn_embed_backward", "hn_se3_apply_forward", "hn_se3_apply_backward", "hn_se3_warp_forward", "hn_se3_warp_backward", "hn_generate_rays", "hn_adam_step",

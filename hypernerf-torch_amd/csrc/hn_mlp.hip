@@ -1061,10 +1061,9 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 // weight packing
 // ------------------------------------------------------------------------------------------------
 template <bool BF16>
-__global__ void hn_pack_kernel(const HnPackUnit* units, int n_units, const float* const* ptrs, char* out,
-                               const HnPackBias* bias, int n_bias, float* bias_out) {
+HN_DEV void hn_pack_one(const HnPackUnit* units, int n_units, const float* const* ptrs, char* out,
+                        const HnPackBias* bias, int n_bias, float* bias_out, int wid) {
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int row = lane & 31, h = lane >> 5;
   if (wid < n_units) {
     const HnPackUnit u = units[wid];
@@ -1093,6 +1092,27 @@ __global__ void hn_pack_kernel(const HnPackUnit* units, int n_units, const float
     const float* src = b.w_id >= 0 ? ptrs[b.w_id] : nullptr;
     for (int i = lane; i < b.len; i += 64) bias_out[b.off + i] = (src != nullptr && i < b.n) ? src[i] : 0.0f;
   }
+}
+template <bool BF16>
+__global__ void hn_pack_kernel(const HnPackUnit* units, int n_units, const float* const* ptrs, char* out,
+                               const HnPackBias* bias, int n_bias, float* bias_out) {
+  hn_pack_one<BF16>(units, n_units, ptrs, out, bias, n_bias, bias_out, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+}
+// several programs' streams in ONE launch (a training step packs three: each launch costs more in dispatch than in work)
+struct HnPackTable {
+  HnPackJob j[HN_MAX_PACK_JOBS];
+  int first_block[HN_MAX_PACK_JOBS + 1];
+  int n;
+};
+template <bool BF16>
+__global__ void hn_pack_multi_kernel(const HnPackTable tab) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < HN_MAX_PACK_JOBS; ++i)
+    if (i < tab.n && (int)blockIdx.x >= tab.first_block[i]) k = i;
+  const HnPackJob jb = tab.j[k];
+  const int wid = ((int)blockIdx.x - tab.first_block[k]) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  hn_pack_one<BF16>(jb.units, jb.n_units, jb.ptrs, (char*)jb.wstream, jb.bias, jb.n_bias, jb.bias_out, wid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1694,6 +1714,33 @@ extern "C" int hn_pack_units(int mode, const HnPackUnit* units, int n_units, con
   else if (mode == HN_MODE_F32)
     hipLaunchKernelGGL(hn_pack_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, units, n_units, ptrs,
                        (char*)wstream, bias, n_bias, bias_out);
+  else
+    return -2;
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hn_pack_units_multi(int mode, const HnPackJob* jobs, int n_jobs, hnStream_t stream) {
+  if (n_jobs < 0 || n_jobs > HN_MAX_PACK_JOBS) return -1;
+  if (n_jobs == 0) return 0;
+  if (jobs == nullptr) return -3;
+  HnPackTable tab = {};
+  int blocks = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    if (jobs[i].n_units < 0 || jobs[i].n_bias < 0) return -1;
+    if (jobs[i].n_units > 0 && (jobs[i].units == nullptr || jobs[i].ptrs == nullptr || jobs[i].wstream == nullptr)) return -3;
+    if (jobs[i].n_bias > 0 && (jobs[i].bias == nullptr || jobs[i].bias_out == nullptr || jobs[i].ptrs == nullptr)) return -3;
+    tab.j[i] = jobs[i];
+    tab.first_block[i] = blocks;
+    blocks += (jobs[i].n_units + jobs[i].n_bias + 3) / 4;
+  }
+  tab.first_block[n_jobs] = blocks;
+  tab.n = n_jobs;
+  if (blocks == 0) return 0;
+  if (mode == HN_MODE_BF16 || mode == HN_MODE_BF16_S8)
+    hipLaunchKernelGGL(hn_pack_multi_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab);
+  else if (mode == HN_MODE_F32)
+    hipLaunchKernelGGL(hn_pack_multi_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab);
   else
     return -2;
   HN_CHECK_LAUNCH();

@@ -339,6 +339,7 @@ class NerfModel(nn.Module):
     # the fine loss reaches the warp field through the coarse level program's external `warped_points` gradient.
     # At config 2: 1/3 of all warp + sheet forward, backward and weight-gradient work and ~10 % of the stash bytes.
     REUSE_COARSE = os.environ.get("HN_REUSE_COARSE", "1") != "0"
+    PREPACK = os.environ.get("HN_PREPACK", "1") != "0"      # one pack launch for the programs of a step (_prepack)
 
     def _can_fuse_level(self, use_warp: bool, metadata_encoded: bool, metadata) -> bool:
         """One launch per level needs: a TranslationField warp, hyper coordinates from the sheet MLP (or none), and
@@ -610,6 +611,23 @@ class NerfModel(nn.Module):
             return 'outside'
         return None
 
+    def _prepack(self, use_warp, metadata_encoded, metadata, return_warp_jacobian, device):
+        """The weight streams of every program this forward pass is about to launch, packed by ONE launch
+        (machine.pack_many) where more than one of them is stale — after an optimizer step that is all three of a
+        training step's (coarse level, fine level over the new samples, fine template over the coarse samples): three
+        dispatches of ~9 us for ~4 us of work each.  A prediction only: a program it misses packs itself as before."""
+        if not self.PREPACK or not self._can_fuse_level(use_warp, metadata_encoded, metadata):
+            return
+        from .. import machine
+        calls = [self._level_call('coarse')]
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in calls[0].program.params)
+        if self.num_fine_samples > 0:
+            calls.append(self._level_call('fine'))
+            if self.REUSE_COARSE and not return_warp_jacobian:
+                n_hyper = self.hyper_sheet_out_dim if self.hyper_slice_method == 'bendy_sheet' else 0
+                calls.append(self._template_reuse_call('fine', n_hyper, self.hyper_slice_method == 'axis_aligned_plane', grad))
+        machine.pack_many([c.runner for c in calls], device, F.mode_of(self.precision), force=grad)
+
     def _render_fine_reusing_coarse(self, coarse, points, z_vals, pts_new, perm, directions, viewdirs, metadata,
                                     use_sample_at_infinity, render_opts, noise, extra_params=None, how='fused'):
         """The fine level (models.py:752-768 -> render_samples 587-671) without re-evaluating the shared networks on the
@@ -756,6 +774,7 @@ class NerfModel(nn.Module):
                     else:
                         rng[name] = t
         self._level_state = None
+        self._prepack(use_warp, metadata_encoded, metadata, return_warp_jacobian, origins.device)
         z_vals, points = model_utils.sample_along_rays(origins, directions, self.num_coarse_samples, near, far,
                                                        self.use_stratified_sampling, self.use_linear_disparity,
                                                        t_rand=rng.get('t_rand'))

@@ -1052,6 +1052,38 @@ except ImportError:     # pragma: no cover
     pass
 
 
+def pack_many(runners: Sequence["MlpRunner"], device, mode: int, force: bool = False):
+    """Pack the weight streams of several programs that are about to run — the programs of one render step — with ONE
+    launch (hn_pack_units_multi) where more than one of them needs it; each runner's own `pack` then finds its streams
+    fresh.  Same rule per program as MlpRunner.pack."""
+    todo = []
+    for r in runners:
+        m = r.effective_mode(mode)
+        d = r._tables(device, m)
+        need, key = r._needs_pack(d, force)
+        if need:
+            todo.append((r, m, d, key))
+    by_mode: Dict[int, list] = {}
+    for item in todo:
+        by_mode.setdefault(item[1], []).append(item)
+    for m, items in by_mode.items():
+        if len(items) < 2:
+            continue                     # a single program: its own pack launch does it
+        for i in range(0, len(items), L.HN_MAX_PACK_JOBS):
+            grp = items[i:i + L.HN_MAX_PACK_JOBS]
+            arr = (L.HnPackJob * len(grp))()
+            for k, (r, _m, d, key) in enumerate(grp):
+                r._pack_job(d, device)
+                arr[k].units, arr[k].ptrs, arr[k].wstream = d.units.data_ptr(), d.ptrs.data_ptr(), d.wstream.data_ptr()
+                arr[k].bias, arr[k].bias_out = d.bias_desc.data_ptr(), d.bias.data_ptr()
+                arr[k].n_units, arr[k].n_bias = d.n_units, d.n_bias
+            L.launch("hn_pack_units_multi", C.c_int(m), arr, C.c_int(len(grp)), L.stream_handle(),
+                     tag="+".join(r.prog.name for r, *_ in grp))
+            for r, _m, d, key in grp:
+                d.pack_backward = BACKWARD_SERIAL[0]
+                d.pack_key = key
+
+
 class MlpRunner:
     """Owns the device copies of a Program's tables and launches the three kernels."""
 
@@ -1093,16 +1125,13 @@ class MlpRunner:
             key.append((p.data_ptr(), p._version, tag[0].version() if tag is not None else 0))
         return tuple(key)
 
-    def pack(self, device, mode, force: bool = False):
-        """(Re)pack both weight streams if a parameter is known to have changed, and — with `force`, i.e. on training
-        forwards — also whenever a backward pass of ANY program has run since the last pack: parameters change
-        between a backward and the next forward, and a fused optimizer step leaves no trace on the tensors.  (The
-        coarse- and fine-level forwards of one step therefore share one pack.)"""
-        d = self._tables(device, mode)
+    def _needs_pack(self, d, force: bool):
+        """(packing needed?, current parameter key) — the rule of `pack` below."""
         key = self._param_key()
-        if d.pack_key == key and not (force and d.pack_backward != BACKWARD_SERIAL[0]):
-            return d
-        d.pack_backward = BACKWARD_SERIAL[0]
+        return not (d.pack_key == key and not (force and d.pack_backward != BACKWARD_SERIAL[0])), key
+
+    def _pack_job(self, d, device):
+        """The arguments of one pack launch for this program (pointer table refreshed if a parameter moved)."""
         for p in self.prog.params:
             L.require_gpu(p)
             if p.dtype != torch.float32 or not p.is_contiguous():
@@ -1111,6 +1140,19 @@ class MlpRunner:
         if d.ptr_key != pk:
             d.ptrs = torch.tensor(list(pk), dtype=torch.int64).to(device)
             d.ptr_key = pk
+        return d
+
+    def pack(self, device, mode, force: bool = False):
+        """(Re)pack both weight streams if a parameter is known to have changed, and — with `force`, i.e. on training
+        forwards — also whenever a backward pass of ANY program has run since the last pack: parameters change
+        between a backward and the next forward, and a fused optimizer step leaves no trace on the tensors.  (The
+        coarse- and fine-level forwards of one step therefore share one pack.)"""
+        d = self._tables(device, mode)
+        need, key = self._needs_pack(d, force)
+        if not need:
+            return d
+        d.pack_backward = BACKWARD_SERIAL[0]
+        self._pack_job(d, device)
         L.launch("hn_pack_units", C.c_int(mode), L.ptr(d.units), C.c_int(d.n_units), L.ptr(d.ptrs), L.ptr(d.wstream),
                  L.ptr(d.bias_desc), C.c_int(d.n_bias), L.ptr(d.bias), L.stream_handle(), tag=self.prog.name)
         d.pack_key = key

@@ -257,6 +257,19 @@ int hn_pack_units(int mode, const HnPackUnit* units_dev, int n_units, const floa
                   void* wstream_dev, const HnPackBias* bias_dev, int n_bias, float* bias_out_dev,
                   hnStream_t stream);
 
+/* The same for up to HN_MAX_PACK_JOBS programs in ONE launch (ABI 331): a training step re-packs the streams of three
+ * programs after every optimizer step, and each of those launches costs more in dispatch than in work. */
+#define HN_MAX_PACK_JOBS 8
+typedef struct {
+  const HnPackUnit* units;      /* device */
+  const float* const* ptrs;     /* device: the program's pointer table */
+  void* wstream;                /* device */
+  const HnPackBias* bias;       /* device */
+  float* bias_out;              /* device */
+  int32_t n_units, n_bias;
+} HnPackJob;
+int hn_pack_units_multi(int mode, const HnPackJob* jobs_host, int n_jobs, hnStream_t stream);
+
 int hn_mlp_forward(const HnMlpArgs* args, hnStream_t stream);
 int hn_mlp_backward(const HnMlpArgs* args, hnStream_t stream);
 /* Workspace query (host arithmetic only, no GPU needed): bytes of `stash` and of `masks` that the forward
