@@ -902,14 +902,21 @@ extern "C" int hn_random_fill(const HnDraw* draws_host, int n_draws, uint64_t* s
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void hn_mse_fwd_kernel(const float* __restrict__ c, const float* __restrict__ f,
                                                           const float* __restrict__ gt, long long n,
-                                                          float* __restrict__ loss) {
+                                                          float* __restrict__ loss, float* __restrict__ d_c,
+                                                          float* __restrict__ d_f) {
   __shared__ float part[2][16];
   float sc = 0.0f, sf = 0.0f;
+  const float s1 = 1.0f * 2.0f / (float)n;      // hn_mse_bwd_kernel's factor for a root gradient of exactly 1
   for (long long i = threadIdx.x; i < n; i += 1024) {
     const float g = gt[i];
     const float dc = c[i] - g;
     sc += dc * dc;
-    if (f != nullptr) { const float df = f[i] - g; sf += df * df; }
+    if (d_c != nullptr) d_c[i] = dc * s1;
+    if (f != nullptr) {
+      const float df = f[i] - g;
+      sf += df * df;
+      if (d_f != nullptr) d_f[i] = df * s1;
+    }
   }
   sc = hn_wave_sum(sc);
   sf = hn_wave_sum(sf);
@@ -938,7 +945,17 @@ extern "C" int hn_mse_loss_forward(const float* coarse, const float* fine, const
   if (n <= 0) return -2;
   if (coarse == nullptr || gt == nullptr || loss_out == nullptr) return -3;
   hipLaunchKernelGGL(hn_mse_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, coarse, fine, gt, (long long)n,
-                     loss_out);
+                     loss_out, (float*)nullptr, (float*)nullptr);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int hn_mse_loss_forward_grad(const float* coarse, const float* fine, const float* gt, int64_t n,
+                                        float* loss_out, float* d_coarse, float* d_fine, hnStream_t stream) {
+  if (n <= 0) return -2;
+  if (coarse == nullptr || gt == nullptr || loss_out == nullptr || d_coarse == nullptr) return -3;
+  if (fine != nullptr && d_fine == nullptr) return -3;
+  hipLaunchKernelGGL(hn_mse_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, coarse, fine, gt, (long long)n,
+                     loss_out, d_coarse, d_fine);
   HN_CHECK_LAUNCH();
   return 0;
 }

@@ -750,8 +750,18 @@ class _MseFn(torch.autograd.Function):
         if c.shape != t.shape or (f is not None and f.shape != t.shape):
             raise L.HnError("mse_loss: prediction and target shapes differ")
         loss = torch.empty((), dtype=torch.float32, device=c.device)
-        L.launch("hn_mse_loss_forward", L.ptr(c), L.ptr(f), L.ptr(t), C.c_int64(c.numel()), L.ptr(loss),
-                 L.stream_handle())
+        ctx.unit = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            # the gradients for a root gradient of exactly 1 come out of the same launch (what `functional.backward(loss)`
+            # passes: the loss of a training step IS the root); any other incoming gradient takes the backward kernel
+            dc = torch.empty_like(c)
+            df = torch.empty_like(f) if f is not None else None
+            L.launch("hn_mse_loss_forward_grad", L.ptr(c), L.ptr(f), L.ptr(t), C.c_int64(c.numel()), L.ptr(loss), L.ptr(dc),
+                     L.ptr(df), L.stream_handle())
+            ctx.unit = (dc, df)
+        else:
+            L.launch("hn_mse_loss_forward", L.ptr(c), L.ptr(f), L.ptr(t), C.c_int64(c.numel()), L.ptr(loss),
+                     L.stream_handle())
         ctx.saved = (c, f, t)
         return loss
 
@@ -759,6 +769,8 @@ class _MseFn(torch.autograd.Function):
     def backward(ctx, g):
         L.load()
         c, f, t = ctx.saved
+        if ctx.unit is not None and g.data_ptr() in _UNIT_ROOTS:      # the cached device scalar 1.0 of functional.backward
+            return ctx.unit[0], ctx.unit[1], None
         g = g.contiguous().float()
         dc = torch.empty_like(c)
         df = torch.empty_like(f) if f is not None else None
@@ -767,6 +779,7 @@ class _MseFn(torch.autograd.Function):
         return dc, df, None
 
 
+_UNIT_ROOTS = set()     # data_ptr() of the cached root gradients that hold exactly 1.0 (never freed: _ROOT_GRADS keeps them)
 _ROOT_GRADS: Dict[tuple, torch.Tensor] = {}
 
 
@@ -780,6 +793,8 @@ def backward(loss: torch.Tensor, weight: float = 1.0):
         if torch.cuda.is_current_stream_capturing():
             raise L.HnError("functional.backward: first use of a new weight inside a stream capture (run a warm-up step)")
         g = _ROOT_GRADS[key] = torch.full((), float(weight), dtype=loss.dtype, device=loss.device)
+        if float(weight) == 1.0 and loss.dtype == torch.float32:
+            _UNIT_ROOTS.add(g.data_ptr())
     loss.backward(gradient=g)
 
 

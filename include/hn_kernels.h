@@ -477,6 +477,10 @@ int hn_mse_loss_forward(const float* coarse, const float* fine, const float* gt,
                         hnStream_t stream);
 int hn_mse_loss_backward(const float* coarse, const float* fine, const float* gt, int64_t n, const float* g_loss,
                          float* d_coarse, float* d_fine, hnStream_t stream);
+/* Forward that also writes the gradients hn_mse_loss_backward would write for a root gradient of exactly 1 (bit for bit):
+ * a training step whose loss is the root of the backward pass needs no second launch. */
+int hn_mse_loss_forward_grad(const float* coarse, const float* fine, const float* gt, int64_t n, float* loss_out,
+                             float* d_coarse, float* d_fine, hnStream_t stream);
 
 /* torch.optim.Adam (the reference's default optimizer, utils/__init__.py get_optimizer) over ONE flat fp32 buffer
  * (ParamArena): p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), m,v updated first, L2 weight decay added to the
