@@ -122,7 +122,7 @@ EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_pack_units_multi",
            "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf", "hn_sample_pdf_split",
            "hn_embed_gather", "hn_embed_backward", "hn_se3_apply_forward", "hn_se3_apply_backward", "hn_se3_warp_forward", "hn_se3_warp_backward", "hn_generate_rays", "hn_adam_step",
            "hn_mse_loss_forward", "hn_mse_loss_backward", "hn_mse_loss_forward_grad", "hn_depth_index", "hn_random_fill",
-           "hn_probe_mfma", "hn_calib_mfma", "hn_calib_stream", "hn_calib_stream_pattern"]
+           "hn_probe_mfma", "hn_calib_mfma", "hn_calib_stream", "hn_calib_stream_pattern", "hn_calib_ring"]
 
 _lib = None
 

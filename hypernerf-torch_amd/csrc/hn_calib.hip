@@ -76,6 +76,70 @@ __global__ __launch_bounds__(512, 2) void hn_calib_stream_kernel(const char* __r
   hn_timeline_end(t);
 }
 
+// The DMA protocol of hn_wgrad_kernel without its products (PROTO 0): a ring of STAGES stages of 32 KiB, every wave issues
+// its 4 pieces of a stage, waits (counted vmcnt) for the oldest stage, all waves meet at a barrier, the freed buffer is
+// refilled.  PROTO 1: the same ring without the barrier (each wave waits for its own pieces only — what the stream costs
+// when nothing is shared).  Each workgroup streams a contiguous region of its own.
+template <int STAGES, int PROTO>
+__global__ __launch_bounds__(512, 2) void hn_calib_ring_kernel(const char* __restrict__ buf, long long n_kib,
+                                                               float* sink, uint64_t* t) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  hn_timeline_begin(t);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long nstage = (n_kib / 32) / gridDim.x;            // stages of 32 KiB per workgroup
+  const char* base = buf + (long long)blockIdx.x * nstage * 32768;
+  auto issue = [&](long long s) {
+    const char* src = base + s * 32768;
+    char* dst = smem + (s % STAGES) * 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int unit = wave + 8 * i;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + unit * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + unit * 1024), 16, 0, 2);
+    }
+  };
+  for (int s0 = 0; s0 < STAGES - 1 && s0 < nstage; ++s0) issue(s0);
+  for (long long s = 0; s < nstage; ++s) {
+    // stages issued after s that may stay in flight: STAGES - 2 (4 pieces each)
+    if (STAGES == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (STAGES == 5) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (PROTO == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (s + STAGES - 1 < nstage) issue(s + STAGES - 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0 && reinterpret_cast<float*>(smem)[0] == 123.456f) sink[0] = 1.0f;
+  hn_timeline_end(t);
+}
+
+extern "C" int hn_calib_ring(const void* buf_dev, long long n_bytes, int stages, int proto, float* sink_dev,
+                             uint64_t* t_dev, hnStream_t stream) {
+  if (n_bytes < 32768LL * 256 || (stages != 3 && stages != 4 && stages != 5) || (proto != 0 && proto != 1)) return -2;
+  if (buf_dev == nullptr || sink_dev == nullptr || t_dev == nullptr) return -3;
+#define HN_RING(S, P)                                                                                                    \
+  {                                                                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hn_calib_ring_kernel<S, P>),                                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
+    hipLaunchKernelGGL((hn_calib_ring_kernel<S, P>), dim3(256), dim3(512), S * 32768, (hipStream_t)stream,               \
+                       (const char*)buf_dev, n_bytes / 1024, sink_dev, t_dev);                                           \
+  }
+  if (stages == 3 && proto == 0) HN_RING(3, 0)
+  else if (stages == 3) HN_RING(3, 1)
+  else if (stages == 4 && proto == 0) HN_RING(4, 0)
+  else if (stages == 4) HN_RING(4, 1)
+  else if (proto == 0) HN_RING(5, 0)
+  else HN_RING(5, 1)
+#undef HN_RING
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int hn_calib_mfma(int iters, float* sink_dev, uint64_t* t_dev, hnStream_t stream) {
   if (iters <= 0) return -2;
   if (sink_dev == nullptr || t_dev == nullptr) return -3;

@@ -1047,7 +1047,9 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
           for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
           const int col = a.embed_col[hn_rho(i, h)];
           if (r == 0 && col >= 0) {
-            if (a.embed_partial != nullptr) a.embed_partial[(size_t)blk * a.embed_dim + col] = v;
+            // (the opt-in 8-bit-stash build keeps the atomics: the host never hands it a partial buffer, and the extra
+            // pointer pushed that build's allocation into scratch)
+            if (!S8 && a.embed_partial != nullptr) a.embed_partial[(size_t)blk * a.embed_dim + col] = v;
             else if (erow >= 0 && erow < a.embed_rows) atomicAdd(a.embed_grad + (size_t)erow * a.embed_dim + col, v);
           }
         }

@@ -535,6 +535,10 @@ int hn_calib_stream(const void* buf_dev, long long n_bytes, float* sink_dev, uin
  * of its own, front to back — 256 far-apart sequential streams, the pattern of hn_wgrad_kernel's jobs. */
 int hn_calib_stream_pattern(const void* buf_dev, long long n_bytes, int pattern, float* sink_dev, uint64_t* t_dev,
                             hnStream_t stream);
+/* The DMA protocol of hn_wgrad_kernel alone: a ring of `stages` (3, 4, 5) stages of 32 KiB, counted vmcnt wait for the
+ * oldest stage, proto 0: + a workgroup barrier per stage (the kernel's), proto 1: no barrier. */
+int hn_calib_ring(const void* buf_dev, long long n_bytes, int stages, int proto, float* sink_dev, uint64_t* t_dev,
+                  hnStream_t stream);
 
 /* Debug/probe: runs one MFMA of each kind on identifiable data (layout self-test on real hardware). */
 int hn_probe_mfma(float* out_bf16_acc, float* out_f32_acc, float* out_glds, hnStream_t stream);
