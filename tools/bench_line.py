@@ -13,5 +13,6 @@ for f in sys.argv[1:]:
     if cal:
         tr = cal.get("timed_region", {})
         print(f"    box: MFMA probe {cal['mfma_probe_tflops']:.0f} TFLOP/s @ {cal['mfma_probe_sclk_mhz']:.0f} MHz, stream probe "
-              f"{cal['hbm_probe_tbps']:.2f} TB/s, step at {tr.get('power_w')} W / {tr.get('sclk_mhz')} MHz; nominal-box "
-              f"{cal.get('normalised', {}).get('ms_per_step_on_nominal_box')} ms")
+              f"{cal['hbm_probe_tbps']:.2f} TB/s, step (soak) at {(cal.get('soak') or {}).get('power_w')} W / "
+              f"{(cal.get('soak') or {}).get('sclk_mhz')} MHz; at the nominal clock "
+              f"{cal.get('normalised', {}).get('ms_per_step_at_nominal_clock')} ms")
