@@ -768,13 +768,16 @@ class Program:
                 # 0.717-0.725 ms with 5 MiB, 20 MiB 0.835 ms: one job longer than the launch), jobs of small ones
                 # fewer (they fill the tail of the launch): WGRAD_JOB_SCALE / `launch_bytes`
                 big, small = n_nt * n_kt >= 48, n_nt * n_kt < 12
+                share_cu = (launch_bytes if launch_bytes else total_tiles * nblk * tile_bytes) / N_CUS
+                # round 5: the base size grows with the launch — a CU never gets more than ~WGRAD_JOBS_PER_CU (16) mid-sized
+                # jobs (config 3 streams 266 MB per CU: 5-MiB jobs were 50 flushes per CU, and 0.5 ms of slab reduction)
+                base = max(job_bytes, share_cu / WGRAD_JOBS_PER_CU) if WGRAD_JOBS_PER_CU > 0 else job_bytes
                 if WGRAD_JOB_SCALE is not None:
                     jb = job_bytes * WGRAD_JOB_SCALE[0 if big else (2 if small else 1)]
                 elif big:
-                    share_cu = (launch_bytes if launch_bytes else total_tiles * nblk * tile_bytes) / N_CUS
-                    jb = min(max(0.85 * share_cu, job_bytes), 8.0 * job_bytes)
+                    jb = min(max(0.85 * share_cu, base), WGRAD_BIG_CAP * base)
                 else:
-                    jb = job_bytes * (0.5 if small else 1.0)
+                    jb = base * (0.5 if small else 1.0)
                 share = max(1, min(nstage, round((n_nt + n_kt) * nblk * tile_bytes / jb)))
             else:
                 share = max(1, min(nstage, round(target_jobs * (n_nt + n_kt) / total_tiles)))
@@ -834,6 +837,8 @@ N_CUS = 256                      # MI355X
 # backward feature-gradient ops: 2 = only tiles with a differentiable feature, no chain-rule factor on identity-only tiles;
 # 1 = only the tile skip; 0 = every tile of a group with a gradient (rounds 1-3)
 AUX_TILE_SKIP = int(os.environ.get("HN_AUX_TILE_SKIP", 2))
+WGRAD_JOBS_PER_CU = float(os.environ.get("HN_WGRAD_JOBS_PER_CU", 16.0))   # 0: the base job size never grows with the launch (round 4)
+WGRAD_BIG_CAP = float(os.environ.get("HN_WGRAD_BIG_CAP", 8.0))     # largest job of a big rectangle, in units of WGRAD_JOB_BYTES
 WGRAD_FUSE_SEGS = int(os.environ.get("HN_WGRAD_FUSE_SEGS", 1))     # 0: one job per input segment of a skip layer (rounds 1-3)
 WGRAD_GRID = int(os.environ.get("HN_WGRAD_GRID", 1))       # 0: the wave grids of rounds 1-3 (Program._wave_grid)
 WGRAD_TAIL_FRAC = float(os.environ.get("HN_WGRAD_TAIL_FRAC", 0.4))   # lightest 40 % of the jobs are halved: -1.8 % step time at config 2
