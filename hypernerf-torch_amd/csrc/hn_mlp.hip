@@ -1302,7 +1302,11 @@ HN_DEV void hn_tr8_block(DwFrag8* xb, DwFrag8* za, unsigned ax, unsigned az) {
 }
 
 HN_DEV void hn_wait_vmcnt(int n) {
-  // s_waitcnt needs an immediate: wait until at most n of this wave's vector-memory ops are outstanding
+  // s_waitcnt needs an immediate: wait until at most n of this wave's vector-memory ops are outstanding; counts without
+  // a case of their own round DOWN (waiting for more than asked is always safe)
+  if (n >= 32) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); return; }
+  if (n >= 24) { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); return; }
+  if (n >= 16) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); return; }
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -1316,9 +1320,7 @@ HN_DEV void hn_wait_vmcnt(int n) {
     case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
     case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;       // 12 .. 15
   }
 }
 
@@ -1335,6 +1337,9 @@ struct HnDwBatchTable {
   int n;
 };
 
+// (Round 5 tried 2 and 4 extra LOADER waves per workgroup that do nothing but the ring's LDS-DMA, so that the compute waves
+// go from the stage barrier straight into their products: 1.00 / 0.78 ms against 0.62 — three waves per SIMD at 168
+// registers + 20 B of scratch, and two waves cannot issue a stage's 32 pieces in a stage's time.  Removed.)
 template <bool BF16, bool S8 = false>
 __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable tab) {
   hn_timeline_begin(tab.timeline);
