@@ -1167,6 +1167,79 @@ HN_DEV void hn_tr_tile(bf16x8* v, unsigned a0, unsigned a1) {
   v[0] = __builtin_bit_cast(bf16x8, w0);
   v[1] = __builtin_bit_cast(bf16x8, w1);
 }
+// All operand tiles of one 32-point block of a wave's rectangle (2 X tiles, NZ dZ tiles of 2 KiB) under ONE wait: 8 + 4 NZ
+// transposed reads in flight together instead of a read-wait-multiply round trip per tile (an LDS round trip next to the
+// ring's DMA writes is ~300 cycles; six of them per block were the critical path of a stage).  Tiles the wave does not own
+// are read all the same (never used; reads past the end of LDS return zero).
+template <int NZ>
+HN_DEV void hn_tr_block(bf16x8 (*x)[2], bf16x8 (*z)[2], unsigned ax0, unsigned ax1, unsigned az0, unsigned az1) {
+  u32x2 r[8 + 4 * NZ];
+  if constexpr (NZ == 4) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %24\n\t"
+        "ds_read_b64_tr_b16 %1, %25\n\t"
+        "ds_read_b64_tr_b16 %2, %24 offset:256\n\t"
+        "ds_read_b64_tr_b16 %3, %25 offset:256\n\t"
+        "ds_read_b64_tr_b16 %4, %24 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %5, %25 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %6, %24 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %7, %25 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %8, %26\n\t"
+        "ds_read_b64_tr_b16 %9, %27\n\t"
+        "ds_read_b64_tr_b16 %10, %26 offset:256\n\t"
+        "ds_read_b64_tr_b16 %11, %27 offset:256\n\t"
+        "ds_read_b64_tr_b16 %12, %26 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %13, %27 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %14, %26 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %15, %27 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %16, %26 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %17, %27 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %18, %26 offset:4352\n\t"
+        "ds_read_b64_tr_b16 %19, %27 offset:4352\n\t"
+        "ds_read_b64_tr_b16 %20, %26 offset:6144\n\t"
+        "ds_read_b64_tr_b16 %21, %27 offset:6144\n\t"
+        "ds_read_b64_tr_b16 %22, %26 offset:6400\n\t"
+        "ds_read_b64_tr_b16 %23, %27 offset:6400\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+          "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15]),
+          "=&v"(r[16]), "=&v"(r[17]), "=&v"(r[18]), "=&v"(r[19]), "=&v"(r[20]), "=&v"(r[21]), "=&v"(r[22]), "=&v"(r[23])
+        : "v"(ax0), "v"(ax1), "v"(az0), "v"(az1)
+        : "memory");
+  } else {
+    static_assert(NZ == 2, "");
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %16\n\t"
+        "ds_read_b64_tr_b16 %1, %17\n\t"
+        "ds_read_b64_tr_b16 %2, %16 offset:256\n\t"
+        "ds_read_b64_tr_b16 %3, %17 offset:256\n\t"
+        "ds_read_b64_tr_b16 %4, %16 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %5, %17 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %6, %16 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %7, %17 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %8, %18\n\t"
+        "ds_read_b64_tr_b16 %9, %19\n\t"
+        "ds_read_b64_tr_b16 %10, %18 offset:256\n\t"
+        "ds_read_b64_tr_b16 %11, %19 offset:256\n\t"
+        "ds_read_b64_tr_b16 %12, %18 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %13, %19 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %14, %18 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %15, %19 offset:2304\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+          "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+        : "v"(ax0), "v"(ax1), "v"(az0), "v"(az1)
+        : "memory");
+  }
+#pragma unroll
+  for (int t = 0; t < 2 + NZ; ++t)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const u32x4 w = {r[4 * t + 2 * m][0], r[4 * t + 2 * m][1], r[4 * t + 2 * m + 1][0], r[4 * t + 2 * m + 1][1]};
+      if (t < 2) x[t][m] = __builtin_bit_cast(bf16x8, w);
+      else z[t - 2][m] = __builtin_bit_cast(bf16x8, w);
+    }
+}
 template <>
 struct DwFrag<true> {
   bf16x8 v[2];
@@ -1367,7 +1440,17 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   constexpr int TU = S8 ? 1 : M::TILE_UNITS;
   constexpr int TBc = TU * 1024;
   constexpr size_t TB = TBc;
-  constexpr int STAGES = S8 ? 3 : 4;      // 8-bit stash: 3 x 48 KiB (a third fewer stage barriers), else 4 x 32 KiB
+#ifndef HN_WGRAD_MAXSLOT
+#define HN_WGRAD_MAXSLOT 8      /* LDS-DMA pieces per wave and stage: a stage holds <= 8 x MAXSLOT KiB; _lib.WGRAD_MAXSLOT mirrors it */
+#endif
+#ifndef HN_WGRAD_STAGES
+#define HN_WGRAD_STAGES 2      /* ring depth of the bf16 / fp32 builds; _lib.WGRAD_STAGES mirrors it (A/B knob) */
+#endif
+  // The ring: 2 x 64 KiB since round 5 (rounds 2-5a: 4 x 32 KiB).  Same box, config 2, the launch in ms — 5 x 32: 0.637,
+  // 4 x 32: 0.615-0.62, 3 x 32: 0.58-0.59, 3 x 48: 0.585, 2 x 32: 0.61, 2 x 64: 0.564, 2 x 80: 0.566 — a stage costs its
+  // barrier, its counted wait and a burst of DMA issue whatever its size, and more than one stage in flight behind the one
+  // being multiplied buys nothing (profiles/r05_wgrad_ring.log).  8-bit stash: 3 x 48 KiB.
+  constexpr int STAGES = S8 ? 3 : HN_WGRAD_STAGES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1420,7 +1503,7 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   // Per-wave LDS-DMA slots of one stage, decoded ONCE (the integer divisions by run-time tile counts would
   // otherwise cost ~600 scalar instructions per stage): slot i moves 1 KiB from
   // sbase[i] + (first block of the stage) * sstride[i]  to  stage buffer + sdst[i], if sblk[i] < blocks in stage.
-  constexpr int MAXSLOT = 8;                     // <= 32 units per stage / 8 waves... (fp32 tiles: 4 units each)
+  constexpr int MAXSLOT = HN_WGRAD_MAXSLOT;                     // <= 32 units per stage / 8 waves... (fp32 tiles: 4 units each)
   // offsets in KiB (every slot offset, tile and unit is a multiple of 1 KiB; 32 bits reach 4 TiB): one register per
   // DMA slot instead of a 64-bit pair — the fp32 build sits at 256 registers, and a spilled address reloaded inside the
   // stage loop drains the ring (scratch loads share the in-order vmcnt queue)
@@ -1506,7 +1589,10 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
 #ifdef HN_PROF
     if (prof_on) HN_TS(t2_);
 #endif
-    if (s + STAGES - 1 < nstage) issue(s + STAGES - 1);   // refill the buffer stage s-1 used
+#ifndef HN_WGRAD_ISSUE_LATE
+#define HN_WGRAD_ISSUE_LATE 0      /* 1: refill behind the stage's products instead of in front of them (A/B knob) */
+#endif
+    if (!HN_WGRAD_ISSUE_LATE && s + STAGES - 1 < nstage) issue(s + STAGES - 1);   // refill the buffer stage s-1 used
 #ifdef HN_PROF
     if (prof_on) HN_TS(t3_);
 #endif
@@ -1528,6 +1614,33 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
             for (int j = 0; j < 2; ++j)
               if (j < my_k) DwFrag8::mma(acc[i][j], za8[i], xb[j]);
             if (bias_mask & (1u << i)) DwFrag8::mma_ones(accb[0], za8[i], i, lane);
+          }
+        });
+        continue;
+      }
+#ifndef HN_WGRAD_BLOCK
+#define HN_WGRAD_BLOCK 1      /* 0: rounds 1-5a, one read-wait-multiply round trip per operand tile (A/B knob) */
+#endif
+      if constexpr (BF16 && !S8 && HN_WGRAD_BLOCK != 0) {
+        // every operand tile of the block under one LDS wait (hn_tr_block), then the products back to back
+        DwFrag<true> za[4];
+        bf16x8 xv[2][2], zv[4][2];
+        if (my_n > 2) hn_tr_block<4>(xv, zv, ax + tro0, ax + tro1, az + tro0, az + tro1);
+        else hn_tr_block<2>(xv, zv, ax + tro0, ax + tro1, az + tro0, az + tro1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { xb[j].v[0] = xv[j][0]; xb[j].v[1] = xv[j][1]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { za[i].v[0] = zv[i][0]; za[i].v[1] = zv[i][1]; }
+        static_for4([&](auto I) __attribute__((always_inline)) {
+          constexpr int i = decltype(I)::value;
+          if (i < my_n) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (j < my_k) Fr::mma(acc[i][j], za[i], xb[j]);
+            if (bias_mask & (1u << i)) {
+              if constexpr (BM) Fr::mma_ones(accb[i % NB], za[i], i, lane);
+              else bsum[i] = za[i].add_point_sum(bsum[i]);
+            }
           }
         });
         continue;
@@ -1556,6 +1669,7 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
         }
       });
     }
+    if (HN_WGRAD_ISSUE_LATE && s + STAGES - 1 < nstage) issue(s + STAGES - 1);
 #ifdef HN_PROF
     if (prof_on) { HN_TS(t4_); tw += t1_ - t0_; tb += t2_ - t1_; ti += t3_ - t2_; tc += t4_ - t3_; }
 #endif
@@ -2030,8 +2144,9 @@ extern "C" void hn_set_wgrad_prof(void* p) { hn_wgrad_prof = p; }     // diagnos
 #endif
 static int hn_launch_wgrad(int mode_word, HnDwBatchTable& tab, int total, hnStream_t stream) {
   hn_allow_big_lds();
-  // 4 stages x 32 KiB : bf16 16 tiles of 2 KiB, fp32 8 of 4 KiB, 8-bit stash 32 of 1 KiB  => 128 KiB
-  size_t lds = 4 * 32 * 1024;
+  // HN_WGRAD_STAGES stages of <= 8 x HN_WGRAD_MAXSLOT KiB (2 x 64 KiB: bf16 32 tiles of 2 KiB, fp32 16 of 4 KiB); 8-bit stash 3 x 48 KiB
+  size_t lds = (size_t)HN_WGRAD_STAGES * 8 * HN_WGRAD_MAXSLOT * 1024;
+  if (lds > 160 * 1024) lds = 160 * 1024;
   const int mode = mode_word & 255, dz_log2 = mode_word >> 8;     // HN_MODE_BF16_S8 | dz_scale_log2 << 8
   tab.unscale = 1.0f;
   if (mode == HN_MODE_BF16_S8) {

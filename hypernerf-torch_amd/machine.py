@@ -746,8 +746,8 @@ class Program:
         stash bytes of that WHOLE launch, all its programs: jobs of big rectangles are sized to one CU's share of it)."""
         goffs = list(grad_offsets) if grad_offsets is not None else self.grad_offsets()[0]
         nblk = (n_points + 31) // 32
-        # tiles per LDS stage of hn_wgrad_kernel: 32 KiB (4-stage ring), 8-bit stash 48 KiB (3-stage ring)
-        stage_tiles = 48 if mode == L.HN_MODE_BF16_S8 else 32 * 1024 // mode_consts(mode)[1]
+        # tiles per LDS stage of hn_wgrad_kernel: 64 KiB (2-stage ring; 32 KiB x 4 in rounds 2-5a), 8-bit stash 48 KiB (3-stage ring)
+        stage_tiles = 48 if mode == L.HN_MODE_BF16_S8 else WGRAD_STAGE_KB * 1024 // mode_consts(mode)[1]
         rects = self._wgrad_rects(mode, n_points)
         total_tiles = sum(r[8] + r[9] for r in rects)
         jobs = []
@@ -837,6 +837,8 @@ N_CUS = 256                      # MI355X
 # backward feature-gradient ops: 2 = only tiles with a differentiable feature, no chain-rule factor on identity-only tiles;
 # 1 = only the tile skip; 0 = every tile of a group with a gradient (rounds 1-3)
 AUX_TILE_SKIP = int(os.environ.get("HN_AUX_TILE_SKIP", 2))
+# LDS stage of hn_wgrad_kernel's ring (bf16 / fp32 builds), KiB: as large as the build's ring allows (2 x 64 KiB; A/B knob)
+WGRAD_STAGE_KB = min(int(os.environ.get("HN_WGRAD_STAGE_KB") or L.WGRAD_MAX_STAGE_KB), L.WGRAD_MAX_STAGE_KB)
 WGRAD_JOBS_PER_CU = float(os.environ.get("HN_WGRAD_JOBS_PER_CU", 16.0))   # 0: the base job size never grows with the launch (round 4)
 WGRAD_BIG_CAP = float(os.environ.get("HN_WGRAD_BIG_CAP", 8.0))     # largest job of a big rectangle, in units of WGRAD_JOB_BYTES
 WGRAD_FUSE_SEGS = int(os.environ.get("HN_WGRAD_FUSE_SEGS", 1))     # 0: one job per input segment of a skip layer (rounds 1-3)

@@ -517,3 +517,30 @@ def test_hot_kernels_stay_within_their_register_budget():
         assert name in info, sorted(info)
         assert info[name]["VGPRs"] <= 256 and info[name]["Occupancy [waves/SIMD]"] == 2, (name, info[name])
         assert info[name]["ScratchSize [bytes/lane]"] <= max_scratch, (name, info[name])
+
+
+def test_wgrad_ring_constants_mirror_the_kernel_defaults():
+    """The host cuts hn_wgrad_kernel's jobs into LDS stages (machine.Program.wgrad_jobs); ring depth and pieces per wave
+    are compile-time constants of the kernel.  _lib mirrors their defaults: a stage the host makes must fit the ring the
+    library was built with (a stage longer than 8 x MAXSLOT KiB is silently never loaded — NaN gradients)."""
+    src = open(os.path.join(L.CSRC, "hn_mlp.hip")).read()
+    stages = int(re.search(r"#define HN_WGRAD_STAGES (\d+)", src).group(1))
+    maxslot = int(re.search(r"#define HN_WGRAD_MAXSLOT (\d+)", src).group(1))
+    if not os.environ.get("HN_WGRAD_STAGES") and not os.environ.get("HN_WGRAD_MAXSLOT"):
+        assert (L.WGRAD_STAGES, L.WGRAD_MAXSLOT) == (stages, maxslot)
+    assert L.WGRAD_STAGES * L.WGRAD_MAX_STAGE_KB <= 160 and L.WGRAD_MAX_STAGE_KB <= 8 * L.WGRAD_MAXSLOT
+    from hypernerf_torch_amd import machine as M
+    assert M.WGRAD_STAGE_KB <= L.WGRAD_MAX_STAGE_KB
+    # every job of a config-2-sized launch: blocks per stage x units per block within the per-wave slot table and the ring
+    m = models.NerfModel(EMB, n_samples_coarse=8, n_samples_fine=8, hyper_slice_method="bendy_sheet",
+                         use_nerf_embed=True, use_alpha_cond=True)
+    progs = [m._level_call("fine").program, warping.SE3Field(in_ch=3)._field_call(True).program,
+             legacy_nerf.NeRF().fused_call(legacy_nerf.Embedding(3, 10), legacy_nerf.Embedding(3, 4), False).program]
+    for prog in progs:
+        for mode in (L.HN_MODE_BF16, L.HN_MODE_F32):
+            tile_units = M.mode_consts(mode)[1] // 1024
+            for jobs in (prog.wgrad_jobs(mode, 1000), prog.wgrad_jobs(mode, 196608, job_bytes=M.WGRAD_JOB_BYTES)):
+                bps = (jobs["pad"] >> 16) & 255
+                units = bps * (jobs["n_nt"] + jobs["n_kt"]) * tile_units
+                assert (bps >= 1).all() and int(units.max()) <= 8 * L.WGRAD_MAXSLOT
+                assert int(units.max()) * L.WGRAD_STAGES <= 160
