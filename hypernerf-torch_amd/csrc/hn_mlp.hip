@@ -1443,6 +1443,9 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
 #ifndef HN_WGRAD_MAXSLOT
 #define HN_WGRAD_MAXSLOT 8      /* LDS-DMA pieces per wave and stage: a stage holds <= 8 x MAXSLOT KiB; _lib.WGRAD_MAXSLOT mirrors it */
 #endif
+#ifndef HN_WGRAD_AUX
+#define HN_WGRAD_AUX 2      /* nt: every stash byte is read once, do not keep it in L2 / MALL */
+#endif
 #ifndef HN_WGRAD_STAGES
 #define HN_WGRAD_STAGES 2      /* ring depth of the bf16 / fp32 builds; _lib.WGRAD_STAGES mirrors it (A/B knob) */
 #endif
@@ -1540,9 +1543,6 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
       if ((sinfo[i] >> 2) < nblk_s) {
         const unsigned kind = sinfo[i] & 3;
         const char* src = stash + ((unsigned long long)(sbase[i] + (unsigned)b0 * (kind == 1 ? zstride : (kind == 2 ? x2stride : xstride))) << 10);
-#ifndef HN_WGRAD_AUX
-#define HN_WGRAD_AUX 2      /* nt: every stash byte is read once, do not keep it in L2 / MALL */
-#endif
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
                                          (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0,
                                          HN_WGRAD_AUX);
@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     if ((sinfo[i] >> 2) < nb_last) ++last_cnt;
 #ifdef HN_PROF   // diagnostic build: wave 0 of every 97th workgroup sums the cycles of its four phases per stage
   long long* prof_buf = (long long*)tab.b[HN_MAX_WGRAD_BATCH - 1].jobs;     // set by hn_set_wgrad_prof
-  const bool prof_on = prof_buf != nullptr && tab.n < HN_MAX_WGRAD_BATCH && (blockIdx.x % 97) == 0 && wave == 0;
+  const bool prof_on = prof_buf != nullptr && tab.n < HN_MAX_WGRAD_BATCH && (blockIdx.x % 97) == 0 && wave == (HN_PROF - 1);     // HN_PROF = 1 + the wave to watch
   unsigned long long tw = 0, tb = 0, ti = 0, tc = 0, t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0, t4_ = 0;
 #define HN_TS(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
 #endif
@@ -1589,10 +1589,12 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
 #ifdef HN_PROF
     if (prof_on) HN_TS(t2_);
 #endif
-#ifndef HN_WGRAD_ISSUE_LATE
-#define HN_WGRAD_ISSUE_LATE 0      /* 1: refill behind the stage's products instead of in front of them (A/B knob) */
-#endif
-    if (!HN_WGRAD_ISSUE_LATE && s + STAGES - 1 < nstage) issue(s + STAGES - 1);   // refill the buffer stage s-1 used
+    // refill the buffer stage s-1 used.  (Measured and dropped, profiles/r05_wgrad_ring.log: the refill behind the stage's
+    // products, for all waves or for the second wave of every SIMD only — no gain at any ring depth; a piece's address kept
+    // in a register pair per slot instead of decoded from the slot tables — wave 0's issue share 34 -> 25 % of a stage, the
+    // stage as long as before: a wave sits ~160-290 cycles on every 1-KiB piece whatever precedes it, the memory pipe's
+    // back-pressure, not instruction count.)
+    if (s + STAGES - 1 < nstage) issue(s + STAGES - 1);
 #ifdef HN_PROF
     if (prof_on) HN_TS(t3_);
 #endif
@@ -1669,7 +1671,6 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
         }
       });
     }
-    if (HN_WGRAD_ISSUE_LATE && s + STAGES - 1 < nstage) issue(s + STAGES - 1);
 #ifdef HN_PROF
     if (prof_on) { HN_TS(t4_); tw += t1_ - t0_; tb += t2_ - t1_; ti += t3_ - t2_; tc += t4_ - t3_; }
 #endif
