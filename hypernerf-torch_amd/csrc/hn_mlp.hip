@@ -2009,9 +2009,11 @@ __global__ __launch_bounds__(256) void hn_wgrad_reduce_kernel(const HnDwReduceTi
                                                               const uint32_t* __restrict__ list, const HnDwReduceTable tab,
                                                               const HnEmbedReduce em) {
   if ((int)blockIdx.x < em.rows) {
-    // one table row (these workgroups come FIRST in the grid: they are the long ones).  Thread x takes blocks x, x + 256,
-    // ... of every program in turn (a fixed order); the 256 partial sums are added by a fixed shuffle tree per wave, the
-    // four waves' sums in wave order by threads 0 .. dim-1, which add the row to the gradient (one writer per element)
+    // one table row (these workgroups come FIRST in the grid: they are the long ones).  Thread x takes rays x, x + 256,
+    // ... of every program in turn and, for the rays that carry this row, their blocks in order (a fixed order; four index
+    // loads in flight — a thread that looked up the ray of every BLOCK in turn paid 24 dependent L2 latencies at config 2);
+    // the 256 partial sums are added by a fixed shuffle tree per wave, the four waves' sums in wave order by threads
+    // 0 .. dim-1, which add the row to the gradient (one writer per element)
     __shared__ float red[4][32];
     const long long row = blockIdx.x;
     float acc[32];
@@ -2021,11 +2023,22 @@ __global__ __launch_bounds__(256) void hn_wgrad_reduce_kernel(const HnDwReduceTi
       const float* P = em.partial[sIdx];
       const int64_t* idx = em.idx[sIdx];
       const int nb = em.n_blocks[sIdx], spr = em.samples_per_ray[sIdx];
-      for (int b = threadIdx.x; b < nb; b += 256) {
-        if (idx[(b * 32) / spr] != row) continue;
+      const int bpr = spr / 32;                         // blocks per ray (this path: samples_per_ray % 32 == 0)
+      const int n_rays = nb / bpr;
+      for (int r0 = threadIdx.x; r0 < n_rays; r0 += 4 * 256) {
+        long long id[4];
 #pragma unroll
-        for (int c = 0; c < 32; ++c)
-          if (c < em.dim && ((em.col_mask >> c) & 1u)) acc[c] += P[(size_t)b * em.dim + c];
+        for (int u = 0; u < 4; ++u) id[u] = (r0 + 256 * u < n_rays) ? (long long)idx[r0 + 256 * u] : -1ll;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (id[u] != row) continue;
+          for (int k = 0; k < bpr; ++k) {
+            const size_t b = (size_t)(r0 + 256 * u) * bpr + k;
+#pragma unroll
+            for (int c = 0; c < 32; ++c)
+              if (c < em.dim && ((em.col_mask >> c) & 1u)) acc[c] += P[b * em.dim + c];
+          }
+        }
       }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
