@@ -8,6 +8,7 @@ numpy MLP to ~1e-12: any layout / ordering mistake in the host compiler shows up
 without needing a GPU.
 """
 import numpy as np
+from hypernerf_torch_amd import _lib as L
 
 CHUNK = 32
 LANES = np.arange(64)
@@ -548,7 +549,8 @@ def run_wgrad(prog, mode, jobs, stash, n_grad):
         assert gn * gk <= 8 and bps >= 1
         tn, tk = -(-jb["n_nt"] // gn), -(-jb["n_kt"] // gk)
         assert tn <= 4 and tk <= 2
-        assert bps * (jb["n_nt"] + jb["n_kt"]) * (2 if mode.bf16 else 4) <= 32      # KiB per LDS stage
+        # KiB per LDS stage: what the build's ring holds (2 x 64 KiB since round 5; _lib mirrors the kernel's constants)
+        assert bps * (jb["n_nt"] + jb["n_kt"]) * (2 if mode.bf16 else 4) <= L.WGRAD_MAX_STAGE_KB
         assert (jb["blk0"] % bps) == 0
         for wave in range(8):
             wn, wk = wave // gk, wave % gk

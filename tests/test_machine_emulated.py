@@ -587,7 +587,7 @@ def test_wgrad_job_tables_cover_every_tile_product_once(launch_bytes):
     rectangle admits, job sizes that follow the launch's bytes, skip layers' two input segments as one rectangle with two
     X slots): whatever the sizing, every (layer part, dZ tile, input k-tile, point block) product is computed by exactly
     ONE job, every bias by exactly one, a job's k-tiles map onto the right stash slot, and every job satisfies the
-    kernel's limits (<= 8 waves, <= 4 x 2 tiles per wave, a stage of `bps` blocks inside 32 / 48 KiB, block ranges
+    kernel's limits (<= 8 waves, <= 4 x 2 tiles per wave, a stage of `bps` blocks inside the build's ring stage (64 KiB; 8-bit stash 48 KiB), block ranges
     aligned to stages)."""
     m = models.NerfModel(EMB, n_samples_coarse=8, n_samples_fine=8, hyper_slice_method="bendy_sheet",
                          use_nerf_embed=True, use_alpha_cond=True)
@@ -598,7 +598,7 @@ def test_wgrad_job_tables_cover_every_tile_product_once(launch_bytes):
                 offs, _, _ = prog.layout(mode, n_points)
                 nblk = (n_points + 31) // 32
                 tile_kib = machine.mode_consts(mode)[1] // 1024
-                stage_kib = 48 if mode == L.HN_MODE_BF16_S8 else 32
+                stage_kib = 48 if mode == L.HN_MODE_BF16_S8 else L.WGRAD_MAX_STAGE_KB      # 2 x 64 KiB ring since round 5
                 jobs = prog.wgrad_jobs(mode, n_points, job_bytes=machine.WGRAD_JOB_BYTES, launch_bytes=launch_bytes)
                 assert len(jobs) > 0
                 # what the jobs stream == what resolve_pending sizes a launch by (round 5: the launch's bytes are computed
