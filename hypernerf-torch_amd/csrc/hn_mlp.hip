@@ -1593,7 +1593,9 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     // products, for all waves or for the second wave of every SIMD only — no gain at any ring depth; a piece's address kept
     // in a register pair per slot instead of decoded from the slot tables — wave 0's issue share 34 -> 25 % of a stage, the
     // stage as long as before: a wave sits ~160-290 cycles on every 1-KiB piece whatever precedes it, the memory pipe's
-    // back-pressure, not instruction count.)
+    // back-pressure, not instruction count; the refill issued piece by piece behind the products of each dZ tile, slot
+    // tables in register lanes read back with v_readlane, rings of 2-4 stages — 0.557-0.564 ms at 3 x 32 KiB against
+    // 0.545-0.557 for this form: every structure lands on the same ~6 TB/s.)
     if (s + STAGES - 1 < nstage) issue(s + STAGES - 1);
 #ifdef HN_PROF
     if (prof_on) HN_TS(t3_);
