@@ -773,11 +773,14 @@ def _points_by_program(progs):
 def _pmc_traffic(a):
     """HBM bytes per step measured with rocprofv3 PMC passes on this configuration (tools/collect_profiles.sh ->
     tools/make_profiles.py -> profiles/rNN_traffic_configC.json), newest round first.  A summary is only quoted when
-    it was collected on THESE kernels (its `build.kernel_src_sha256` equals the running build's): a round that changes
+    it was collected on THESE kernels (its `build.kernel_src_sha256` equals the running build's, or — comment-only edits of the
+    sources — its `build.lib_sha256` equals the hash of the library this process loaded): a round that changes
     the stash must not report last round's bytes.  Returns (summary | None, note | None)."""
     import glob
     from hypernerf_torch_amd import _lib as L
-    mine = L.build_id()["kernel_src_sha256"]
+    ident = L.build_id()
+    mine = ident["kernel_src_sha256"]
+    mine_lib = ident.get("lib_sha256")          # the built library itself: a comment-only source edit leaves it unchanged
     hits = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_config{a.config}.json")), reverse=True)
     stale = None
     for h in hits:
@@ -789,7 +792,8 @@ def _pmc_traffic(a):
                 and t.get("dtype", "bf16") == a.precision):      # the fp32 mode moves 3x the bytes of the bf16 mode
             continue
         theirs = (t.get("build") or {}).get("kernel_src_sha256")
-        if theirs == mine:
+        theirs_lib = (t.get("build") or {}).get("lib_sha256")
+        if theirs == mine or (mine_lib is not None and theirs_lib == mine_lib):
             t["source"] = os.path.relpath(h, ROOT)
             return t, None
         stale = stale or (f"{os.path.relpath(h, ROOT)} was collected on kernel sources {theirs}, this build is {mine}: "

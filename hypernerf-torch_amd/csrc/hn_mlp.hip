@@ -1399,9 +1399,9 @@ HN_DEV void hn_wait_vmcnt(int n) {
 
 // One workgroup (8 waves, two per SIMD) = one job = the whole dW tile grid (<= 8x8 tiles in bf16, 4x4 in
 // fp32) of one Linear-layer input segment over a range of point blocks.  The dZ and X stash tiles are fetched
-// ONCE by LDS-DMA into a 3-stage ring (a stage = `bps` blocks, <= 32 KiB; 2 stages in flight; counted vmcnt;
-// one raw barrier per stage) and shared by the 8 waves, which own a gn x gk grid of tn x tk (<= 4x2) tile
-// rectangles.  HBM-bound by construction: every stash byte is read exactly once.
+// ONCE by LDS-DMA into a ring of HN_WGRAD_STAGES stages (a stage = `bps` blocks, <= 8 x HN_WGRAD_MAXSLOT KiB: 2 x 64 KiB;
+// counted vmcnt; one raw barrier per stage) and shared by the 8 waves, which own a gn x gk grid of tn x tk (<= 4x2)
+// tile rectangles.  HBM-bound by construction: every stash byte is read exactly once.
 struct HnDwBatchTable {
   HnDwBatch b[HN_MAX_WGRAD_BATCH];
   float unscale;          // HN_MODE_BF16_S8: 2^-dz_scale_log2, applied to every sum before it is added to the gradient
@@ -1628,7 +1628,7 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
       if constexpr (BF16 && !S8 && HN_WGRAD_BLOCK != 0) {
         // every operand tile of the block under one LDS wait (hn_tr_block), then the products back to back
         DwFrag<true> za[4];
-        bf16x8 xv[2][2], zv[4][2];
+        bf16x8 xv[2][2], zv[4][2];      // (a wave with <= 2 dZ tiles reads two; tiles 2, 3 are then never multiplied: i < my_n below)
         if (my_n > 2) hn_tr_block<4>(xv, zv, ax + tro0, ax + tro1, az + tro0, az + tro1);
         else hn_tr_block<2>(xv, zv, ax + tro0, ax + tro1, az + tro0, az + tro1);
 #pragma unroll

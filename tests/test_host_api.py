@@ -417,6 +417,12 @@ def test_pmc_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
     (prof / "r04_traffic_config2.json").write_text(json.dumps(dict(base, build={"kernel_src_sha256": mine})))
     t, note = bench._pmc_traffic(A)
     assert t is not None and note is None and t["source"].endswith("r04_traffic_config2.json")
+    lib = L.build_id().get("lib_sha256")
+    if lib is not None:           # a comment-only edit of the sources: other source hash, the SAME built library -> quoted
+        (prof / "r04_traffic_config2.json").unlink()
+        (prof / "r05_traffic_config2.json").write_text(json.dumps(dict(base, build={"kernel_src_sha256": "1" * 16, "lib_sha256": lib})))
+        t, note = bench._pmc_traffic(A)
+        assert t is not None and note is None and t["source"].endswith("r05_traffic_config2.json")
     A.precision = "fp32"          # a bf16 collection says nothing about the fp32 mode's bytes
     assert bench._pmc_traffic(A)[0] is None
 
