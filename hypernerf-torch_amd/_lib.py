@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libhn_hip.so")
 SOURCES = ["hn_mlp.hip", "hn_render.hip", "hn_calib.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hn_kernels.h")
-BUILD_MACROS = ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX", "HN_WGRAD_EXP", "HN_WGRAD_BIAS_MFMA", "HN_WGRAD_BLOCK", "HN_WGRAD_STAGES", "HN_WGRAD_MAXSLOT")     # build-time tuning knobs (A/B experiments)
+BUILD_MACROS = ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX", "HN_WGRAD_EXP", "HN_WGRAD_BIAS_MFMA", "HN_WGRAD_BLOCK", "HN_WGRAD_STAGES", "HN_WGRAD_MAXSLOT", "HN_WSTREAM_ASYM")     # build-time tuning knobs (A/B experiments)
 
 HN_MODE_F32, HN_MODE_BF16, HN_MODE_BF16_S8 = 0, 1, 2
 # hn_wgrad_kernel's LDS ring (bf16 / fp32 builds): mirrors of the #define defaults in csrc/hn_mlp.hip (the same environment

@@ -35,6 +35,27 @@ struct WStream {
   HN_DEV void issue(int c) {
     const char* src = g + (size_t)c * (HN_CHUNK_UNITS * 1024);
     char* dst = lds + (c & 1) * (HN_CHUNK_UNITS * 1024);
+#ifndef HN_WSTREAM_ASYM
+#define HN_WSTREAM_ASYM 1      /* 0: rounds 1-5a, every wave issues its eighth of a chunk's DMA (A/B knob) */
+#endif
+    if constexpr (WAVES == 8 && HN_WSTREAM_ASYM != 0) {
+      // Waves w and w + 4 share a SIMD.  A wave sits ~100-200 cycles on every 1-KiB LDS-DMA instruction it issues (the
+      // memory pipe's back-pressure, measured in hn_wgrad_kernel); with all eight waves issuing four pieces each behind
+      // the chunk barrier, every SIMD's matrix pipe idled that long once per chunk.  Now the SECOND wave of every SIMD
+      // issues the whole chunk (eight pieces) and the first goes from the barrier straight into its products: forward
+      // -1.5 %, backward -1.3 % same box (profiles/r05_wgrad_ring.log: waves 0-3 instead -0.3 / -1.6 %, two waves x 16
+      // pieces -2.0 / -1.2 %, one wave x 32 +8 / +4 %).
+      if (wave >= 4) {
+#pragma unroll
+        for (int i = 0; i < HN_CHUNK_UNITS / 4; ++i) {
+          const int unit = (wave - 4) + i * 4;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(src + unit * 1024 + lane * 16),
+              (__attribute__((address_space(3))) void*)(dst + unit * 1024), 16, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < HN_CHUNK_UNITS / WAVES; ++i) {
       const int unit = wave + i * WAVES;
@@ -1595,7 +1616,9 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     // stage as long as before: a wave sits ~160-290 cycles on every 1-KiB piece whatever precedes it, the memory pipe's
     // back-pressure, not instruction count; the refill issued piece by piece behind the products of each dZ tile, slot
     // tables in register lanes read back with v_readlane, rings of 2-4 stages — 0.557-0.564 ms at 3 x 32 KiB against
-    // 0.545-0.557 for this form: every structure lands on the same ~6 TB/s.)
+    // 0.545-0.557 for this form; the whole refill issued by the second wave of every SIMD, 16 pieces each — what pays in
+    // the forward / backward machines' weight stream (WStream::issue) — 0.585-0.594 against 0.553-0.564: every structure
+    // lands on the same ~6 TB/s or worse.)
     if (s + STAGES - 1 < nstage) issue(s + STAGES - 1);
 #ifdef HN_PROF
     if (prof_on) HN_TS(t3_);
