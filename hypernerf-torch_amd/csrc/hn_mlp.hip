@@ -46,9 +46,13 @@ struct WStream {
       // -1.5 %, backward -1.3 % same box (profiles/r05_wgrad_ring.log: waves 0-3 instead -0.3 / -1.6 %, two waves x 16
       // pieces -2.0 / -1.2 %, one wave x 32 +8 / +4 %).
       if (wave >= 4) {
+        // the first unit is made opaque here: otherwise the eight piece addresses of chunk 0 are hoisted out of the
+        // persistent tile loop and held in 16 registers for the whole kernel (the AUXG = 3 training build spilled)
+        int u0 = wave - 4;
+        asm volatile("" : "+s"(u0));
 #pragma unroll
         for (int i = 0; i < HN_CHUNK_UNITS / 4; ++i) {
-          const int unit = (wave - 4) + i * 4;
+          const int unit = u0 + i * 4;
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void*)(src + unit * 1024 + lane * 16),
               (__attribute__((address_space(3))) void*)(dst + unit * 1024), 16, 0, 0);
