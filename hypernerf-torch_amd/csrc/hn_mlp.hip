@@ -2185,6 +2185,15 @@ extern "C" int hn_mlp_wgrad_reduce(int mode, const HnDwReduceTile* tiles, int n_
 static void* hn_wgrad_prof = nullptr;
 extern "C" void hn_set_wgrad_prof(void* p) { hn_wgrad_prof = p; }     // diagnostic builds only: (64, 8) int64 buffer
 #endif
+// HN_MODE_BF16 / HN_MODE_F32: bits 8..15 of the mode word state the LDS stage (KiB) the HOST cut the jobs' `bps` for
+// (0 = not stated).  A stage longer than the ring this library was built with would never be loaded in full — the job
+// tables live in device memory, so this is the one place the mismatch can be refused: -8.
+static int hn_wgrad_stage_check(int mode_word) {
+  if ((mode_word & 255) == HN_MODE_BF16_S8) return 0;      // (bits 8.. carry the dZ scale there; its ring is fixed)
+  const int kb = (mode_word >> 8) & 255;
+  if (kb > 8 * HN_WGRAD_MAXSLOT || kb * HN_WGRAD_STAGES > 160) return -8;
+  return 0;
+}
 static int hn_launch_wgrad(int mode_word, HnDwBatchTable& tab, int total, hnStream_t stream) {
   hn_allow_big_lds();
   // HN_WGRAD_STAGES stages of <= 8 x HN_WGRAD_MAXSLOT KiB (2 x 64 KiB: bf16 32 tiles of 2 KiB, fp32 16 of 4 KiB); 8-bit stash 3 x 48 KiB
@@ -2209,6 +2218,7 @@ static int hn_launch_wgrad(int mode_word, HnDwBatchTable& tab, int total, hnStre
 
 extern "C" int hn_mlp_wgrad(int mode, const HnDwJob* jobs, int n_jobs, const void* stash, float* grads,
                             hnStream_t stream) {
+  if (hn_wgrad_stage_check(mode) != 0) return -8;
   if (n_jobs < 0) return -1;
   if (n_jobs == 0) return 0;
   if (jobs == nullptr || stash == nullptr || grads == nullptr) return -3;
@@ -2225,6 +2235,7 @@ extern "C" int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches, int n_ba
 
 extern "C" int hn_mlp_wgrad_batched_t(int mode, const HnDwBatch* batches, int n_batches, const int32_t* order_dev,
                                       uint64_t* timeline_dev, hnStream_t stream) {
+  if (hn_wgrad_stage_check(mode) != 0) return -8;
   if (n_batches < 0 || n_batches > HN_MAX_WGRAD_BATCH) return -1;
   if (n_batches > 0 && batches == nullptr) return -3;
   HnDwBatchTable tab = {};

@@ -825,8 +825,9 @@ class _DevTables:
 
 
 def wgrad_mode_word(mode: int) -> int:
-    """The `mode` argument of hn_mlp_wgrad*: HN_MODE_BF16_S8 carries the dZ scale in bits 8.. (include/hn_kernels.h)."""
-    return mode | (DZ_SCALE_LOG2 << 8) if mode == L.HN_MODE_BF16_S8 else mode
+    """The `mode` argument of hn_mlp_wgrad*: HN_MODE_BF16_S8 carries the dZ scale in bits 8.., the other modes the LDS
+    stage (KiB) the job tables were cut for — the library refuses one that does not fit its ring (include/hn_kernels.h)."""
+    return mode | (DZ_SCALE_LOG2 << 8) if mode == L.HN_MODE_BF16_S8 else mode | (WGRAD_STAGE_KB << 8)
 
 
 # job size relative to WGRAD_JOB_BYTES for rectangles of >= 48 / >= 12 / fewer tiles (see wgrad_jobs)

@@ -280,7 +280,11 @@ int hn_mlp_backward(const HnMlpArgs* args, hnStream_t stream);
 int hn_mlp_workspace_bytes(const int32_t* ops_host, int n_ops, int backward, int mode, int64_t n_points,
                            int64_t* stash_bytes, int64_t* mask_bytes);
 
-/* dW/db for every Linear of a program: grads (fp32) are ACCUMULATED with float atomics. */
+/* dW/db for every Linear of a program: grads (fp32) are ACCUMULATED with float atomics.
+ * `mode` of the three hn_mlp_wgrad* launches is a word: bits 0..7 = HN_MODE_*; HN_MODE_BF16_S8: bits 8.. = dz_scale_log2;
+ * HN_MODE_BF16 / HN_MODE_F32: bits 8..15 = the LDS stage, in KiB, the host cut the jobs' blocks-per-stage (HnDwJob.pad
+ * bits 16..23) for — 0 = not stated.  The kernel's ring is a compile-time constant of the library (2 x 64 KiB); a stated
+ * stage that does not fit it is refused with -8 instead of silently loading part of every stage. */
 int hn_mlp_wgrad(int mode, const HnDwJob* jobs_dev, int n_jobs, const void* stash_dev,
                  float* grad_base_dev, hnStream_t stream);
 

@@ -52,6 +52,13 @@ def test_argument_errors_are_reported_not_crashes():
     c = L.HnCompositeArgs()
     assert lib.hn_composite_forward(ctypes.byref(c), None) < 0
     assert lib.hn_sample_pdf(None, 0, None, 0, None, 0, None, None, None, 0, 0, 0, None, None, None, None, None) < 0
+    # the weight-gradient launches refuse job tables cut for a longer LDS stage than the library's ring holds (mode word
+    # bits 8..15, KiB): -8 before anything else; the stage the host uses and "not stated" pass (no jobs: status 0)
+    ok, none, bad = L.HN_MODE_BF16 | L.WGRAD_MAX_STAGE_KB << 8, L.HN_MODE_BF16, L.HN_MODE_BF16 | (L.WGRAD_MAX_STAGE_KB + 16) << 8
+    assert lib.hn_mlp_wgrad_batched(bad, None, 0, None, None) == -8 and lib.hn_mlp_wgrad(bad, None, 0, None, None, None) == -8
+    assert lib.hn_mlp_wgrad_batched_t(L.HN_MODE_F32 | 255 << 8, None, 0, None, None, None) == -8
+    assert lib.hn_mlp_wgrad_batched(ok, None, 0, None, None) == 0 and lib.hn_mlp_wgrad_batched(none, None, 0, None, None) == 0
+    assert lib.hn_mlp_wgrad_batched(L.HN_MODE_BF16_S8 | 16 << 8, None, 0, None, None) == 0      # bits 8.. = the dZ scale there
 
 
 def test_workspace_query_matches_the_host_compiler():
@@ -89,7 +96,8 @@ def test_workspace_query_matches_the_host_compiler():
         assert len(j8) > 0 and set(cover(j8)) == set(cover(j16))
         assert int(((j8["n_nt"] + j8["n_kt"]).astype(np.int64) * (j8["blk1"] - j8["blk0"])).sum()) == \
             int(((j16["n_nt"] + j16["n_kt"]).astype(np.int64) * (j16["blk1"] - j16["blk0"])).sum())
-    assert machine.wgrad_mode_word(L.HN_MODE_BF16) == 1 and machine.wgrad_mode_word(L.HN_MODE_F32) == 0
+    assert machine.wgrad_mode_word(L.HN_MODE_BF16) == 1 | machine.WGRAD_STAGE_KB << 8
+    assert machine.wgrad_mode_word(L.HN_MODE_F32) == 0 | machine.WGRAD_STAGE_KB << 8
     assert machine.wgrad_mode_word(L.HN_MODE_BF16_S8) == 2 | machine.DZ_SCALE_LOG2 << 8
     bad = np.zeros((1, 8), dtype=np.int32); bad[0, 0] = 99
     s_out, m_out = ctypes.c_int64(), ctypes.c_int64()
