@@ -15,19 +15,50 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libhn_hip.so")
+PRODUCT_LIB_PATH = os.path.join(CSRC, "libhn_hip.so")
+# HN_LIB_PATH: run under ANOTHER build of the library (the A/B tools compare prebuilt variants without ever overwriting
+# the product library); build() / needs_build() only ever write the product path
+LIB_PATH = os.environ.get("HN_LIB_PATH") or PRODUCT_LIB_PATH
 SOURCES = ["hn_mlp.hip", "hn_render.hip", "hn_calib.hip"]
+CSRC_HEADERS = ["hn_common.h", "hn_pack.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hn_kernels.h")
 BUILD_MACROS = ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX", "HN_WGRAD_EXP", "HN_WGRAD_BIAS_MFMA", "HN_WGRAD_BLOCK", "HN_WGRAD_STAGES", "HN_WGRAD_MAXSLOT", "HN_WSTREAM_ASYM")     # build-time tuning knobs (A/B experiments)
 
 HN_MODE_F32, HN_MODE_BF16, HN_MODE_BF16_S8 = 0, 1, 2
-# hn_wgrad_kernel's LDS ring (bf16 / fp32 builds): mirrors of the #define defaults in csrc/hn_mlp.hip (the same environment
-# variables drive an A/B build); the host cuts the jobs' stages to fit (machine.Program.wgrad_jobs)
-WGRAD_STAGES = int(os.environ.get("HN_WGRAD_STAGES") or 2)
-WGRAD_MAXSLOT = int(os.environ.get("HN_WGRAD_MAXSLOT") or 8)
+BUILD_CONFIG_KEYS = ("WGRAD_STAGES", "WGRAD_MAXSLOT", "WGRAD_BIAS_MFMA", "CHUNK_UNITS", "WGRAD_BLOCK", "WSTREAM_ASYM",
+                     "BF16_WAVES", "WGRAD_AUX")
+
+
+def _read_build_config(path: str):
+    """The build-time knobs of the library at `path`, or None when there is no library (or one older than ABI 340).
+    Read from the marker string the library carries (`hn_build_config_text`) WITHOUT dlopen-ing it: this runs at import
+    time, and a library that was dlopen-ed once stays mapped under its path — a rebuild that follows (build(force=True))
+    would then never be seen by load().  load() cross-checks the text against hn_build_config() of the mapped code."""
+    import re
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    m = re.search(rb"HN_BUILD_CONFIG:([0-9, ]+);", blob)
+    if m is None:
+        return None
+    vals = [int(x) for x in m.group(1).decode().replace(" ", "").split(",")]
+    return {k: v for k, v in zip(BUILD_CONFIG_KEYS, vals)}
+
+
+# hn_wgrad_kernel's LDS ring, the weight-stream chunk and the bias path of the build: host-side mirrors of build-time
+# macros in csrc/hn_mlp.hip.  They come from the LIBRARY (hn_build_config) whenever one exists — a library prebuilt
+# with other knobs carries its own values; the environment variables (which also drive build()) only stand in before the
+# first build, and load() refuses a library that disagrees with the mirrors in use.
+BUILD_CONFIG = _read_build_config(LIB_PATH)
+_cfg = BUILD_CONFIG or {}
+WGRAD_STAGES = _cfg.get("WGRAD_STAGES", int(os.environ.get("HN_WGRAD_STAGES") or 2))
+WGRAD_MAXSLOT = _cfg.get("WGRAD_MAXSLOT", int(os.environ.get("HN_WGRAD_MAXSLOT") or 8))
+WGRAD_BIAS_MFMA = bool(_cfg.get("WGRAD_BIAS_MFMA", os.environ.get("HN_WGRAD_BIAS_MFMA", "0") not in ("", "0")))
 WGRAD_MAX_STAGE_KB = min(8 * WGRAD_MAXSLOT, 160 // WGRAD_STAGES)
 HN_MAX_SRC, HN_MAX_DST, HN_MAX_SLOTS = 8, 4, 128
-HN_OP_WORDS, HN_CHUNK_UNITS, HN_DSRC_COMPS = 8, int(os.environ.get("HN_CHUNK_UNITS", 32)), 32
+HN_OP_WORDS, HN_CHUNK_UNITS, HN_DSRC_COMPS = 8, _cfg.get("CHUNK_UNITS", int(os.environ.get("HN_CHUNK_UNITS", 32))), 32
 HN_AUXG_MAX = 3
 HN_MAX_COMPS = 32
 
@@ -93,6 +124,14 @@ class HnDraw(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("n", C.c_int64), ("kind", C.c_int32), ("pad", C.c_int32)]
 
 
+class HnPrologue(C.Structure):
+    _fields_ = [("t_rand_draw", C.c_int32), ("n_rays", C.c_int32), ("n", C.c_int32), ("ray_ld", C.c_int32),
+                ("per_ray_bounds", C.c_int32), ("scale", C.c_float),
+                ("origins", C.c_void_p), ("dirs", C.c_void_p), ("lower", C.c_void_p), ("upper", C.c_void_p),
+                ("z_out", C.c_void_p), ("pts_out", C.c_void_p), ("ids_src", C.c_void_p), ("ids_dst", C.c_void_p),
+                ("ids_ld", C.c_int32), ("n_ids", C.c_int32)]
+
+
 class HnCompositeArgs(C.Structure):
     _fields_ = [
         ("variant", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("white_bg", C.c_int32),
@@ -122,9 +161,18 @@ DWJOB_DT = np.dtype([("z_off", "<u8"), ("x_off", "<u8"), ("z_nt", "<i4"), ("x_nt
 DWREDUCE_DT = np.dtype([("batch", "<i4"), ("w_off", "<i4"), ("ld", "<i4"), ("row0", "<i4"), ("col0", "<i4"),
                         ("r_end", "<i4"), ("c_end", "<i4"), ("first", "<i4"), ("count", "<i4")])
 
-EXPORTS = ["hn_version", "hn_abi_sizes", "hn_pack_units", "hn_pack_units_multi", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
+ADAM_RANGE_DT = np.dtype([("start", "<i8"), ("len", "<i4"), ("pad", "<i4")])
+
+
+class HnAdamFuse(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("hyper", C.c_void_p), ("step", C.c_void_p), ("rest", C.c_void_p),
+                ("n_rest", C.c_int32), ("zero_grad", C.c_int32)]
+
+
+EXPORTS = ["hn_version", "hn_abi_sizes", "hn_build_config", "hn_mlp_wgrad_reduce_adam", "hn_render_prologue", "hn_pack_units", "hn_pack_units_multi", "hn_mlp_forward", "hn_mlp_backward", "hn_mlp_wgrad",
            "hn_mlp_wgrad_batched", "hn_mlp_wgrad_batched_t", "hn_mlp_wgrad_reduce", "hn_mlp_workspace_bytes",
-           "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf", "hn_sample_pdf_split",
+           "hn_sample_along_rays", "hn_sample_legacy", "hn_posenc", "hn_composite_forward", "hn_composite_backward", "hn_sample_pdf", "hn_sample_pdf_split", "hn_composite_sample_pdf",
            "hn_embed_gather", "hn_embed_backward", "hn_se3_apply_forward", "hn_se3_apply_backward", "hn_se3_warp_forward", "hn_se3_warp_backward", "hn_generate_rays", "hn_adam_step",
            "hn_mse_loss_forward", "hn_mse_loss_backward", "hn_mse_loss_forward_grad", "hn_depth_index", "hn_random_fill",
            "hn_probe_mfma", "hn_calib_mfma", "hn_calib_stream", "hn_calib_stream_pattern", "hn_calib_ring"]
@@ -144,19 +192,20 @@ def hipcc_path() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(PRODUCT_LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "hn_common.h"), HEADER]
+    t = os.path.getmtime(PRODUCT_LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in CSRC_HEADERS] + [HEADER]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into csrc/libhn_hip.so (cross-compiles without a GPU)."""
     if not force and not needs_build():
-        return LIB_PATH
+        return PRODUCT_LIB_PATH
+    out = os.environ.get("HN_BUILD_OUT") or PRODUCT_LIB_PATH      # HN_BUILD_OUT: an A/B variant beside the product library
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
-           "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
     for macro in BUILD_MACROS:          # build-time tuning knobs (A/B experiments)
         if os.environ.get(macro):
             cmd.insert(1, f"-D{macro}={os.environ[macro]}")
@@ -165,7 +214,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise HnError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
     if verbose:
         print(res.stdout + res.stderr)
-    return LIB_PATH
+    return out
 
 
 def build_id() -> dict:
@@ -174,7 +223,7 @@ def build_id() -> dict:
     traffic summaries with it, and bench.py only quotes a summary whose source hash equals the running build's."""
     import hashlib
     h = hashlib.sha256()
-    for d in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "hn_common.h"), HEADER]:
+    for d in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in CSRC_HEADERS] + [HEADER]:
         with open(d, "rb") as f:
             h.update(f.read())
     for macro in BUILD_MACROS:
@@ -183,7 +232,13 @@ def build_id() -> dict:
     if os.path.exists(LIB_PATH):
         with open(LIB_PATH, "rb") as f:
             lib = hashlib.sha256(f.read()).hexdigest()[:16]
-    return {"kernel_src_sha256": h.hexdigest()[:16], "lib_sha256": lib}
+    ident = {"kernel_src_sha256": h.hexdigest()[:16], "lib_sha256": lib}
+    if LIB_PATH != PRODUCT_LIB_PATH:      # an A/B variant: the source hash above describes the tree, not this library
+        ident["lib_path_override"] = LIB_PATH
+        ident["kernel_src_sha256"] = "override:" + (lib or "?")
+    if BUILD_CONFIG is not None:
+        ident["build_config"] = dict(BUILD_CONFIG)
+    return ident
 
 
 def load():
@@ -200,6 +255,17 @@ def load():
         if not hasattr(lib, name):
             raise HnError(f"{LIB_PATH} does not export {name}")
         getattr(lib, name).restype = C.c_int
+    # the host tables in use were cut for the mirrors above: a library built with other knobs must not run under them
+    # (e.g. bias records whose slab tiles a bias-by-MFMA build never writes: garbage gradients, no error)
+    buf = (C.c_int32 * len(BUILD_CONFIG_KEYS))()
+    n_cfg = lib.hn_build_config(buf, len(BUILD_CONFIG_KEYS))
+    now = {k: int(buf[i]) for i, k in enumerate(BUILD_CONFIG_KEYS[:n_cfg])}
+    mine = {"WGRAD_STAGES": WGRAD_STAGES, "WGRAD_MAXSLOT": WGRAD_MAXSLOT, "WGRAD_BIAS_MFMA": int(WGRAD_BIAS_MFMA),
+            "CHUNK_UNITS": HN_CHUNK_UNITS}
+    bad = {k: (v, now.get(k)) for k, v in mine.items() if now.get(k) != v}
+    if bad:
+        raise HnError(f"{LIB_PATH} was built with other tuning knobs than the host tables assume (mirror, library): {bad}; "
+                      "re-import hypernerf_torch_amd after building, or unset the HN_* build variables")
     _lib = lib
     return lib
 

@@ -97,7 +97,14 @@ class ParamArena:
         return arena, offs
 
     # ---- training-loop side -----------------------------------------------------------------------
+    def _complete_grad(self):
+        """An optimizer may be holding this arena's reduce launch back (optim.ArenaAdam(fuse_reduce=True)): whoever needs
+        the complete gradient buffer first runs it."""
+        from . import machine
+        machine.flush_pending_reduce(self.grad)
+
     def zero_grad(self):
+        self._complete_grad()
         self.grad.zero_()
 
     def all_reduce_sum(self, group=None, force: bool = False):
@@ -105,10 +112,12 @@ class ParamArena:
         consumer (ArenaAdam's grad_scale: no separate division launch).  `force`: issue the collective even in a
         one-rank group (RCCL runs it as a copy) — what lets a one-GPU box exercise the captured all-reduce."""
         if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
+            self._complete_grad()
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
     def all_reduce_mean(self, group=None):
         """Average the gradient buffer across ranks: one all-reduce, in place (for optimizers without grad_scale)."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            self._complete_grad()
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
             self.grad.div_(dist.get_world_size(group))

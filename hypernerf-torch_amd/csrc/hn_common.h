@@ -41,7 +41,12 @@ HN_DEV void hn_timeline_begin(uint64_t* t) {
   }
 }
 HN_DEV void hn_timeline_end(uint64_t* t) {
-  if (t == nullptr || threadIdx.x != 0) return;
+  if (t == nullptr) return;
+  // every wave of the workgroup has finished its stores before thread 0 stamps the end (without the barrier waves 1-7
+  // could still be writing their tiles when wave 0 of the LAST workgroup reads the clock: durations under-reported).
+  // `t` is a kernel argument and every call site is workgroup-uniform, so the barrier is too.
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   const uint64_t now = wall_clock64();
   if (atomicAdd(reinterpret_cast<unsigned*>(t + 3), 1u) == gridDim.x - 1) {
     const uint64_t start = atomicAdd(reinterpret_cast<unsigned long long*>(t), 0ull);
@@ -51,6 +56,43 @@ HN_DEV void hn_timeline_end(uint64_t* t) {
     atomicAdd(reinterpret_cast<unsigned long long*>(t + 5), 1ull);
     atomicExch(reinterpret_cast<unsigned*>(t + 2), 0u);
     atomicExch(reinterpret_cast<unsigned*>(t + 3), 0u);
+  }
+}
+
+// torch.optim.Adam's update of ONE element (utils.get_optimizer's default, reference utils/__init__.py:23-41), shared by
+// hn_adam_kernel and the reduce launch that applies it on the fly (hn_mlp_wgrad_reduce_adam): the same operations in the
+// same order, so both paths produce bit-identical parameters.
+struct HnAdamConsts {
+  float beta1, beta2, eps, weight_decay, gscale, step_size, inv_sqrt_bc2, t;
+};
+HN_DEV HnAdamConsts hn_adam_consts(const float* __restrict__ hyper, const float* step) {
+  // hyper-parameters are read from device memory: a captured launch (HIP graph) follows later changes of lr etc.
+  HnAdamConsts c;
+  const float lr = hyper[0];
+  c.beta1 = hyper[1]; c.beta2 = hyper[2]; c.eps = hyper[3]; c.weight_decay = hyper[4];
+  c.gscale = hyper[5];      // 1 / world size after a SUM all-reduce (1 otherwise)
+  c.t = step[0] + 1.0f;     // step[0] = number of updates done so far; this launch is update t
+  const float bc1 = 1.0f - powf(c.beta1, c.t), bc2 = 1.0f - powf(c.beta2, c.t);
+  c.step_size = lr / bc1;
+  c.inv_sqrt_bc2 = rsqrtf(bc2);
+  return c;
+}
+HN_DEV void hn_adam_update(const HnAdamConsts& c, float& p, float g, float& m, float& v) {
+  const float gk = g * c.gscale + c.weight_decay * p;
+  m = c.beta1 * m + (1.0f - c.beta1) * gk;
+  v = c.beta2 * v + (1.0f - c.beta2) * gk * gk;
+  p -= c.step_size * m / (sqrtf(v) * c.inv_sqrt_bc2 + c.eps);
+}
+// the block that finishes LAST (ticket counter in step[1]) stores t and re-arms the ticket — by then every block has read
+// the old value, so no second launch is needed to advance the counter.  Call from ALL threads of the block.
+HN_DEV void hn_adam_ticket(float* step, float t) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* ticket = reinterpret_cast<unsigned*>(step) + 1;
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      step[0] = t;
+      *ticket = 0u;
+    }
   }
 }
 

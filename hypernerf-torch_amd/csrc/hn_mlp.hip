@@ -1087,59 +1087,15 @@ __global__ __launch_bounds__(ModeT<BF16>::WAVES * 64, BF16 ? 2 : 1) void hn_mlp_
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
-template <bool BF16>
-HN_DEV void hn_pack_one(const HnPackUnit* units, int n_units, const float* const* ptrs, char* out,
-                        const HnPackBias* bias, int n_bias, float* bias_out, int wid) {
-  const int lane = threadIdx.x & 63;
-  const int row = lane & 31, h = lane >> 5;
-  if (wid < n_units) {
-    const HnPackUnit u = units[wid];
-    const float* W = u.w_id >= 0 ? ptrs[u.w_id] : nullptr;
-    auto fetch = [&](int k) -> float {
-      int sr, sc;
-      if (u.transposed) { sr = u.r0 + k; sc = u.c0 + row; }
-      else { sr = u.r0 + row; sc = u.c0 + k; }
-      if (W == nullptr || sr < 0 || sc < 0 || sr >= u.r_end || sc >= u.c_end) return 0.0f;
-      return W[(size_t)sr * u.ld + sc];
-    };
-    char* dst = out + (size_t)wid * 1024 + lane * 16;
-    if (BF16) {
-      bf16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (__bf16)fetch(u.k0 + hn_pi16(h, j));
-      *reinterpret_cast<bf16x8*>(dst) = o;
-    } else {
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = fetch(hn_rho(u.k0 + e, h));
-      *reinterpret_cast<f32x4*>(dst) = o;
-    }
-  } else if (wid - n_units < n_bias) {
-    const HnPackBias b = bias[wid - n_units];
-    const float* src = b.w_id >= 0 ? ptrs[b.w_id] : nullptr;
-    for (int i = lane; i < b.len; i += 64) bias_out[b.off + i] = (src != nullptr && i < b.n) ? src[i] : 0.0f;
-  }
-}
+#include "hn_pack.h"
 template <bool BF16>
 __global__ void hn_pack_kernel(const HnPackUnit* units, int n_units, const float* const* ptrs, char* out,
                                const HnPackBias* bias, int n_bias, float* bias_out) {
   hn_pack_one<BF16>(units, n_units, ptrs, out, bias, n_bias, bias_out, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 }
-// several programs' streams in ONE launch (a training step packs three: each launch costs more in dispatch than in work)
-struct HnPackTable {
-  HnPackJob j[HN_MAX_PACK_JOBS];
-  int first_block[HN_MAX_PACK_JOBS + 1];
-  int n;
-};
 template <bool BF16>
 __global__ void hn_pack_multi_kernel(const HnPackTable tab) {
-  int k = 0;
-#pragma unroll
-  for (int i = 1; i < HN_MAX_PACK_JOBS; ++i)
-    if (i < tab.n && (int)blockIdx.x >= tab.first_block[i]) k = i;
-  const HnPackJob jb = tab.j[k];
-  const int wid = ((int)blockIdx.x - tab.first_block[k]) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  hn_pack_one<BF16>(jb.units, jb.n_units, jb.ptrs, (char*)jb.wstream, jb.bias, jb.n_bias, jb.bias_out, wid);
+  hn_pack_block<BF16>(tab, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1832,10 +1788,31 @@ extern "C" int hn_abi_sizes(int32_t* out, int n) {
   return 8;
 }
 
+// Build-time tuning knobs this library was compiled with, in the order HN_BUILD_CONFIG_* of include/hn_kernels.h.  The
+// host mirrors (hypernerf_torch_amd/_lib.py) are READ from here at load time: a library prebuilt with other knobs (the
+// A/B tools) can no longer run under host tables cut for the defaults.
+#define HN_STR2(x) #x
+#define HN_STR(x) HN_STR2(x)
+// the same values as text inside the binary: a host that must know them BEFORE it may dlopen the library (Python's import
+// of the package, which a rebuild can follow) finds them by scanning the file for the marker
+extern "C" __attribute__((used)) const char hn_build_config_text[] =
+    "HN_BUILD_CONFIG:" HN_STR(HN_WGRAD_STAGES) "," HN_STR(HN_WGRAD_MAXSLOT) "," HN_STR(HN_WGRAD_BIAS_MFMA) "," HN_STR(HN_CHUNK_UNITS) ","
+    HN_STR(HN_WGRAD_BLOCK) "," HN_STR(HN_WSTREAM_ASYM) "," HN_STR(HN_BF16_WAVES) "," HN_STR(HN_WGRAD_AUX) ";";
+extern "C" int hn_build_config(int32_t* out, int n) {
+  const int32_t v[HN_BUILD_CONFIG_N] = {HN_WGRAD_STAGES, HN_WGRAD_MAXSLOT, HN_WGRAD_BIAS_MFMA, HN_CHUNK_UNITS,
+                                        HN_WGRAD_BLOCK,  HN_WSTREAM_ASYM,  HN_BF16_WAVES,      HN_WGRAD_AUX};
+  for (int i = 0; i < n && i < HN_BUILD_CONFIG_N; ++i) out[i] = v[i];
+  return HN_BUILD_CONFIG_N;
+}
+
 static void hn_allow_big_lds() {
-  static bool done = false;
-  if (done) return;
-  done = true;
+  // per device: hipFuncSetAttribute applies to the device that is current at the call (a process driving several GPUs
+  // must raise the limit on each of them before its first launch there)
+  static bool done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (done[dev]) return;
+  done[dev] = true;
   const int big = 160 * 1024;
 #define HN_BIG(k) (void)hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, big)
   HN_BIG((hn_mlp_fwd_kernel<true, 2, false, true>)); HN_BIG((hn_mlp_fwd_kernel<true, 2, false, false>));
@@ -1872,21 +1849,10 @@ extern "C" int hn_pack_units(int mode, const HnPackUnit* units, int n_units, con
 }
 
 extern "C" int hn_pack_units_multi(int mode, const HnPackJob* jobs, int n_jobs, hnStream_t stream) {
-  if (n_jobs < 0 || n_jobs > HN_MAX_PACK_JOBS) return -1;
-  if (n_jobs == 0) return 0;
-  if (jobs == nullptr) return -3;
   HnPackTable tab = {};
   int blocks = 0;
-  for (int i = 0; i < n_jobs; ++i) {
-    if (jobs[i].n_units < 0 || jobs[i].n_bias < 0) return -1;
-    if (jobs[i].n_units > 0 && (jobs[i].units == nullptr || jobs[i].ptrs == nullptr || jobs[i].wstream == nullptr)) return -3;
-    if (jobs[i].n_bias > 0 && (jobs[i].bias == nullptr || jobs[i].bias_out == nullptr || jobs[i].ptrs == nullptr)) return -3;
-    tab.j[i] = jobs[i];
-    tab.first_block[i] = blocks;
-    blocks += (jobs[i].n_units + jobs[i].n_bias + 3) / 4;
-  }
-  tab.first_block[n_jobs] = blocks;
-  tab.n = n_jobs;
+  const int rc = hn_pack_table_fill(jobs, n_jobs, tab, blocks);
+  if (rc != 0) return rc;
   if (blocks == 0) return 0;
   if (mode == HN_MODE_BF16 || mode == HN_MODE_BF16_S8)
     hipLaunchKernelGGL(hn_pack_multi_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab);
@@ -2033,10 +1999,49 @@ struct HnDwReduceTable {
   float* partials[HN_MAX_WGRAD_BATCH];
   float* grads[HN_MAX_WGRAD_BATCH];
 };
-template <bool S8>
-__global__ __launch_bounds__(256) void hn_wgrad_reduce_kernel(const HnDwReduceTile* __restrict__ tiles, int n_tiles,
+// ADAM = true (hn_mlp_wgrad_reduce_adam): the launch that completes the gradient also CONSUMES it — a workgroup that has
+// summed its destination tile applies torch.optim.Adam's update to those elements in registers and writes p / m / v (the
+// gradient buffer is read once more — whatever other launches added to it — and left zeroed): no gradient write-back, no
+// second pass over the arena.  Elements no tile / bias record / table row covers (`rest`: parameters outside the launch's
+// programs, alignment gaps) are updated by extra workgroups at the end of the grid, so every element of the arena is
+// updated exactly once (the host proves the partition: machine.adam_rest_ranges, tests/test_host_api.py).
+struct HnAdamFuseDev {
+  float* p; float* g; float* m; float* v;
+  const float* hyper; float* step;
+  const HnAdamRange* rest;
+  int n_rest, zero_grad;
+};
+#ifndef HN_REDUCE_SPLIT
+#define HN_REDUCE_SPLIT 1      /* parts a destination tile's slab list is summed in (workgroup = SPLIT x 256 threads) */
+#endif
+template <bool S8, bool ADAM>
+__global__ __launch_bounds__(256 * HN_REDUCE_SPLIT) void hn_wgrad_reduce_kernel(const HnDwReduceTile* __restrict__ tiles, int n_tiles,
                                                               const uint32_t* __restrict__ list, const HnDwReduceTable tab,
-                                                              const HnEmbedReduce em) {
+                                                              const HnEmbedReduce em, const HnAdamFuseDev A) {
+  __shared__ HnAdamConsts s_k;
+  HnAdamConsts K = {};
+  if (ADAM) {
+    // one thread per block pays the bias-correction arithmetic (two powf, an rsqrtf); every block reads step[0] before it
+    // does anything else, the block that finishes last advances it (hn_adam_ticket)
+    if (threadIdx.x == 0) s_k = hn_adam_consts(A.hyper, A.step);
+    __syncthreads();
+    K = s_k;
+  }
+  // the gradient element at `G + off` is complete with `add`: plain path adds it (one writer per element), ADAM path
+  // updates the parameter behind it
+  auto finish = [&](float* Gp, float add) {
+    if (ADAM) {
+      const size_t i = (size_t)(Gp - A.g);
+      const float g = *Gp + add;
+      hn_adam_update(K, A.p[i], g, A.m[i], A.v[i]);
+      *Gp = A.zero_grad ? 0.0f : g;
+    } else {
+      atomicAdd(Gp, add);
+    }
+  };
+  // (with HN_REDUCE_SPLIT > 1 the table-row, bias and rest paths run on the first 256 threads; every barrier below is
+  // reached by all threads of the workgroup)
+  const bool first256 = threadIdx.x < 256;
   if ((int)blockIdx.x < em.rows) {
     // one table row (these workgroups come FIRST in the grid: they are the long ones).  Thread x takes rays x, x + 256,
     // ... of every program in turn and, for the rays that carry this row, their blocks in order (a fixed order; four index
@@ -2048,7 +2053,7 @@ __global__ __launch_bounds__(256) void hn_wgrad_reduce_kernel(const HnDwReduceTi
     float acc[32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) acc[c] = 0.0f;
-    for (int sIdx = 0; sIdx < em.n_src; ++sIdx) {
+    for (int sIdx = 0; first256 && sIdx < em.n_src; ++sIdx) {
       const float* P = em.partial[sIdx];
       const int64_t* idx = em.idx[sIdx];
       const int nb = em.n_blocks[sIdx], spr = em.samples_per_ray[sIdx];
@@ -2077,78 +2082,140 @@ __global__ __launch_bounds__(256) void hn_wgrad_reduce_kernel(const HnDwReduceTi
         float v = acc[c];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-        if (lane == 0) red[wave][c] = v;
+        if (lane == 0 && wave < 4) red[wave][c] = v;
       }
     }
     __syncthreads();
     const int c = threadIdx.x;
-    if (c < em.dim && ((em.col_mask >> c) & 1u))
-      em.grad[row * em.dim + c] += ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
-    return;
-  }
-  const HnDwReduceTile t = tiles[blockIdx.x - em.rows];
-  if (t.ld == 0) {
-    // bias record: col0 = dZ tiles of the rectangle; thread x = row 32 (x >> 5) + (x & 31) of it.  A job's bias slab
-    // holds 32 floats per dZ tile, rows in natural order
-    const int i_n = threadIdx.x >> 5, rr = threadIdx.x & 31;
-    const int row = t.row0 + 32 * i_n + rr;
-    if (i_n >= t.col0 || row < 0 || row >= t.r_end) return;
-    const int off = i_n * 32 + rr;
-    float sb = 0.0f;
-    for (int k = 0; k < t.count; ++k) {
-      const uint32_t e = list[t.first + k];
-      float* P = tab.partials[0];
-#pragma unroll
-      for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
-        if ((int)(e >> 28) == i) P = tab.partials[i];
-      sb += P[(size_t)(e & 0x0fffffffu) * 1024 + off];
+    if (c < em.dim && ((em.col_mask >> c) & 1u)) {
+      const float tot = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+      if (ADAM) finish(em.grad + row * em.dim + c, tot);
+      else em.grad[row * em.dim + c] += tot;
     }
-    float* Gb = tab.grads[0];
+  } else if ((int)blockIdx.x < em.rows + n_tiles) {
+    const HnDwReduceTile t = tiles[blockIdx.x - em.rows];
+    if (t.ld == 0) {
+      // bias record: col0 = dZ tiles of the rectangle; thread x = row 32 (x >> 5) + (x & 31) of it.  A job's bias slab
+      // holds 32 floats per dZ tile, rows in natural order
+      const int i_n = threadIdx.x >> 5, rr = threadIdx.x & 31;
+      const int row = t.row0 + 32 * i_n + rr;
+      if (first256 && !(i_n >= t.col0 || row < 0 || row >= t.r_end)) {
+        const int off = i_n * 32 + rr;
+        float sb = 0.0f;
+        for (int k = 0; k < t.count; ++k) {
+          const uint32_t e = list[t.first + k];
+          float* P = tab.partials[0];
 #pragma unroll
-    for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
-      if (t.batch == i) Gb = tab.grads[i];
-    atomicAdd(Gb + t.w_off + row, sb);
-    return;
-  }
-  // a slab tile is [register quad q4 (4)][lane (64)][4 floats]; thread x sums the float4 at x: registers 4 q4 .. 4 q4 + 3
-  // of one lane.  The slab loads are issued eight at a time (a dependent load-add chain pays one memory latency per slab).
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < t.count; k0 += 8) {
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (k0 + u < t.count) {
-        const uint32_t e = list[t.first + k0 + u];
-        float* P = tab.partials[0];
+          for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
+            if ((int)(e >> 28) == i) P = tab.partials[i];
+          sb += P[(size_t)(e & 0x0fffffffu) * 1024 + off];
+        }
+        float* Gb = tab.grads[0];
 #pragma unroll
         for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
-          if ((int)(e >> 28) == i) P = tab.partials[i];
-        v[u] = *reinterpret_cast<const f32x4*>(P + (size_t)(e & 0x0fffffffu) * 1024 + threadIdx.x * 4);
+          if (t.batch == i) Gb = tab.grads[i];
+        finish(Gb + t.w_off + row, sb);
+      }
+    } else {
+      // a slab tile is [register quad q4 (4)][lane (64)][4 floats]; thread x sums the float4 at x: registers 4 q4 .. 4 q4 + 3
+      // of one lane.  The slab loads are issued eight at a time (a dependent load-add chain pays one memory latency per
+      // slab); with HN_REDUCE_SPLIT > 1 the workgroup has SPLIT x 256 threads and part j sums slabs j, j + SPLIT, ... —
+      // SPLIT times the bytes in flight per tile, 1 / SPLIT of the chain — and part 0 adds the parts' sums in part order
+      // (a fixed order: the gradient stays bit-reproducible).
+      // With SPLIT > 1 every part ALSO finishes 4 / SPLIT of the thread's four elements (the parts' sums meet in LDS), so
+      // the tail of a tile — the read-modify-write of the gradient or, ADAM, of p / m / v — is one element per thread
+      // at SPLIT 4; its loads are issued BEFORE the slab loop (their latency hides behind it).
+      constexpr int SP = HN_REDUCE_SPLIT, EPT = 4 / SP;      // elements a thread finishes
+      static_assert(SP == 1 || SP == 2 || SP == 4, "HN_REDUCE_SPLIT");
+      __shared__ f32x4 s_part[SP > 1 ? SP * 256 : 1];
+      const int part = threadIdx.x >> 8, x = threadIdx.x & 255;
+      float* G = tab.grads[0];
+#pragma unroll
+      for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
+        if (t.batch == i) G = tab.grads[i];
+      G += t.w_off;
+      const int q4 = x >> 6, lane = x & 63, h = lane >> 5, c = lane & 31;
+      const int col = t.col0 + (S8 ? hn_dw8_feature(c) : c);
+      const bool col_ok = col >= 0 && col < t.c_end;
+      float* gp[EPT];
+      float g4[EPT], p4[EPT], m4[EPT], v4[EPT];
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) {
+        const int e = part * EPT + j;
+        const int rr = hn_rho(4 * q4 + e, h);
+        const int row = t.row0 + (S8 ? hn_dw8_feature(rr) : rr);
+        gp[j] = (col_ok && row >= 0 && row < t.r_end) ? G + (size_t)row * t.ld + col : nullptr;
+        if (ADAM && gp[j] != nullptr) {
+          const size_t i = (size_t)(gp[j] - A.g);
+          g4[j] = *gp[j]; p4[j] = A.p[i]; m4[j] = A.m[i]; v4[j] = A.v[i];
+        }
+      }
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int k0 = part; k0 < t.count; k0 += 8 * SP) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int k = k0 + u * SP;
+          if (k < t.count) {
+            const uint32_t e = list[t.first + k];
+            float* P = tab.partials[0];
+#pragma unroll
+            for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
+              if ((int)(e >> 28) == i) P = tab.partials[i];
+            v[u] = *reinterpret_cast<const f32x4*>(P + (size_t)(e & 0x0fffffffu) * 1024 + x * 4);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];          // fixed order: slab k0, k0 + SPLIT, ...
+      }
+      float tot[EPT];
+      if (SP > 1) {
+        s_part[part * 256 + x] = s;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+          const int e = part * EPT + j;
+          float a = s_part[x][e];
+#pragma unroll
+          for (int q = 1; q < SP; ++q) a += s_part[q * 256 + x][e];      // part order: fixed
+          tot[j] = a;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) tot[j] = s[j];
+      }
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) {
+        if (gp[j] == nullptr) continue;
+        if (ADAM) {
+          g4[j] += tot[j];
+          hn_adam_update(K, p4[j], g4[j], m4[j], v4[j]);
+        } else {
+          atomicAdd(gp[j], tot[j]);
+        }
+      }
+      if (ADAM) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+          if (gp[j] == nullptr) continue;
+          const size_t i = (size_t)(gp[j] - A.g);
+          A.p[i] = p4[j]; A.m[i] = m4[j]; A.v[i] = v4[j];
+          *gp[j] = A.zero_grad ? 0.0f : g4[j];
+        }
       }
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];          // fixed order: slab k0, k0 + 1, ...
+  } else if (ADAM) {
+    // the rest of the arena: elements nothing in this launch adds to (their gradient is whatever the buffer holds)
+    const HnAdamRange r = A.rest[blockIdx.x - em.rows - n_tiles];
+    for (int i = threadIdx.x; first256 && i < r.len; i += 256) finish(A.g + r.start + i, 0.0f);
   }
-  float* G = tab.grads[0];
-#pragma unroll
-  for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
-    if (t.batch == i) G = tab.grads[i];
-  G += t.w_off;
-  const int q4 = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-  const int col = t.col0 + (S8 ? hn_dw8_feature(c) : c);
-  if (col < 0 || col >= t.c_end) return;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int rr = hn_rho(4 * q4 + e, h);
-    const int row = t.row0 + (S8 ? hn_dw8_feature(rr) : rr);
-    if (row >= 0 && row < t.r_end) atomicAdd(G + (size_t)row * t.ld + col, s[e]);
-  }
+  if (ADAM) hn_adam_ticket(A.step, K.t);
 }
 
-extern "C" int hn_mlp_wgrad_reduce(int mode, const HnDwReduceTile* tiles, int n_tiles, const uint32_t* list,
-                                   const HnDwBatch* batches, int n_batches, const HnEmbedReduce* embed,
-                                   hnStream_t stream) {
+static int hn_launch_reduce(int mode, const HnDwReduceTile* tiles, int n_tiles, const uint32_t* list,
+                            const HnDwBatch* batches, int n_batches, const HnEmbedReduce* embed, const HnAdamFuse* adam,
+                            hnStream_t stream) {
   if (n_tiles < 0 || n_batches < 0 || n_batches > HN_MAX_WGRAD_BATCH) return -1;
   HnEmbedReduce em = {};
   if (embed != nullptr) {
@@ -2159,26 +2226,53 @@ extern "C" int hn_mlp_wgrad_reduce(int mode, const HnDwReduceTile* tiles, int n_
       if (em.partial[i] == nullptr || em.idx[i] == nullptr || em.n_blocks[i] < 0 || em.samples_per_ray[i] < 32) return -3;
     if (em.n_src == 0) em.rows = 0;
   }
-  const int total = n_tiles + em.rows;
+  HnAdamFuseDev A = {};
+  if (adam != nullptr) {
+    if (adam->n < 1 || adam->n_rest < 0) return -2;
+    if (adam->params == nullptr || adam->grads == nullptr || adam->exp_avg == nullptr || adam->exp_avg_sq == nullptr ||
+        adam->hyper == nullptr || adam->step == nullptr || (adam->n_rest > 0 && adam->rest == nullptr))
+      return -3;
+    A.p = adam->params; A.g = adam->grads; A.m = adam->exp_avg; A.v = adam->exp_avg_sq;
+    A.hyper = adam->hyper; A.step = adam->step; A.rest = adam->rest; A.n_rest = adam->n_rest; A.zero_grad = adam->zero_grad;
+    // every destination of the launch must lie in the arena the optimizer steps
+    if (em.rows > 0 && (em.grad < adam->grads || em.grad + (size_t)em.rows * em.dim > adam->grads + adam->n)) return -9;
+  }
+  const int total = n_tiles + em.rows + A.n_rest;
   if (total == 0) return 0;
   if (n_tiles > 0 && (tiles == nullptr || list == nullptr || batches == nullptr || n_batches < 1)) return -3;
   HnDwReduceTable tab = {};
   for (int i = 0; i < n_batches; ++i) {
     if (n_tiles > 0 && (batches[i].partials == nullptr || batches[i].grads == nullptr)) return -3;
+    if (adam != nullptr && batches[i].grads != adam->grads) return -9;
     tab.partials[i] = batches[i].partials;
     tab.grads[i] = batches[i].grads;
   }
   const int m = mode & 255;
-  if (m == HN_MODE_BF16_S8)
-    hipLaunchKernelGGL(hn_wgrad_reduce_kernel<true>, dim3(total), dim3(256), 0, (hipStream_t)stream, tiles, n_tiles, list,
-                       tab, em);
-  else if (m == HN_MODE_BF16 || m == HN_MODE_F32)
-    hipLaunchKernelGGL(hn_wgrad_reduce_kernel<false>, dim3(total), dim3(256), 0, (hipStream_t)stream, tiles, n_tiles, list,
-                       tab, em);
-  else
+  const dim3 grid(total), blk(256 * HN_REDUCE_SPLIT);
+  if (m == HN_MODE_BF16_S8) {
+    if (adam != nullptr) hipLaunchKernelGGL((hn_wgrad_reduce_kernel<true, true>), grid, blk, 0, (hipStream_t)stream, tiles, n_tiles, list, tab, em, A);
+    else hipLaunchKernelGGL((hn_wgrad_reduce_kernel<true, false>), grid, blk, 0, (hipStream_t)stream, tiles, n_tiles, list, tab, em, A);
+  } else if (m == HN_MODE_BF16 || m == HN_MODE_F32) {
+    if (adam != nullptr) hipLaunchKernelGGL((hn_wgrad_reduce_kernel<false, true>), grid, blk, 0, (hipStream_t)stream, tiles, n_tiles, list, tab, em, A);
+    else hipLaunchKernelGGL((hn_wgrad_reduce_kernel<false, false>), grid, blk, 0, (hipStream_t)stream, tiles, n_tiles, list, tab, em, A);
+  } else {
     return -2;
+  }
   HN_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int hn_mlp_wgrad_reduce(int mode, const HnDwReduceTile* tiles, int n_tiles, const uint32_t* list,
+                                   const HnDwBatch* batches, int n_batches, const HnEmbedReduce* embed,
+                                   hnStream_t stream) {
+  return hn_launch_reduce(mode, tiles, n_tiles, list, batches, n_batches, embed, nullptr, stream);
+}
+
+extern "C" int hn_mlp_wgrad_reduce_adam(int mode, const HnDwReduceTile* tiles, int n_tiles, const uint32_t* list,
+                                        const HnDwBatch* batches, int n_batches, const HnEmbedReduce* embed,
+                                        const HnAdamFuse* adam, hnStream_t stream) {
+  if (adam == nullptr) return -3;
+  return hn_launch_reduce(mode, tiles, n_tiles, list, batches, n_batches, embed, adam, stream);
 }
 
 #ifdef HN_PROF

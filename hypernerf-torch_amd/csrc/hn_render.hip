@@ -3,6 +3,7 @@
 // embedding gather / gradient.  One wavefront (64 lanes) per ray; all HBM accesses are coalesced
 // rows of the (B,S,*) arrays.  These kernels are HBM-bound (tens of bytes per sample).
 #include "hn_common.h"
+#include "hn_pack.h"
 
 // ------------------------------------------------------------------------------------------------
 // wave64 scans
@@ -188,11 +189,10 @@ HN_DEV HnPartRow hn_part_row(const HnCompositeArgs& a, int ray, size_t row, int 
   return HnPartRow{(size_t)ray * (a.n_samples - a.split) + (k - a.split), true};
 }
 
+// One ray's compositing on one wave.  `w_lds` (forward only, optional): the ray's weights are ALSO left in LDS there — the
+// inverse-CDF sampler of the same wave reads them from it (hn_composite_pdf_kernel).
 template <bool BACKWARD>
-__global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ray >= a.n_rays) return;
+HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float* w_lds) {
   const int S = a.n_samples;
   const int nseg = (S + 63) / 64;
   const size_t row = (size_t)ray * S;
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
       if (!BACKWARD) {
         if (in) {
           a.out_weights[row + s] = w;
+          if (w_lds != nullptr) w_lds[s] = w;
           const float* c = (pr.second ? a.rgb1 : a.rgb) + pr.row * 3;
           s_r += w * c[0];
           s_g += w * c[1];
@@ -359,6 +360,13 @@ __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs
     }
   }
 }
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.n_rays) return;
+  hn_composite_ray<BACKWARD>(a, ray, lane, nullptr);
+}
 
 static int hn_check_comp(const HnCompositeArgs* a, bool bwd) {
   if (a == nullptr) return -1;
@@ -440,30 +448,31 @@ extern "C" int hn_depth_index(const float* weights, const float* z, int n_rays, 
 constexpr int HN_PDF_MAXC = 256;   // max coarse samples
 constexpr int HN_PDF_MAXT = 512;   // max coarse + fine
 
+// One ray's inverse-CDF sampling + merge on one wave.  `wr`: the ray's bin weights (global memory, or LDS when the same
+// wave has just composited them); cdf / bins / srt / sidx: this wave's LDS scratch.
+struct HnPdfArgs {
+  const float* weights; int w_ld;
+  const float* bins_in; int nb;
+  const float* z; int nc;
+  const float* u; const float* origins; const float* dirs; int ray_ld, n_rays, nf;
+  float* z_all; float* pts; int64_t* inds; float* z_samples; int32_t* perm; float* pts_new;
+};
 template <bool PERM>
-__global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const float* __restrict__ weights, int w_ld,
-                                                            const float* __restrict__ bins_in, int nb,
-                                                            const float* __restrict__ z, int nc,
-                                                            const float* __restrict__ u, const float* __restrict__ origins,
-                                                            const float* __restrict__ dirs, int ray_ld, int n_rays,
-                                                            int nf, float* __restrict__ z_all,
-                                                            float* __restrict__ pts, int64_t* __restrict__ inds,
-                                                            float* __restrict__ z_samples, int32_t* __restrict__ perm,
-                                                            float* __restrict__ pts_new) {
-  __shared__ float s_cdf[4][HN_PDF_MAXC];
-  __shared__ float s_bins[4][HN_PDF_MAXC];
-  __shared__ float s_sort[4][HN_PDF_MAXT];
-  __shared__ int s_idx[PERM ? 4 : 1][PERM ? HN_PDF_MAXT : 1];   // the sort's payload: position in cat(z, z_samples)
-  int* sidx = s_idx[PERM ? (threadIdx.x >> 6) : 0];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int ray = blockIdx.x * 4 + wv;
-  if (ray >= n_rays) return;
-  float* cdf = s_cdf[wv];
-  float* bins = s_bins[wv];
-  float* srt = s_sort[wv];
+HN_DEV void hn_pdf_ray(const HnPdfArgs& q, int ray, int lane, const float* wr, float* cdf, float* bins, float* srt, int* sidx) {
+  const float* __restrict__ bins_in = q.bins_in;
+  const float* __restrict__ z = q.z;
+  const float* __restrict__ u = q.u;
+  const float* __restrict__ origins = q.origins;
+  const float* __restrict__ dirs = q.dirs;
+  float* __restrict__ z_all = q.z_all;
+  float* __restrict__ pts = q.pts;
+  int64_t* __restrict__ inds = q.inds;
+  float* __restrict__ z_samples = q.z_samples;
+  int32_t* __restrict__ perm = q.perm;
+  float* __restrict__ pts_new = q.pts_new;
+  const int nb = q.nb, nc = q.nc, nf = q.nf, ray_ld = q.ray_ld;
   const int ncdf = nb + 1;     // cdf entries = bin edges
   const float* zr = z != nullptr ? z + (size_t)ray * nc : nullptr;
-  const float* wr = weights + (size_t)ray * w_ld;
   if (bins_in != nullptr) {
     for (int i = lane; i < ncdf; i += 64) bins[i] = bins_in[(size_t)ray * ncdf + i];
   } else {
@@ -586,28 +595,81 @@ __global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const float* __restr
     }
   }
 }
+template <bool PERM>
+__global__ __launch_bounds__(256) void hn_sample_pdf_kernel(const HnPdfArgs q) {
+  __shared__ float s_cdf[4][HN_PDF_MAXC];
+  __shared__ float s_bins[4][HN_PDF_MAXC];
+  __shared__ float s_sort[4][HN_PDF_MAXT];
+  __shared__ int s_idx[PERM ? 4 : 1][PERM ? HN_PDF_MAXT : 1];   // the sort's payload: position in cat(z, z_samples)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  if (ray >= q.n_rays) return;
+  hn_pdf_ray<PERM>(q, ray, lane, q.weights + (size_t)ray * q.w_ld, s_cdf[wv], s_bins[wv], s_sort[wv], s_idx[PERM ? wv : 0]);
+}
+// A level's compositing and the inverse-CDF sampling of the NEXT level from its weights as one launch (round 6; reference
+// call order models.py:744-768: render_samples(coarse) -> sample_pdf(coarse weights)): the same wave composites a ray and
+// then draws its fine samples — the weights reach the sampler through LDS (they are also written out: the level's
+// `weights` output), one dispatch and one HBM round trip of (B, S) floats fewer.  Same arithmetic as the two kernels.
+template <bool PERM>
+__global__ __launch_bounds__(256) void hn_composite_pdf_kernel(const HnCompositeArgs a, const HnPdfArgs q) {
+  __shared__ float s_cdf[4][HN_PDF_MAXC];
+  __shared__ float s_bins[4][HN_PDF_MAXC];
+  __shared__ float s_sort[4][HN_PDF_MAXT];
+  __shared__ float s_w[4][HN_PDF_MAXC + 1];
+  __shared__ int s_idx[PERM ? 4 : 1][PERM ? HN_PDF_MAXT : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  if (ray >= a.n_rays) return;
+  hn_composite_ray<false>(a, ray, lane, s_w[wv]);
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  hn_pdf_ray<PERM>(q, ray, lane, s_w[wv] + 1, s_cdf[wv], s_bins[wv], s_sort[wv], s_idx[PERM ? wv : 0]);
+}
+
+static int hn_pdf_check(const HnPdfArgs& q, bool own_weights) {
+  if (q.n_rays <= 0 || q.nb < 1 || q.nf <= 0) return -2;
+  if (q.z != nullptr && q.nc < 2) return -2;
+  if (q.bins_in == nullptr && (q.z == nullptr || q.nc - 2 != q.nb)) return -2;
+  if (q.nb + 1 > HN_PDF_MAXC || (q.z != nullptr ? q.nc : 0) + q.nf > HN_PDF_MAXT) return -2;
+  if ((own_weights && q.weights == nullptr) || q.u == nullptr) return -3;
+  if (q.z_all == nullptr && q.z_samples == nullptr && q.inds == nullptr && q.pts_new == nullptr) return -3;
+  if (q.pts != nullptr && (q.origins == nullptr || q.dirs == nullptr || q.z_all == nullptr)) return -3;
+  if (q.pts_new != nullptr && (q.origins == nullptr || q.dirs == nullptr)) return -3;
+  if (q.perm != nullptr && (q.z == nullptr || q.z_all == nullptr)) return -3;
+  return 0;
+}
 
 extern "C" int hn_sample_pdf_split(const float* weights, int w_ld, const float* bins, int n_bins, const float* z,
                                    int n_coarse, const float* u, const float* origins, const float* dirs, int ray_ld,
                                    int n_rays, int n_fine, float* z_all, float* pts, int64_t* inds, float* z_samples,
                                    int32_t* perm, float* pts_new, hnStream_t stream) {
-  if (n_rays <= 0 || n_bins < 1 || n_fine <= 0) return -2;
-  if (z != nullptr && n_coarse < 2) return -2;
-  if (bins == nullptr && (z == nullptr || n_coarse - 2 != n_bins)) return -2;
-  if (n_bins + 1 > HN_PDF_MAXC || (z != nullptr ? n_coarse : 0) + n_fine > HN_PDF_MAXT) return -2;
-  if (weights == nullptr || u == nullptr) return -3;
-  if (z_all == nullptr && z_samples == nullptr && inds == nullptr && pts_new == nullptr) return -3;
-  if (pts != nullptr && (origins == nullptr || dirs == nullptr || z_all == nullptr)) return -3;
-  if (pts_new != nullptr && (origins == nullptr || dirs == nullptr)) return -3;
-  if (perm != nullptr && (z == nullptr || z_all == nullptr)) return -3;
+  const HnPdfArgs q = {weights, w_ld, bins, n_bins, z, n_coarse, u, origins, dirs, ray_ld, n_rays, n_fine,
+                       z_all, pts, inds, z_samples, perm, pts_new};
+  const int rc = hn_pdf_check(q, true);
+  if (rc) return rc;
   if (perm != nullptr)
-    hipLaunchKernelGGL(hn_sample_pdf_kernel<true>, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, weights,
-                       w_ld, bins, n_bins, z, n_coarse, u, origins, dirs, ray_ld, n_rays, n_fine, z_all, pts, inds,
-                       z_samples, perm, pts_new);
+    hipLaunchKernelGGL(hn_sample_pdf_kernel<true>, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, q);
   else
-    hipLaunchKernelGGL(hn_sample_pdf_kernel<false>, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, weights,
-                       w_ld, bins, n_bins, z, n_coarse, u, origins, dirs, ray_ld, n_rays, n_fine, z_all, pts, inds,
-                       z_samples, perm, pts_new);
+    hipLaunchKernelGGL(hn_sample_pdf_kernel<false>, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, q);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hn_composite_sample_pdf(const HnCompositeArgs* a, const float* u, const float* origins, const float* dirs,
+                                       int ray_ld, int n_fine, float* z_all, float* pts, int64_t* inds, float* z_samples,
+                                       int32_t* perm, float* pts_new, hnStream_t stream) {
+  int rc = hn_check_comp(a, false);
+  if (rc) return rc;
+  if (a->perm != nullptr) return -2;           // the level that feeds the sampler is composited in one part
+  // hn_sample_pdf's fused form: bins = midpoints of the level's z, weights = columns 1 .. S-2 of the level's weights
+  const HnPdfArgs q = {nullptr, 0, nullptr, a->n_samples - 2, a->z, a->n_samples, u, origins, dirs, ray_ld, a->n_rays,
+                       n_fine, z_all, pts, inds, z_samples, perm, pts_new};
+  rc = hn_pdf_check(q, false);
+  if (rc) return rc;
+  if (perm != nullptr)
+    hipLaunchKernelGGL(hn_composite_pdf_kernel<true>, dim3((a->n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a, q);
+  else
+    hipLaunchKernelGGL(hn_composite_pdf_kernel<false>, dim3((a->n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a, q);
   HN_CHECK_LAUNCH();
   return 0;
 }
@@ -732,26 +794,18 @@ extern "C" int hn_generate_rays(int H, int W, float focal, const float* c2w, int
 __global__ __launch_bounds__(256) void hn_adam_kernel(float* p, float* g, float* m, float* v, long long n,
                                                        const float* __restrict__ hyper, float* step,
                                                        int zero_grad) {
-  // hyper-parameters are read from device memory: a captured launch (HIP graph) follows later changes of lr etc.
-  const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], weight_decay = hyper[4];
-  const float gscale = hyper[5];      // 1 / world size after a SUM all-reduce (1 otherwise)
-  // step[0] = number of updates done so far; this launch is update t = step[0] + 1.  Every block reads step[0]
-  // before it does anything else; the block that finishes LAST (ticket counter in step[1]) stores t and re-arms the
-  // ticket — by then every block has read the old value, so no second launch is needed to advance the counter.
-  const float t = step[0] + 1.0f;
-  const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
-  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  // every block reads step[0] (hn_adam_consts) before it does anything else; the block that finishes LAST advances it
+  const HnAdamConsts k = hn_adam_consts(hyper, step);
   const long long stride = (long long)gridDim.x * blockDim.x * 4;
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
       f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<f32x4*>(g + i);
       f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float gk = gg[k] * gscale + weight_decay * pp[k];
-        mm[k] = beta1 * mm[k] + (1.0f - beta1) * gk;
-        vv[k] = beta2 * vv[k] + (1.0f - beta2) * gk * gk;
-        pp[k] -= step_size * mm[k] / (sqrtf(vv[k]) * inv_sqrt_bc2 + eps);
+      for (int e = 0; e < 4; ++e) {
+        float pe = pp[e], me = mm[e], ve = vv[e];
+        hn_adam_update(k, pe, gg[e], me, ve);
+        pp[e] = pe; mm[e] = me; vv[e] = ve;
       }
       *reinterpret_cast<f32x4*>(p + i) = pp;
       *reinterpret_cast<f32x4*>(m + i) = mm;
@@ -759,22 +813,12 @@ __global__ __launch_bounds__(256) void hn_adam_kernel(float* p, float* g, float*
       if (zero_grad) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
       for (long long j = i; j < n; ++j) {
-        float gk = g[j] * gscale + weight_decay * p[j];
-        m[j] = beta1 * m[j] + (1.0f - beta1) * gk;
-        v[j] = beta2 * v[j] + (1.0f - beta2) * gk * gk;
-        p[j] -= step_size * m[j] / (sqrtf(v[j]) * inv_sqrt_bc2 + eps);
+        hn_adam_update(k, p[j], g[j], m[j], v[j]);
         if (zero_grad) g[j] = 0.f;
       }
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned* ticket = reinterpret_cast<unsigned*>(step) + 1;
-    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
-      step[0] = t;
-      *ticket = 0u;
-    }
-  }
+  hn_adam_ticket(step, k.t);
 }
 
 extern "C" int hn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
@@ -828,10 +872,37 @@ HN_DEV void hn_philox4x32_10(uint32_t (&c)[4], uint64_t seed) {
   }
 }
 
-__global__ __launch_bounds__(256) void hn_random_kernel(const HnDrawTable t, unsigned long long* state) {
+// Coarse sampling riding on the draw of t_rand (hn_render_prologue): the thread that has just drawn four values of the
+// (B, n) uniform buffer places those four samples — hn_sample_kernel's arithmetic, operation for operation.
+struct HnSampleRide {
+  int draw;                 // index of the uniform draw that is t_rand, -1: none
+  int n_rays, n, ray_ld, per_ray_bounds;
+  float scale;
+  const float* origins; const float* dirs; const float* lower; const float* upper;
+  float* z_out; float* pts_out;
+};
+HN_DEV void hn_place_sample(const HnSampleRide& sp, long long i, float t) {
+  const int b = (int)(i / sp.n), s = (int)(i % sp.n);
+  const size_t bi = sp.per_ray_bounds ? (size_t)i : (size_t)s;
+  float z = sp.lower[bi];
+  // z = lower + (upper - lower) * (scale * t): three separately rounded fp32 ops, as ATen does
+  if (sp.scale != 1.0f) t = __fmul_rn(sp.scale, t);
+  z = __fadd_rn(z, __fmul_rn(__fsub_rn(sp.upper[bi], z), t));
+  sp.z_out[i] = z;
+  if (sp.pts_out != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      sp.pts_out[i * 3 + c] = __fadd_rn(sp.origins[(size_t)b * sp.ray_ld + c], __fmul_rn(z, sp.dirs[(size_t)b * sp.ray_ld + c]));
+  }
+}
+
+// the draws of blocks [blk, blk + nblk) of a launch section of `nblk` blocks (grid-stride inside the section); the block
+// that finishes last advances the generator's offset
+template <bool RIDE>
+HN_DEV void hn_random_section(const HnDrawTable& t, unsigned long long* state, int blk, int nblk, const HnSampleRide& sp) {
   const unsigned long long seed = state[0], offset = state[1];
   const long long total = t.first_thread[t.count];
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = (long long)blk * blockDim.x + threadIdx.x; i < total; i += (long long)nblk * blockDim.x) {
     int b = 0;
 #pragma unroll
     for (int k = 1; k < HN_MAX_DRAWS; ++k)
@@ -862,22 +933,28 @@ __global__ __launch_bounds__(256) void hn_random_kernel(const HnDrawTable t, uns
     } else {
       for (int e = 0; e < 4 && j + e < t.n[b]; ++e) dst[e] = v[e];
     }
+    if (RIDE && b == sp.draw)
+      for (int e = 0; e < 4 && j + e < t.n[b]; ++e) hn_place_sample(sp, j + e, v[e]);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned* ticket = reinterpret_cast<unsigned*>(state + 2);
-    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {      // every block has read the old offset by now
+    if (atomicAdd(ticket, 1u) == (unsigned)nblk - 1) {      // every block of the section has read the old offset by now
       state[1] = offset + (unsigned long long)total;
       *ticket = 0u;
     }
   }
 }
 
-extern "C" int hn_random_fill(const HnDraw* draws_host, int n_draws, uint64_t* state_dev, hnStream_t stream) {
+__global__ __launch_bounds__(256) void hn_random_kernel(const HnDrawTable t, unsigned long long* state) {
+  hn_random_section<false>(t, state, (int)blockIdx.x, (int)gridDim.x, HnSampleRide{});
+}
+
+static int hn_draw_table_fill(const HnDraw* draws_host, int n_draws, HnDrawTable& t, long long& blocks) {
+  blocks = 0;
   if (n_draws < 0 || n_draws > HN_MAX_DRAWS) return -1;
   if (n_draws == 0) return 0;
-  if (draws_host == nullptr || state_dev == nullptr) return -3;
-  HnDrawTable t = {};
+  if (draws_host == nullptr) return -3;
   long long threads = 0;
   for (int i = 0; i < n_draws; ++i) {
     if (draws_host[i].n < 0 || (draws_host[i].kind != 0 && draws_host[i].kind != 1)) return -2;
@@ -888,11 +965,91 @@ extern "C" int hn_random_fill(const HnDraw* draws_host, int n_draws, uint64_t* s
   }
   t.count = n_draws;
   t.first_thread[n_draws] = threads;
-  if (threads == 0) return 0;
-  long long blocks = (threads + 255) / 256;
+  blocks = (threads + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  return 0;
+}
+
+extern "C" int hn_random_fill(const HnDraw* draws_host, int n_draws, uint64_t* state_dev, hnStream_t stream) {
+  HnDrawTable t = {};
+  long long blocks = 0;
+  const int rc = hn_draw_table_fill(draws_host, n_draws, t, blocks);
+  if (rc != 0) return rc;
+  if (n_draws == 0 || blocks == 0) return 0;
+  if (state_dev == nullptr) return -3;
   hipLaunchKernelGGL(hn_random_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t,
                      (unsigned long long*)state_dev);
+  HN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The head of a render step as ONE launch (round 6): everything the step needs before its first machine launch and that
+// depends on nothing but the step's inputs — the weight streams of its programs (hn_pack_units_multi), all random draws
+// (hn_random_fill), the coarse samples placed from the t_rand draw (hn_sample_along_rays) and the int64 image ids of the
+// ray rows (the reference's `.type(torch.long)`, model_utils.py:389-392).  Four launches of 5-13 us each, of which ~5 us
+// apiece is the floor of a dispatch, become one: sections of the grid [pack | draws + samples | ids].
+// ------------------------------------------------------------------------------------------------
+struct HnPrologueDev {
+  HnPackTable pack;
+  HnDrawTable draws;
+  HnSampleRide ride;
+  unsigned long long* state;
+  const float* ids_src; int64_t* ids_dst; int ids_ld, n_ids;
+  int pack_blocks, draw_blocks;
+};
+template <bool BF16>
+__global__ __launch_bounds__(256) void hn_prologue_kernel(const HnPrologueDev a) {
+  const int blk = (int)blockIdx.x;
+  if (blk < a.pack_blocks) {
+    hn_pack_block<BF16>(a.pack, blk);
+  } else if (blk < a.pack_blocks + a.draw_blocks) {
+    hn_random_section<true>(a.draws, a.state, blk - a.pack_blocks, a.draw_blocks, a.ride);
+  } else {
+    const int i = (blk - a.pack_blocks - a.draw_blocks) * 256 + (int)threadIdx.x;
+    if (i < a.n_ids) a.ids_dst[i] = (int64_t)a.ids_src[(size_t)i * a.ids_ld];      // float -> long: truncation toward zero, as ATen
+  }
+}
+
+extern "C" int hn_render_prologue(int mode, const HnPackJob* pack_jobs, int n_pack, const HnDraw* draws_host, int n_draws,
+                                  uint64_t* state_dev, const HnPrologue* p, hnStream_t stream) {
+  HnPrologueDev a = {};
+  int pb = 0;
+  int rc = hn_pack_table_fill(pack_jobs, n_pack, a.pack, pb);
+  if (rc != 0) return rc;
+  long long db = 0;
+  rc = hn_draw_table_fill(draws_host, n_draws, a.draws, db);
+  if (rc != 0) return rc;
+  if (db > 0 && state_dev == nullptr) return -3;
+  if (mode != HN_MODE_BF16 && mode != HN_MODE_BF16_S8 && mode != HN_MODE_F32) return -2;
+  a.state = (unsigned long long*)state_dev;
+  a.ride.draw = -1;
+  int ib = 0;
+  if (p != nullptr) {
+    if (p->t_rand_draw >= 0) {
+      if (p->t_rand_draw >= n_draws || p->n_rays <= 0 || p->n <= 0) return -2;
+      if (draws_host[p->t_rand_draw].kind != 0 || draws_host[p->t_rand_draw].n != (int64_t)p->n_rays * p->n) return -2;
+      if (p->lower == nullptr || p->upper == nullptr || p->z_out == nullptr) return -3;
+      if (p->pts_out != nullptr && (p->origins == nullptr || p->dirs == nullptr)) return -3;
+      a.ride.draw = p->t_rand_draw; a.ride.n_rays = p->n_rays; a.ride.n = p->n; a.ride.ray_ld = p->ray_ld;
+      a.ride.per_ray_bounds = p->per_ray_bounds; a.ride.scale = p->scale;
+      a.ride.origins = p->origins; a.ride.dirs = p->dirs; a.ride.lower = p->lower; a.ride.upper = p->upper;
+      a.ride.z_out = p->z_out; a.ride.pts_out = p->pts_out;
+    }
+    if (p->n_ids > 0) {
+      if (p->ids_src == nullptr || p->ids_dst == nullptr || p->ids_ld < 1) return -3;
+      a.ids_src = p->ids_src; a.ids_dst = p->ids_dst; a.ids_ld = p->ids_ld; a.n_ids = p->n_ids;
+      ib = (p->n_ids + 255) / 256;
+    }
+  }
+  a.pack_blocks = pb;
+  a.draw_blocks = (int)db;
+  const long long total = (long long)pb + db + ib;
+  if (total == 0) return 0;
+  if (mode == HN_MODE_F32)
+    hipLaunchKernelGGL(hn_prologue_kernel<false>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(hn_prologue_kernel<true>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
   HN_CHECK_LAUNCH();
   return 0;
 }

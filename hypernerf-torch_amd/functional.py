@@ -351,6 +351,8 @@ def drop_pending_wgrads():
     _PENDING.clear()
     _HELD.clear()
     _FORKED.clear()
+    from . import machine as _M
+    _M.drop_pending_reduce()
 
 
 def held_wgrads() -> int:
@@ -577,28 +579,88 @@ def seed_draws(seed: Optional[int] = None, device=None):
     return st
 
 
+def _draw_state(device) -> torch.Tensor:
+    st = _DRAW_STATE.get(str(device))
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.HnError("random_draws: first use inside a stream capture (run a warm-up step first)")
+        st = seed_draws(None, device)
+    return st
+
+
+def _draw_table(specs: Sequence[Tuple[Tuple[int, ...], str]], device):
+    if len(specs) > L.HN_MAX_DRAWS:
+        raise L.HnError(f"at most {L.HN_MAX_DRAWS} buffers per random_draws call")
+    outs = [torch.empty(shape, dtype=torch.float32, device=device) for shape, _ in specs]
+    arr = (L.HnDraw * max(1, len(specs)))()
+    for i, ((shape, kind), t) in enumerate(zip(specs, outs)):
+        if kind not in ("uniform", "normal"):
+            raise ValueError(kind)
+        arr[i].ptr, arr[i].n, arr[i].kind = t.data_ptr(), t.numel(), 0 if kind == "uniform" else 1
+    return outs, arr
+
+
 def random_draws(specs: Sequence[Tuple[Tuple[int, ...], str]], device) -> List[torch.Tensor]:
     """One launch (hn_random_fill) for all the random tensors of a render step.  specs: [(shape, 'uniform' | 'normal')]
     -> fp32 tensors on `device`: U[0,1) (24 bits, as torch.rand) / N(0,1).  Philox4x32-10 with a device-resident
     counter: graph replays draw fresh numbers; `torch.manual_seed` before the first call (or `seed_draws`) makes the
     sequence reproducible.  Not the same stream as torch's own generator (nor is torch's GPU stream its CPU one)."""
     L.load()
-    if len(specs) > L.HN_MAX_DRAWS:
-        raise L.HnError(f"at most {L.HN_MAX_DRAWS} buffers per random_draws call")
     device = torch.device(device)
-    st = _DRAW_STATE.get(str(device))
-    if st is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise L.HnError("random_draws: first use inside a stream capture (run a warm-up step first)")
-        st = seed_draws(None, device)
-    outs = [torch.empty(shape, dtype=torch.float32, device=device) for shape, _ in specs]
-    arr = (L.HnDraw * len(specs))()
-    for i, ((shape, kind), t) in enumerate(zip(specs, outs)):
-        if kind not in ("uniform", "normal"):
-            raise ValueError(kind)
-        arr[i].ptr, arr[i].n, arr[i].kind = t.data_ptr(), t.numel(), 0 if kind == "uniform" else 1
+    st = _draw_state(device)
+    outs, arr = _draw_table(specs, device)
     L.launch("hn_random_fill", arr, C.c_int(len(specs)), L.ptr(st), L.stream_handle())
     return outs
+
+
+PROLOGUE = os.environ.get("HN_PROLOGUE", "1") != "0"      # A/B switch of the fused step head (NerfModel.forward)
+
+
+def render_prologue(device, mode: int, pack_groups, specs: Sequence[Tuple[Tuple[int, ...], str]], sample=None, ids=None):
+    """The head of a render step as ONE launch (hn_render_prologue): the weight streams of `pack_groups`
+    (machine.collect_pack_jobs: at most one group), the random tensors `specs` (as random_draws), the coarse samples
+    placed from draw `sample['draw']` — sample = dict(draw, origins, directions, lower, upper, scale) -> (z, pts) as
+    sample_along_rays — and ids = (float column view (B,), out int64 (B,)).  Returns (draw tensors, z | None, pts | None)."""
+    from . import machine as _M
+    L.load()
+    device = torch.device(device)
+    outs, arr = _draw_table(specs, device)
+    st = _draw_state(device) if specs else None
+    if len(pack_groups) > 1:
+        raise L.HnError("render_prologue: one pack group (one numeric mode, <= HN_MAX_PACK_JOBS programs)")
+    p = L.HnPrologue()
+    p.t_rand_draw = -1
+    z = pts = None
+    keep = []
+    if sample is not None:
+        o, d = sample["origins"], sample["directions"]
+        if o.stride(-1) != 1 or d.stride(-1) != 1 or o.stride(0) != d.stride(0):
+            o, d = o.contiguous(), d.contiguous()
+        lower, upper = sample["lower"].contiguous(), sample["upper"].contiguous()
+        b, n = o.shape[0], lower.shape[-1]
+        z = torch.empty(b, n, dtype=torch.float32, device=device)
+        pts = torch.empty(b, n, 3, dtype=torch.float32, device=device)
+        p.t_rand_draw, p.n_rays, p.n, p.ray_ld = int(sample["draw"]), b, n, o.stride(0)
+        p.per_ray_bounds, p.scale = int(lower.dim() == 2), float(sample.get("scale", 1.0))
+        p.origins, p.dirs, p.lower, p.upper = o.data_ptr(), d.data_ptr(), lower.data_ptr(), upper.data_ptr()
+        p.z_out, p.pts_out = z.data_ptr(), pts.data_ptr()
+        keep += [o, d, lower, upper]
+    if ids is not None:
+        src, dst = ids
+        if src.dtype != torch.float32 or src.dim() != 1 or dst.dtype != torch.int64 or not dst.is_contiguous() or \
+                dst.numel() != src.numel():
+            raise L.HnError("render_prologue: ids = (fp32 column view (B,), contiguous int64 (B,))")
+        p.ids_src, p.ids_dst, p.ids_ld, p.n_ids = src.data_ptr(), dst.data_ptr(), max(1, src.stride(0)), src.numel()
+    if pack_groups:
+        m, jobs, grp = pack_groups[0]
+        tag = "+".join(r.prog.name for r, *_ in grp)
+    else:
+        m, jobs, grp, tag = mode, None, [], ""
+    L.launch("hn_render_prologue", C.c_int(m), jobs, C.c_int(len(grp)), arr if specs else None, C.c_int(len(specs)),
+             L.ptr(st), C.byref(p), L.stream_handle(), tag=tag)
+    if grp:
+        _M.mark_packed(grp)
+    return outs, z, pts
 
 
 # --------------------------------------------------------------------------------------------
@@ -612,7 +674,8 @@ class _CompositeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median,
-                dust_threshold=None, keep=None, noise_scale=1.0, rgb1=None, raw1=None, warped1=None, perm=None):
+                dust_threshold=None, keep=None, noise_scale=1.0, rgb1=None, raw1=None, warped1=None, perm=None,
+                then_pdf=None):
         L.require_gpu(rgb, raw, z, dirs)
         L.load()
         b, s = z.shape
@@ -662,7 +725,31 @@ class _CompositeFn(torch.autograd.Function):
         a.out_rgb, a.out_depth, a.out_acc, a.out_weights = o_rgb.data_ptr(), o_depth.data_ptr(), o_acc.data_ptr(), o_w.data_ptr()
         a.out_med_depth = o_md.data_ptr() if o_md is not None else 0
         a.out_med_points = o_mp.data_ptr() if o_mp is not None else 0
-        L.launch("hn_composite_forward", C.byref(a), L.stream_handle())
+        pdf_out = None
+        if then_pdf is not None:
+            # the inverse-CDF sampling of the next level from this level's weights, in the same launch (sample_pdf's fused
+            # form + split): then_pdf = dict(u (B, Nf), origins, directions, split)
+            if perm is not None:
+                raise L.HnError("composite(then_pdf=...) needs a level composited in one part")
+            u_c = then_pdf["u"].contiguous()
+            o_, d_ = then_pdf["origins"], then_pdf["directions"]
+            if o_.stride(-1) != 1 or d_.stride(-1) != 1 or o_.stride(0) != d_.stride(0):
+                o_, d_ = o_.contiguous(), d_.contiguous()
+            nf = u_c.shape[1]
+            z_all = torch.empty(b, s + nf, dtype=torch.float32, device=dev)
+            pts_all = torch.empty(b, s + nf, 3, dtype=torch.float32, device=dev)
+            inds = torch.empty(b, nf, dtype=torch.int64, device=dev)
+            zs = torch.empty(b, nf, dtype=torch.float32, device=dev)
+            perm_o = pts_new = None
+            if then_pdf.get("split"):
+                perm_o = torch.empty(b, s + nf, dtype=torch.int32, device=dev)
+                pts_new = torch.empty(b, nf, 3, dtype=torch.float32, device=dev)
+            L.launch("hn_composite_sample_pdf", C.byref(a), L.ptr(u_c), L.ptr(o_), L.ptr(d_), C.c_int(o_.stride(0)),
+                     C.c_int(nf), L.ptr(z_all), L.ptr(pts_all), L.ptr(inds), L.ptr(zs), L.ptr(perm_o), L.ptr(pts_new),
+                     L.stream_handle())
+            pdf_out = [z_all, pts_all, inds, zs] + ([perm_o, pts_new] if perm_o is not None else [])
+        else:
+            L.launch("hn_composite_forward", C.byref(a), L.stream_handle())
         ctx.saved = (rgb_c, raw_c, noise_c, z_c, dirs_c)
         ctx.parts = (perm_c, rgb1_c, raw1_c, s0)
         ctx.filt = (dust_threshold, keep_c)
@@ -681,6 +768,9 @@ class _CompositeFn(torch.autograd.Function):
             # the sorted `warped_points` stays differentiable w.r.t. the parts' warped rows (a loss the caller puts on
             # it: rare, un-permuted with torch ops in backward)
             outs.append(o_warped)
+        if pdf_out is not None:     # appended LAST (backward ignores them): (z_all, pts, inds, z_samples[, perm, pts_new])
+            outs += pdf_out
+            nd += pdf_out
         ctx.mark_non_differentiable(*nd)
         ctx.set_materialize_grads(False)      # unused outputs (depth, acc, weights) arrive as None, not as zero fills
         return tuple(outs)
@@ -721,19 +811,25 @@ class _CompositeFn(torch.autograd.Function):
                 d_warped, d_warped1 = cat[:, :s0].contiguous(), cat[:, s0:].contiguous()
         L.launch("hn_composite_backward", C.byref(a), L.stream_handle())
         return (d_rgb, d_raw.view(ctx.raw_shape), None, None, None, d_warped, None, None, None, None, None, None, None,
-                d_rgb1, d_raw1.view(ctx.raw1_shape) if d_raw1 is not None else None, d_warped1, None)
+                d_rgb1, d_raw1.view(ctx.raw1_shape) if d_raw1 is not None else None, d_warped1, None, None)
+
+
+COMPOSITE_PDF = os.environ.get("HN_COMPOSITE_PDF", "1") != "0"      # A/B switch: coarse compositing + inverse-CDF sampling as one launch
 
 
 def composite(rgb, raw, noise, z, dirs, warped=None, variant=0, white_bg=False, sample_at_infinity=True,
               want_median=True, dust_threshold=None, keep=None, noise_scale: float = 1.0, rgb1=None, raw1=None,
-              warped1=None, perm=None):
+              warped1=None, perm=None, then_pdf=None):
     """Returns (rgb (B,3), depth (B), acc (B), weights (B,S)[, med_depth (B)[, med_points (B)]]).
     `noise` (B,S): standard-normal draws, scaled by `noise_scale` inside the kernel (noise_std of noise_regularize).
     dust_threshold / keep (B,S 0/1): the reference's filter_sigma (models.py:35-63) applied to the activated density.
     With `perm` (B,S) int32 the level comes in two parts — (rgb, raw, warped) and (rgb1, raw1, warped1), see
-    _CompositeFn — and the sorted warped points (B,S,H) are appended to the result."""
+    _CompositeFn — and the sorted warped points (B,S,H) are appended to the result.
+    `then_pdf` = dict(u (B,Nf), origins, directions, split): the next level's inverse-CDF sampling from this level's
+    weights in the SAME launch (hn_composite_sample_pdf); sample_pdf's results (z_all, pts, inds, z_samples[, perm,
+    pts_new]) are appended to the result."""
     return _CompositeFn.apply(rgb, raw, noise, z, dirs, warped, variant, white_bg, sample_at_infinity, want_median,
-                              dust_threshold, keep, noise_scale, rgb1, raw1, warped1, perm)
+                              dust_threshold, keep, noise_scale, rgb1, raw1, warped1, perm, then_pdf)
 
 
 # --------------------------------------------------------------------------------------------

@@ -176,6 +176,57 @@ def noise_regularize(raw, noise_std, use_stratified_sampling, noise=None):
     return raw
 
 
+class RayMetadata(dict):
+    """`metadata` of prepare_ray_dict: the four keys of the reference ('warp', 'camera', 'appearance', 'time') all hold
+    ONE int64 tensor, column 8 of the ray rows converted with `.type(torch.long)` (reference model_utils.py:389-398).
+    The conversion is made on first access — NerfModel.forward's fused step head (hn_render_prologue) makes it inside
+    its own launch instead (`raw` = the fp32 column view, `set_converted`) —, so a dict is all a caller ever sees."""
+    KEYS = ('warp', 'camera', 'appearance', 'time')
+
+    def __init__(self, column=None, **kw):
+        if isinstance(column, torch.Tensor):
+            super().__init__({k: None for k in self.KEYS})
+            self.raw = column
+            self._idx = None
+        else:       # rebuilt from (key, value) pairs by code that maps over containers (DDP's input scatter, copy): a plain dict
+            super().__init__(column if column is not None else (), **kw)
+            self.raw = None
+            self._idx = next((v for v in super().values() if v is not None), None)
+
+    def converted(self) -> bool:
+        return self._idx is not None or self.raw is None
+
+    def set_converted(self, idx: torch.Tensor):
+        self._idx = idx
+        for k in self.KEYS:
+            super().__setitem__(k, idx)
+
+    def _get(self):
+        if self._idx is None and self.raw is not None:
+            self.set_converted(self.raw.type(torch.long))
+        return self._idx
+
+    def __getitem__(self, k):
+        if k in self.KEYS and super().__getitem__(k) is None:
+            self._get()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        self._get()
+        return super().items()
+
+    def values(self):
+        self._get()
+        return super().values()
+
+    def copy(self):
+        self._get()
+        return dict(super().items())
+
+
 def prepare_ray_dict(rays: torch.Tensor) -> dict:
     """(B,8|9) nerf_pl ray rows -> ray dict (reference: hypernerf/model_utils.py:365-404).
     near/far columns are read and dropped, viewdirs is None, column 8 feeds all four metadata keys."""
@@ -183,11 +234,14 @@ def prepare_ray_dict(rays: torch.Tensor) -> dict:
     if len(rays.shape) > 2:
         rays = rays.view(-1, 8)
     b = rays.shape[0]
-    if use_meta:
-        idx = rays[:, 8].type(torch.long)
+    if use_meta and rays.dtype == torch.float32 and rays.is_cuda:
+        metadata = RayMetadata(rays[:, 8])          # converted on first use (or by the model's step head, in its launch)
     else:
-        idx = torch.ones((b, 1), dtype=torch.long, device=rays.device)
-    metadata = {k: idx for k in ('warp', 'camera', 'appearance', 'time')}     # read-only downstream: one tensor
+        if use_meta:
+            idx = rays[:, 8].type(torch.long)
+        else:
+            idx = torch.ones((b, 1), dtype=torch.long, device=rays.device)
+        metadata = {k: idx for k in ('warp', 'camera', 'appearance', 'time')}     # read-only downstream: one tensor
     return {"origins": rays[:, :3], "directions": rays[:, 3:6], "viewdirs": None, "metadata": metadata}
 
 

@@ -7,6 +7,7 @@ fused HIP launches per level: sampling -> warp-field machine -> hyper-sheet mach
 """
 from __future__ import annotations
 
+import ctypes as C
 import functools
 import os
 from typing import Any, Callable, Dict, Mapping, Optional, Sequence
@@ -485,8 +486,10 @@ class NerfModel(nn.Module):
 
     def render_samples(self, level, points, z_vals, directions, viewdirs, metadata, extra_params, use_warp=True,
                        metadata_encoded=False, return_warp_jacobian=False, use_sample_at_infinity=False,
-                       render_opts=None, noise=None):
-        """One level of the render (reference: models.py:587-671)."""
+                       render_opts=None, noise=None, then_pdf=None):
+        """One level of the render (reference: models.py:587-671).  `then_pdf` (forward() for the coarse level): the fine
+        level's inverse-CDF sampling rides on this level's compositing launch; its results land in out['_pdf']."""
+        self._then_pdf = then_pdf
         # filter_sigma (reference models.py:35-63, call site :650) runs inside the compositing kernel: the dust
         # threshold as a scalar, the bounding box as a 0/1 mask over the sample points
         dust, keep = None, None
@@ -611,13 +614,15 @@ class NerfModel(nn.Module):
             return 'outside'
         return None
 
-    def _prepack(self, use_warp, metadata_encoded, metadata, return_warp_jacobian, device):
+    def _prepack(self, use_warp, metadata_encoded, metadata, return_warp_jacobian, device, collect=False):
         """The weight streams of every program this forward pass is about to launch, packed by ONE launch
         (machine.pack_many) where more than one of them is stale — after an optimizer step that is all three of a
         training step's (coarse level, fine level over the new samples, fine template over the coarse samples): three
-        dispatches of ~9 us for ~4 us of work each.  A prediction only: a program it misses packs itself as before."""
+        dispatches of ~9 us for ~4 us of work each.  A prediction only: a program it misses packs itself as before.
+        `collect`: return the pack groups (machine.collect_pack_jobs) instead of launching them — the step head
+        (functional.render_prologue) packs them in its own launch."""
         if not self.PREPACK or not self._can_fuse_level(use_warp, metadata_encoded, metadata):
-            return
+            return []
         from .. import machine
         calls = [self._level_call('coarse')]
         grad = torch.is_grad_enabled() and any(p.requires_grad for p in calls[0].program.params)
@@ -626,7 +631,17 @@ class NerfModel(nn.Module):
             if self.REUSE_COARSE and not return_warp_jacobian:
                 n_hyper = self.hyper_sheet_out_dim if self.hyper_slice_method == 'bendy_sheet' else 0
                 calls.append(self._template_reuse_call('fine', n_hyper, self.hyper_slice_method == 'axis_aligned_plane', grad))
+        if collect:
+            groups = machine.collect_pack_jobs([c.runner for c in calls], device, F.mode_of(self.precision), force=grad,
+                                               min_jobs=1)
+            if len(groups) <= 1:
+                return groups
+            for m, arr, grp in groups:           # two numeric modes in one model: not the step head's business
+                L.launch("hn_pack_units_multi", C.c_int(m), arr, C.c_int(len(grp)), L.stream_handle())
+                machine.mark_packed(grp)
+            return []
         machine.pack_many([c.runner for c in calls], device, F.mode_of(self.precision), force=grad)
+        return []
 
     def _render_fine_reusing_coarse(self, coarse, points, z_vals, pts_new, perm, directions, viewdirs, metadata,
                                     use_sample_at_infinity, render_opts, noise, extra_params=None, how='fused'):
@@ -721,9 +736,13 @@ class NerfModel(nn.Module):
             if noise is None or tuple(noise.shape) != (b, s, 1):
                 noise = torch.randn((b, s, 1), device=device, dtype=torch.float32)
             scale = float(self.noise_std)                                              # scaled inside the kernel
+        then_pdf = getattr(self, '_then_pdf', None)
+        self._then_pdf = None
         res = F.composite(rgb.view(b, s, 3), alpha.view(b, s), noise, z_vals, directions, warped, variant=0,
                           white_bg=self.use_white_background, sample_at_infinity=use_sample_at_infinity,
-                          want_median=True, dust_threshold=dust, keep=keep, noise_scale=scale)
+                          want_median=True, dust_threshold=dust, keep=keep, noise_scale=scale, then_pdf=then_pdf)
+        if then_pdf is not None:
+            out['_pdf'] = res[-(6 if then_pdf.get('split') else 4):]
         out['warped_points'] = warped
         out['rgb'], out['depth'], out['acc'], out['weights'], out['med_depth'] = res[0], res[1], res[2], res[3], res[4]
         out['med_points'] = res[5].view(b, 1, 1)
@@ -753,10 +772,10 @@ class NerfModel(nn.Module):
         # calls (model_utils.py:31 t_rand, :226 u, :300-317 the density noise of each level); the noise stays N(0,1)
         # and is scaled by noise_std inside the compositing kernel
         self._auto_noise = {}
+        want = []
         if self.use_stratified_sampling and F.FAST_DRAWS:
             nc, nf = self.num_coarse_samples, self.num_fine_samples
             noisy = (self.noise_std is not None) and self.noise_std > 0.0
-            want = []
             if 't_rand' not in rng:
                 want.append(('t_rand', (b, nc), 'uniform'))
             if noisy and 'noise_coarse' not in rng:
@@ -765,25 +784,41 @@ class NerfModel(nn.Module):
                 want.append(('u', (b, nf), 'uniform'))
             if nf > 0 and noisy and 'noise_fine' not in rng:
                 want.append(('noise_fine', (b, nc + nf, 1), 'normal'))
-            if want:
-                got = F.random_draws([(shape, kind) for _, shape, kind in want], origins.device)
-                rng = dict(rng)
-                for (name, _, _), t in zip(want, got):
-                    if name.startswith('noise_'):
-                        self._auto_noise[name[6:]] = t
-                    else:
-                        rng[name] = t
         self._level_state = None
-        self._prepack(use_warp, metadata_encoded, metadata, return_warp_jacobian, origins.device)
-        z_vals, points = model_utils.sample_along_rays(origins, directions, self.num_coarse_samples, near, far,
-                                                       self.use_stratified_sampling, self.use_linear_disparity,
-                                                       t_rand=rng.get('t_rand'))
-        coarse = self.render_samples('coarse', points, z_vals, directions, viewdirs, metadata, extra_params,
-                                     use_warp=use_warp, metadata_encoded=metadata_encoded,
-                                     return_warp_jacobian=return_warp_jacobian,
-                                     use_sample_at_infinity=self.use_sample_at_infinity,
-                                     noise=rng.get('noise_coarse'))
-        out = {'coarse': coarse}
+        lazy_ids = isinstance(metadata, model_utils.RayMetadata) and not metadata.converted()
+        z_vals = points = None
+        if F.PROLOGUE and (want or lazy_ids):
+            # the step head as ONE launch (hn_render_prologue): the draws, the stale weight streams of the programs this
+            # pass will run, the coarse samples placed from the t_rand draw, the int64 image ids of the ray rows — four
+            # launches of 5-13 us (each ~5 us of dispatch floor) otherwise
+            ids = None
+            if lazy_ids:
+                ids = (metadata.raw, torch.empty(b, dtype=torch.int64, device=origins.device))
+            sample = None
+            if want and want[0][0] == 't_rand':
+                lower, upper, _ = model_utils.stratified_bounds(self.num_coarse_samples, near, far,
+                                                                self.use_linear_disparity, origins.device)
+                sample = dict(draw=0, origins=origins, directions=directions, lower=lower, upper=upper)
+            if ids is not None:
+                metadata.set_converted(ids[1])       # (the launch below fills it; nothing reads it before)
+            groups = self._prepack(use_warp, metadata_encoded, metadata, return_warp_jacobian, origins.device, collect=True)
+            got, z_vals, points = F.render_prologue(origins.device, F.mode_of(self.precision), groups,
+                                                    [(shape, kind) for _, shape, kind in want], sample, ids)
+        else:
+            got = F.random_draws([(shape, kind) for _, shape, kind in want], origins.device) if want else []
+            self._prepack(use_warp, metadata_encoded, metadata, return_warp_jacobian, origins.device)
+        if want:
+            rng = dict(rng)
+            for (name, _, _), t in zip(want, got):
+                if name.startswith('noise_'):
+                    self._auto_noise[name[6:]] = t
+                else:
+                    rng[name] = t
+        if z_vals is None:
+            z_vals, points = model_utils.sample_along_rays(origins, directions, self.num_coarse_samples, near, far,
+                                                           self.use_stratified_sampling, self.use_linear_disparity,
+                                                           t_rand=rng.get('t_rand'))
+        u = then_pdf = None
         if self.num_fine_samples > 0:
             u = rng.get('u')
             if u is None:
@@ -797,16 +832,37 @@ class NerfModel(nn.Module):
                     if u is None:
                         u = torch.linspace(0, 1, self.num_fine_samples).to(origins.device).expand(b, -1).contiguous()
                         self._det_u[key] = u
+            if F.COMPOSITE_PDF and 3 <= self.num_coarse_samples <= 256 and self.num_coarse_samples + self.num_fine_samples <= 512:
+                # the fine level's inverse-CDF sampling rides on the coarse level's compositing launch (whether the fine
+                # level will re-use the coarse warp is only known after the coarse level ran: the split outputs — merge
+                # permutation, new points — are produced whenever REUSE_COARSE could apply)
+                then_pdf = dict(u=u, origins=origins, directions=directions,
+                                split=bool(self.REUSE_COARSE and use_warp and not return_warp_jacobian))
+        coarse = self.render_samples('coarse', points, z_vals, directions, viewdirs, metadata, extra_params,
+                                     use_warp=use_warp, metadata_encoded=metadata_encoded,
+                                     return_warp_jacobian=return_warp_jacobian,
+                                     use_sample_at_infinity=self.use_sample_at_infinity,
+                                     noise=rng.get('noise_coarse'), then_pdf=then_pdf)
+        pdf = coarse.pop('_pdf', None)
+        self._then_pdf = None
+        out = {'coarse': coarse}
+        if self.num_fine_samples > 0:
             how = self._can_reuse_coarse(use_warp, metadata_encoded, metadata, return_warp_jacobian)
             self._reused_coarse = how
-            if how is not None:
-                z_fine, pts_fine, inds, _, perm, pts_new = F.sample_pdf(coarse['weights'], z_vals, u, origins,
-                                                                        directions, split=True)
+            if how is not None and (pdf is None or len(pdf) == 6):
+                if pdf is not None:
+                    z_fine, pts_fine, inds, _, perm, pts_new = pdf
+                else:
+                    z_fine, pts_fine, inds, _, perm, pts_new = F.sample_pdf(coarse['weights'], z_vals, u, origins,
+                                                                            directions, split=True)
                 fine = self._render_fine_reusing_coarse(coarse, pts_fine, z_fine, pts_new, perm, directions, viewdirs,
                                                         metadata, use_sample_at_infinity, render_opts,
                                                         rng.get('noise_fine'), extra_params, how)
             else:
-                z_fine, pts_fine, inds, _ = F.sample_pdf(coarse['weights'], z_vals, u, origins, directions)
+                if pdf is not None:
+                    z_fine, pts_fine, inds = pdf[0], pdf[1], pdf[2]
+                else:
+                    z_fine, pts_fine, inds, _ = F.sample_pdf(coarse['weights'], z_vals, u, origins, directions)
                 fine = self.render_samples('fine', pts_fine, z_fine, directions, viewdirs, metadata, extra_params,
                                            use_warp=use_warp, metadata_encoded=metadata_encoded,
                                            return_warp_jacobian=return_warp_jacobian,

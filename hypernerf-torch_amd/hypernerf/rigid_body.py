@@ -5,10 +5,13 @@ Same names and argument meaning; every function also takes a BATCH of inputs (le
 cannot (`w.view(3)`, rigid_body.py:35).  The exponential maps run on the GPU through the SE(3) kernel of the render path
 (`hn_se3_apply_forward`, csrc/hn_render.hip — the kernel SE3Field's warp uses, pinned to the reference's one valid
 `exp_se3` result by tests/golden G13): the rigid transform is applied to the origin and the three basis vectors, which
-yields t and the columns of R.  The screw axis is the unit axis of Modern Robotics eq. 3.88 that the reference's
-docstrings cite and that SE3Field passes (w / theta, warping.py:226-232); a non-unit `w` is refused (upstream's formula
-would return I + sin(theta)[w] + (1 - cos(theta))[w]^2, which is no rotation).  Tensors must live on the GPU: there is no
-CPU path (the reference hard-codes `.cuda()` here too, rigid_body.py:38, 52, 57).
+yields t and the columns of R.  For the unit screw axis of Modern Robotics eq. 3.88 that the reference's docstrings cite
+and that SE3Field passes (w / theta, warping.py:226-232) the result is upstream's.  Every other input upstream accepts is
+accepted too and gets the exponential map of the twist [S] theta itself: a non-unit `w` rotates about w / |w| by |w| theta
+(upstream's formula returns I + sin(theta)[w] + (1 - cos(theta))[w]^2 there, which is no rotation), and w = 0 is the pure
+translation R = I, p = theta v (the same as upstream's).  `STRICT_UNIT_AXIS = True` turns the old refusal of non-unit axes
+back on (it costs a device-to-host sync per call; off, nothing here synchronises, so the functions can be captured).
+Tensors must live on the GPU: there is no CPU path (the reference hard-codes `.cuda()` here too, rigid_body.py:38, 52, 57).
 
 Two upstream defects are not reproduced: `to_homogenous` RESHAPES (N, 4) into (4, N) instead of transposing it
 (rigid_body.py:85-89: correct for one point only, scrambled beyond), and `exp_se3` reshapes `v` likewise (:76).  Here both
@@ -46,7 +49,12 @@ def rp_to_se3(r: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
     return torch.cat([up, low], dim=-2)
 
 
+STRICT_UNIT_AXIS = False
+
+
 def _unit_axis(w: torch.Tensor, what: str):
+    if not STRICT_UNIT_AXIS:
+        return
     n = w.norm(dim=-1)
     if not bool(((n - 1.0).abs() <= 1e-4).all()):
         raise ValueError(f"{what}: the rotation axis must be a unit vector (Modern Robotics eq. 3.51 / 3.88: "
@@ -63,22 +71,31 @@ def _magnitudes(theta, n: int, device) -> torch.Tensor:
 
 
 def _rigid(w: torch.Tensor, v: torch.Tensor, theta: torch.Tensor):
-    """(R (N,3,3), t (N,3)) of exp([S] theta) for N unit screw axes through hn_se3_apply_forward: the kernel takes the
-    exponential coordinates (w theta, v theta) and a point; the origin gives t, the basis vectors the columns of R."""
+    """(R (N,3,3), t (N,3)) of exp([S] theta) for N screw axes through hn_se3_apply_forward: the kernel takes the
+    exponential coordinates (w theta, v theta) and a point.  The origin with the twist's v gives t; the three basis vectors
+    with v = 0 give the columns of R directly (no (R e_i + t) - t cancellation when |t| is large).  Rows with w theta = 0
+    (the kernel divides by |w theta|, as SE3Field does: warping.py:226-232) are the pure translation R = I, t = v theta,
+    selected by a device-side mask — no host sync."""
     n = w.shape[0]
     th = theta.reshape(n, 1).float()
     wt, vt = (w.float() * th).contiguous(), (v.float() * th).contiguous()
+    still = (wt == 0).all(dim=-1, keepdim=True)                                            # (n, 1)
+    e1 = torch.zeros(1, 3, device=w.device)
+    e1[0, 0] = 1.0
+    wk = torch.where(still, e1.expand(n, 3), wt)                                           # any finite axis: result replaced below
     pts = torch.cat([torch.zeros(1, 3), torch.eye(3)], 0).to(w.device)                     # origin, e1, e2, e3
-    y = F.se3_apply(wt[:, None, :].expand(n, 4, 3).reshape(-1, 3), vt[:, None, :].expand(n, 4, 3).reshape(-1, 3),
+    vk = torch.cat([vt[:, None, :], torch.zeros(n, 3, 3, device=w.device)], 1)             # v for the origin only
+    y = F.se3_apply(wk[:, None, :].expand(n, 4, 3).reshape(-1, 3), vk.reshape(-1, 3),
                     pts[None].expand(n, 4, 3).reshape(-1, 3)).view(n, 4, 3)
-    t = y[:, 0]
-    r = (y[:, 1:] - t[:, None, :]).transpose(1, 2)                                          # column i = R e_i
+    t = torch.where(still, vt, y[:, 0])
+    r = y[:, 1:].transpose(1, 2)                                                            # column i = R e_i
+    r = torch.where(still[:, :, None], torch.eye(3, device=w.device).expand(n, 3, 3), r)
     return r, t
 
 
 def exp_so3(w: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
     """Rodrigues: I + sin(theta) [w] + (1 - cos(theta)) [w]^2 for unit axes w (..., 3), theta (...) or scalar
-    (reference rigid_body.py:55-57) -> (..., 3, 3)."""
+    (reference rigid_body.py:55-57) -> (..., 3, 3); a non-unit w rotates about w / |w| by |w| theta, w = 0 gives I."""
     L.require_gpu(w)
     lead = w.shape[:-1] if w.dim() > 1 and w.shape[-1] == 3 else ()
     wf = w.reshape(-1, 3)

@@ -16,8 +16,10 @@ Vocabulary
 from __future__ import annotations
 
 import os
+import weakref
 
 import ctypes as C
+import itertools
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -875,8 +877,10 @@ def slab_tiles(jobs: np.ndarray) -> np.ndarray:
 class ResolvedWgrad:
     """A PendingWgrad cut into jobs (device table cached by the program's runner)."""
 
-    def __init__(self, mode, jobs_dev, n_jobs, stash, grads, weights, bucket=0, jobs_host=None):
+    def __init__(self, mode, jobs_dev, n_jobs, stash, grads, weights, bucket=0, jobs_host=None, owner=None):
         self.mode, self.jobs_dev, self.n_jobs, self.stash, self.grads = mode, jobs_dev, n_jobs, stash, grads
+        self.owner = owner              # the MlpRunner whose `_jobs` entry holds jobs_dev: tables derived from a GROUP of
+                                        # job tables (global order, reduce tables) live in the first share's owner
         self.weights = weights          # per job: stash tiles it streams (host numpy, for the global order)
         self.bucket = bucket            # 0 = launched at the end of backward, 1 = held (see WGRAD_SPLIT_OFFSET)
         self.jobs_host = jobs_host      # the job table (numpy): what the reduce tables of a partials launch are built from
@@ -889,8 +893,29 @@ class ResolvedWgrad:
 # (HnDwBatch.partials) and ONE more launch (hn_mlp_wgrad_reduce, a workgroup per destination tile) sums the slabs and adds
 # every gradient element once: 1/12 of the atomics, and sums whose order no longer depends on which job finished first.
 WGRAD_PARTIALS = int(os.environ.get("HN_WGRAD_PARTIALS", 1))
-BIAS_MFMA_BUILD = os.environ.get("HN_WGRAD_BIAS_MFMA", "0") not in ("", "0")      # A/B build: bias by all-ones MFMAs + atomics
-_REDUCE_CACHE: Dict[tuple, tuple] = {}
+BIAS_MFMA_BUILD = L.WGRAD_BIAS_MFMA      # A/B build: bias by all-ones MFMAs + atomics (asked of the library: hn_build_config)
+_UID = itertools.count(1)
+_ORPHAN_GROUP_CACHE: Dict[tuple, tuple] = {}      # shares built without an owner (tests that assemble ResolvedWgrad by hand)
+
+
+def _uid(t: torch.Tensor) -> int:
+    """Identity of a device table / gradient buffer that is NOT its address: the caching allocator hands the address of
+    a freed model's job table to the next model's, and a table derived from the old one (destination offsets of the
+    reduce launch) would then be used on the new one without any error (advisor, round 5)."""
+    u = getattr(t, "_hn_uid", None)
+    if u is None:
+        u = t._hn_uid = next(_UID)
+    return u
+
+
+def _group_cache(grp: Sequence["ResolvedWgrad"]) -> dict:
+    """Where the tables derived from this GROUP of job tables are kept: on the runner that owns the first share's job
+    table, so that they are freed with it (the key names every table of the group by uid, so an entry can never be
+    taken for another group's)."""
+    owner = grp[0].owner
+    if owner is None:
+        return _ORPHAN_GROUP_CACHE
+    return owner._group_tables
 
 
 def _embed_struct(embeds: Sequence[dict]) -> "L.HnEmbedReduce":
@@ -946,7 +971,136 @@ def _reduce_tables(grp: Sequence["ResolvedWgrad"], device):
     for t, (key, v) in enumerate(sorted(dest.items(), key=lambda kv: -len(kv[1]))):
         tiles[t] = (v[0], key[1], key[2], key[3], key[4], key[5], key[6], len(lst), len(v) - 1)
         lst.extend(v[1:])
-    return (L.to_device_bytes(tiles, device), L.to_device_bytes(np.asarray(lst, dtype=np.uint32), device), len(tiles))
+    # [3]: host-side extras of the table — the destination records themselves (what adam_rest_ranges proves the partition
+    # of the arena with) and a cache of what is derived from them
+    extras = {"tiles_host": tiles, "one_buffer": len({key[0] for key in dest}) <= 1}
+    return (L.to_device_bytes(tiles, device), L.to_device_bytes(np.asarray(lst, dtype=np.uint32), device), len(tiles), extras)
+
+
+ADAM_REST_CHUNK = 2048      # elements per `rest` workgroup of hn_mlp_wgrad_reduce_adam
+
+
+def adam_rest_ranges(tiles_host: np.ndarray, numel: int, embed: Optional[Tuple[int, int, int, int]] = None):
+    """The partition hn_mlp_wgrad_reduce_adam needs (include/hn_kernels.h HnAdamFuse.rest): how often every element of a
+    gradient arena of `numel` floats is a destination of the reduce launch described by `tiles_host` (HnDwReduceTile
+    records: 32 x 32 tiles of weight matrices, bias records with ld == 0) and `embed` = (offset, rows, dim, col_mask) of the
+    gathered table's gradient.  Returns (ranges, coverage): ranges = int64 (n, 2) array of (start, len <= ADAM_REST_CHUNK)
+    covering exactly the elements NOTHING writes, or None when some element is a destination twice (two records of one
+    launch that overlap: the unfused reduce adds both contributions, a fused optimizer would step that element twice —
+    the caller then keeps the two-launch form).  Pure host arithmetic (tests/test_host_api.py)."""
+    cov = np.zeros(numel, dtype=np.uint8)
+    for t in tiles_host:
+        w_off, ld, row0, col0, r_end, c_end = (int(t[k]) for k in ("w_off", "ld", "row0", "col0", "r_end", "c_end"))
+        if ld == 0:       # bias record: col0 = dZ tiles of the rectangle, rows row0 .. row0 + 32 col0 clipped to [0, r_end)
+            lo, hi = max(row0, 0), min(row0 + 32 * col0, r_end)
+            if hi > lo:
+                cov[w_off + lo:w_off + hi] += 1
+            continue
+        r_lo, r_hi = max(row0, 0), min(row0 + 32, r_end)
+        c_lo, c_hi = max(col0, 0), min(col0 + 32, c_end)
+        if r_hi <= r_lo or c_hi <= c_lo:
+            continue
+        idx = w_off + np.arange(r_lo, r_hi, dtype=np.int64)[:, None] * ld + np.arange(c_lo, c_hi, dtype=np.int64)[None, :]
+        cov[idx.reshape(-1)] += 1
+    if embed is not None:
+        off, rows, dim, mask = embed
+        cols = np.array([c for c in range(dim) if (mask >> c) & 1], dtype=np.int64)
+        if rows > 0 and len(cols):
+            idx = off + np.arange(rows, dtype=np.int64)[:, None] * dim + cols[None, :]
+            cov[idx.reshape(-1)] += 1
+    if int(cov.max(initial=0)) > 1:
+        return None, cov
+    free = np.flatnonzero(cov == 0)
+    out = []
+    if len(free):
+        cut = np.flatnonzero(np.diff(free) != 1) + 1
+        for run in np.split(free, cut):
+            a, n = int(run[0]), len(run)
+            for o in range(0, n, ADAM_REST_CHUNK):
+                out.append((a + o, min(ADAM_REST_CHUNK, n - o)))
+    return np.asarray(out, dtype=np.int64).reshape(-1, 2), cov
+
+
+class PendingReduce:
+    """The second half of a batched weight-gradient launch (hn_mlp_wgrad_reduce), held back because an optimizer
+    registered to consume it (optim.ArenaAdam(fuse_reduce=True) -> REDUCE_CONSUMERS): `fused(...)` runs it as
+    hn_mlp_wgrad_reduce_adam, `plain()` as the reduce it would have been.  Keeps the slab workspaces, the batch array and
+    the table tensors alive until then."""
+
+    def __init__(self, mode, red, arr, n_grp, em, keep):
+        self.mode, self.red, self.arr, self.n_grp, self.em, self.keep = mode, red, arr, n_grp, em, keep
+
+    def plain(self):
+        L.launch("hn_mlp_wgrad_reduce", C.c_int(wgrad_mode_word(self.mode)), L.ptr(self.red[0]), C.c_int(self.red[2]),
+                 L.ptr(self.red[1]), self.arr, C.c_int(self.n_grp), C.byref(self.em) if self.em is not None else None,
+                 L.stream_handle())
+
+    def rest_table(self, grads: torch.Tensor):
+        """(device table of HnAdamRange, n) for the arena behind `grads`, or None when the launch is not a partition of
+        it (cached with the reduce tables; built outside stream captures only)."""
+        extras = self.red[3]
+        emb = None
+        if self.em is not None:
+            emb = ((int(self.em.grad) - grads.data_ptr()) // 4, int(self.em.rows), int(self.em.dim), int(self.em.col_mask))
+        key = ("rest", grads.numel(), emb)
+        hit = extras.get(key)
+        if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.HnError("fused reduce + Adam: rest table first needed inside a stream capture (run one warm-up "
+                                "step of the same shapes first)")
+            ranges = None
+            if extras["one_buffer"] and (emb is None or (0 <= emb[0] and emb[0] + emb[1] * emb[2] <= grads.numel())):
+                ranges, _ = adam_rest_ranges(extras["tiles_host"], grads.numel(), emb)
+            if ranges is None:
+                hit = (None, -1)
+            else:
+                tab = np.zeros(len(ranges), dtype=L.ADAM_RANGE_DT)
+                if len(ranges):
+                    tab["start"], tab["len"] = ranges[:, 0], ranges[:, 1]
+                hit = (L.to_device_bytes(tab, grads.device), len(ranges))
+            extras[key] = hit
+        return None if hit[1] < 0 else hit
+
+    def fused(self, adam_struct):
+        L.launch("hn_mlp_wgrad_reduce_adam", C.c_int(wgrad_mode_word(self.mode)), L.ptr(self.red[0]), C.c_int(self.red[2]),
+                 L.ptr(self.red[1]), self.arr, C.c_int(self.n_grp), C.byref(self.em) if self.em is not None else None,
+                 C.byref(adam_struct), L.stream_handle())
+
+
+# uid of a gradient arena -> weak reference to the optimizer that consumes its reduce launch (ArenaAdam(fuse_reduce=True))
+REDUCE_CONSUMERS: Dict[int, "weakref.ref"] = {}
+_PENDING_REDUCE: Dict[int, PendingReduce] = {}
+
+
+def _reduce_consumer(grads: torch.Tensor):
+    u = getattr(grads, "_hn_uid", None)
+    ref = REDUCE_CONSUMERS.get(u) if u is not None else None
+    opt = ref() if ref is not None else None
+    if ref is not None and opt is None:
+        del REDUCE_CONSUMERS[u]
+    return opt
+
+
+def take_pending_reduce(grads: torch.Tensor) -> Optional[PendingReduce]:
+    u = getattr(grads, "_hn_uid", None)
+    return _PENDING_REDUCE.pop(u, None) if u is not None else None
+
+
+def flush_pending_reduce(grads: Optional[torch.Tensor] = None):
+    """Complete the gradient buffer(s) NOW with the plain reduce launch: whoever reads a gradient arena between backward
+    and the optimizer step (an all-reduce, a test, gradient clipping) calls this first — ParamArena does for its own
+    collectives and zero_grad."""
+    if grads is not None:
+        p = take_pending_reduce(grads)
+        if p is not None:
+            p.plain()
+        return
+    for u in list(_PENDING_REDUCE):
+        _PENDING_REDUCE.pop(u).plain()
+
+
+def drop_pending_reduce():
+    _PENDING_REDUCE.clear()
 
 
 # Data-parallel overlap (training.TrainStep / bench.py with more than one rank): when set to an offset (floats) into
@@ -956,9 +1110,6 @@ def _reduce_tables(grp: Sequence["ResolvedWgrad"], device):
 # all-reduce of bucket 0's slice then runs while bucket 1 is still being computed.
 WGRAD_SPLIT_OFFSET: Optional[int] = None
 HELD_JOB_DIV = int(os.environ.get("HN_HELD_JOB_DIV", 6))
-
-
-_ORDER_CACHE: Dict[tuple, torch.Tensor] = {}
 
 
 def resolve_pending(pending: Sequence[PendingWgrad]) -> List[ResolvedWgrad]:
@@ -972,7 +1123,7 @@ def resolve_pending(pending: Sequence[PendingWgrad]) -> List[ResolvedWgrad]:
         first = True
         for b, (jd, nj, w, jh) in enumerate(p.runner.wgrad_tables(p.stash.device, p.mode, p.n_points, p.goffs, p.split, total)):
             if nj > 0:
-                out.append(ResolvedWgrad(p.mode, jd, nj, p.stash, p.grads, w, bucket=b, jobs_host=jh))
+                out.append(ResolvedWgrad(p.mode, jd, nj, p.stash, p.grads, w, bucket=b, jobs_host=jh, owner=p.runner))
                 if first:
                     out[-1].embed, first = p.embed, False
         if first and p.embed is not None:           # no job at all (cannot happen for a program with parameters)
@@ -1003,8 +1154,9 @@ def launch_resolved_wgrads(shares: Sequence[ResolvedWgrad]):
                         raise L.HnError("weight-gradient partials: more than 2^28 slab tiles in one program")
                     slabs.append(torch.empty(max(1, n_tiles) * 1024, dtype=torch.float32, device=p.stash.device))
                     arr[k].partials = slabs[-1].data_ptr()
-            key = tuple((p.jobs_dev.data_ptr(), p.n_jobs) for p in grp)
-            order = _ORDER_CACHE.get(key)
+            cache = _group_cache(grp)
+            key = ("order",) + tuple((_uid(p.jobs_dev), p.n_jobs) for p in grp)
+            order = cache.get(key)
             if order is None:
                 if torch.cuda.is_current_stream_capturing():
                     raise L.HnError("weight-gradient job order: first use of this set of programs inside a stream "
@@ -1012,16 +1164,16 @@ def launch_resolved_wgrads(shares: Sequence[ResolvedWgrad]):
                 w = np.concatenate([p.weights for p in grp])
                 ids = np.concatenate([(k << 24) | np.arange(p.n_jobs, dtype=np.int64) for k, p in enumerate(grp)])
                 order = torch.from_numpy(ids[np.argsort(-w, kind="stable")].astype(np.int32)).to(grp[0].stash.device)
-                _ORDER_CACHE[key] = order
+                cache[key] = order
             red = None
             if use_partials:
-                rkey = key + tuple(p.grads.data_ptr() for p in grp)
-                red = _REDUCE_CACHE.get(rkey)
+                rkey = ("reduce",) + key[1:] + tuple(_uid(p.grads) for p in grp)
+                red = cache.get(rkey)
                 if red is None:
                     if torch.cuda.is_current_stream_capturing():
                         raise L.HnError("weight-gradient reduce tables: first use of this set of programs inside a stream "
                                         "capture (run one warm-up step of the same shapes first)")
-                    red = _REDUCE_CACHE[rkey] = _reduce_tables(grp, grp[0].stash.device)
+                    red = cache[rkey] = _reduce_tables(grp, grp[0].stash.device)
             L.launch("hn_mlp_wgrad_batched_t", C.c_int(wgrad_mode_word(mode)), arr, C.c_int(len(grp)), L.ptr(order),
                      C.c_void_p(L.timeline_slot("hn_mlp_wgrad_batched", grp[0].stash.device)), L.stream_handle(),
                      tag="batched")
@@ -1031,9 +1183,20 @@ def launch_resolved_wgrads(shares: Sequence[ResolvedWgrad]):
                 by_table.setdefault(e["grad"].data_ptr(), []).append(e)
             tables = list(by_table.values())
             if red is not None and red[2] > 0:
-                em = _embed_struct(tables.pop(0)) if tables else None
-                L.launch("hn_mlp_wgrad_reduce", C.c_int(wgrad_mode_word(mode)), L.ptr(red[0]), C.c_int(red[2]), L.ptr(red[1]),
-                         arr, C.c_int(len(grp)), C.byref(em) if em is not None else None, L.stream_handle())
+                first = tables.pop(0) if tables else None
+                em = _embed_struct(first) if first else None
+                pend = PendingReduce(mode, red, arr, len(grp), em, (slabs, grp, first))
+                g0 = grp[0].grads
+                opt = _reduce_consumer(g0) if all(p.grads is g0 for p in grp) else None
+                if opt is not None and len(by_mode) == 1 and len(lst) <= L.HN_MAX_WGRAD_BATCH:
+                    # an optimizer consumes this arena's reduce (ArenaAdam(fuse_reduce=True)): held until its step()
+                    # — which runs it as ONE launch with the update, hn_mlp_wgrad_reduce_adam — or until anything else
+                    # needs the complete gradient (flush_pending_reduce).  At most one per arena: an earlier one (the
+                    # previous chunk's backward pass) is completed first.
+                    flush_pending_reduce(g0)
+                    _PENDING_REDUCE[_uid(g0)] = pend
+                else:
+                    pend.plain()
             for tb in tables:           # a second table in one launch, or no slabs at all: a reduce of its own
                 _launch_embed_reduce(mode, tb)
 
@@ -1060,10 +1223,11 @@ except ImportError:     # pragma: no cover
     pass
 
 
-def pack_many(runners: Sequence["MlpRunner"], device, mode: int, force: bool = False):
-    """Pack the weight streams of several programs that are about to run — the programs of one render step — with ONE
-    launch (hn_pack_units_multi) where more than one of them needs it; each runner's own `pack` then finds its streams
-    fresh.  Same rule per program as MlpRunner.pack."""
+def collect_pack_jobs(runners: Sequence["MlpRunner"], device, mode: int, force: bool = False, min_jobs: int = 2):
+    """[(mode, HnPackJob array, [(runner, tables, key)])] for the stale weight streams among `runners` — the programs of
+    one render step —, grouped for hn_pack_units_multi / hn_render_prologue (groups of fewer than `min_jobs` programs are
+    left to the program's own pack launch).  `mark_packed(group)` after the launch that packed them.  Same rule per
+    program as MlpRunner.pack."""
     todo = []
     for r in runners:
         m = r.effective_mode(mode)
@@ -1074,8 +1238,9 @@ def pack_many(runners: Sequence["MlpRunner"], device, mode: int, force: bool = F
     by_mode: Dict[int, list] = {}
     for item in todo:
         by_mode.setdefault(item[1], []).append(item)
+    out = []
     for m, items in by_mode.items():
-        if len(items) < 2:
+        if len(items) < min_jobs:
             continue                     # a single program: its own pack launch does it
         for i in range(0, len(items), L.HN_MAX_PACK_JOBS):
             grp = items[i:i + L.HN_MAX_PACK_JOBS]
@@ -1085,11 +1250,24 @@ def pack_many(runners: Sequence["MlpRunner"], device, mode: int, force: bool = F
                 arr[k].units, arr[k].ptrs, arr[k].wstream = d.units.data_ptr(), d.ptrs.data_ptr(), d.wstream.data_ptr()
                 arr[k].bias, arr[k].bias_out = d.bias_desc.data_ptr(), d.bias.data_ptr()
                 arr[k].n_units, arr[k].n_bias = d.n_units, d.n_bias
-            L.launch("hn_pack_units_multi", C.c_int(m), arr, C.c_int(len(grp)), L.stream_handle(),
-                     tag="+".join(r.prog.name for r, *_ in grp))
-            for r, _m, d, key in grp:
-                d.pack_backward = BACKWARD_SERIAL[0]
-                d.pack_key = key
+            out.append((m, arr, [(r, d, key) for r, _m, d, key in grp]))
+    return out
+
+
+def mark_packed(group):
+    for r, d, key in group:
+        d.pack_backward = BACKWARD_SERIAL[0]
+        d.pack_key = key
+
+
+def pack_many(runners: Sequence["MlpRunner"], device, mode: int, force: bool = False):
+    """Pack the weight streams of several programs that are about to run — the programs of one render step — with ONE
+    launch (hn_pack_units_multi) where more than one of them needs it; each runner's own `pack` then finds its streams
+    fresh."""
+    for m, arr, grp in collect_pack_jobs(runners, device, mode, force):
+        L.launch("hn_pack_units_multi", C.c_int(m), arr, C.c_int(len(grp)), L.stream_handle(),
+                 tag="+".join(r.prog.name for r, *_ in grp))
+        mark_packed(grp)
 
 
 class MlpRunner:
@@ -1099,6 +1277,7 @@ class MlpRunner:
         self.prog = program
         self._dev: Dict[Tuple[str, int], _DevTables] = {}
         self._jobs: Dict[Tuple[str, int, int], Tuple[torch.Tensor, int]] = {}
+        self._group_tables: Dict[tuple, object] = {}      # launch_resolved_wgrads: job order / reduce tables of the groups this runner leads
 
     def _tables(self, device, mode) -> _DevTables:
         key = (str(device), mode)

@@ -20,11 +20,24 @@ from . import _lib as L
 from .arena import ParamArena
 
 
+# A/B switch of the fused reduce + Adam launch for the callers that turn it on (TrainStep, bench.py): HN_FUSE_REDUCE=0
+FUSE_REDUCE = __import__("os").environ.get("HN_FUSE_REDUCE", "0") != "0"
+
+
 class ArenaAdam:
     def __init__(self, arena: ParamArena, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, zero_grad: bool = True, grad_scale: float = 1.0):
+                 weight_decay: float = 0.0, zero_grad: bool = True, grad_scale: float = 1.0, fuse_reduce: bool = False):
         L.require_gpu(arena.data)
         self.arena = arena
+        # fuse_reduce: consume the reduce launch of the batched weight gradient (machine.PendingReduce) — `step()` then
+        # completes the gradient and applies the update in ONE launch (hn_mlp_wgrad_reduce_adam).  Between backward() and
+        # step() the gradient buffer is then INCOMPLETE; `finish_gradients()` (or any ParamArena collective / zero_grad)
+        # completes it with the plain reduce.  Single-GPU training steps: training.TrainStep and bench.py switch it on.
+        self.fuse_reduce = bool(fuse_reduce)
+        if self.fuse_reduce:
+            import weakref
+            from . import machine
+            machine.REDUCE_CONSUMERS[machine._uid(arena.grad)] = weakref.ref(self)
         self.param_groups = [{"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay}]
         self.grad_scale = float(grad_scale)        # 1 / world size when the gradients arrive SUM-all-reduced
         self.zero_grad_in_step = zero_grad
@@ -60,10 +73,29 @@ class ArenaAdam:
         if not torch.cuda.is_current_stream_capturing():
             self.sync_hyper()
         a = self.arena
-        L.launch("hn_adam_step", L.ptr(a.data), L.ptr(a.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
-                 C.c_longlong(a.numel), L.ptr(self.hyper), L.ptr(self.step_count),
-                 C.c_int(int(self.zero_grad_in_step)), L.stream_handle())
+        from . import machine
+        pend = machine.take_pending_reduce(a.grad)
+        if pend is not None:
+            rest = pend.rest_table(a.grad) if self.fuse_reduce else None
+            if rest is None:            # not a partition of this arena (or fusion off): the two-launch form
+                pend.plain()
+                pend = None
+        if pend is not None:
+            f = L.HnAdamFuse()
+            f.params, f.grads, f.exp_avg, f.exp_avg_sq = a.data.data_ptr(), a.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+            f.n, f.hyper, f.step = a.numel, self.hyper.data_ptr(), self.step_count.data_ptr()
+            f.rest, f.n_rest, f.zero_grad = rest[0].data_ptr(), rest[1], int(self.zero_grad_in_step)
+            pend.fused(f)
+        else:
+            L.launch("hn_adam_step", L.ptr(a.data), L.ptr(a.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                     C.c_longlong(a.numel), L.ptr(self.hyper), L.ptr(self.step_count),
+                     C.c_int(int(self.zero_grad_in_step)), L.stream_handle())
         a.bump()
+
+    def finish_gradients(self):
+        """Complete the gradient buffer before step() (fuse_reduce holds the reduce launch back until then)."""
+        from . import machine
+        machine.flush_pending_reduce(self.arena.grad)
 
     def zero_grad(self, set_to_none: bool = False):
         self.arena.zero_grad()

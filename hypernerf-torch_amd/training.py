@@ -60,8 +60,11 @@ class TrainStep:
         # hn_adam_step: one launch for all parameters, clears the gradient buffer on the way out, graph-capturable
         # (on one GPU it is part of the captured step; with N>1 it follows the gradient all-reduce and scales the
         # summed gradient by 1/world itself)
+        # Without a collective between backward and the optimizer (one GPU) the launch that completes the gradient also
+        # applies the update (hn_mlp_wgrad_reduce_adam: no gradient write-back, no second pass over the arena)
+        from . import optim as _optim
         self.optimizer = ArenaAdam(self.arena, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, zero_grad=True,
-                                   grad_scale=1.0 / self.world)
+                                   grad_scale=1.0 / self.world, fuse_reduce=(not self.dp) and _optim.FUSE_REDUCE)
         # 'steplr' of the reference (utils/__init__.py:43-46): stepped once per epoch by the caller (`epoch_end`)
         self.scheduler = MultiStepLR(self.optimizer, decay_step, decay_gamma) if decay_step else None
         # any scheduler of the reference's get_scheduler (utils/__init__.py:43-59): `hparams` carries lr_scheduler

@@ -29,9 +29,10 @@ extern "C" {
 
 typedef void* hnStream_t; /* hipStream_t */
 
-#define HN_VERSION 331   /* 320: HnDwJob carries a second X slot; 321: HN_BOP_AUX w2 = tile word; 330: a level composited
+#define HN_VERSION 340   /* 320: HnDwJob carries a second X slot; 321: HN_BOP_AUX w2 = tile word; 330: a level composited
                             from two parts through a merge permutation (HnCompositeArgs.perm, hn_sample_pdf_split); 331: weight-gradient
-                            jobs flush to partial slabs + hn_mlp_wgrad_reduce (HnDwBatch.partials, HnDwJob.p_tile) */
+                            jobs flush to partial slabs + hn_mlp_wgrad_reduce (HnDwBatch.partials, HnDwJob.p_tile); 340: hn_build_config,
+                            hn_mlp_wgrad_reduce_adam (the reduce launch applies the optimizer) */
 
 /* numeric modes of the MLP machine */
 #define HN_MODE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode (<=1e-4 vs oracle) */
@@ -250,6 +251,13 @@ int hn_version(void);
 /* sizeof() of the ABI structs, in the order HnMlpArgs, HnPackUnit, HnPackBias, HnDwJob,
  * HnCompositeArgs, HnFeat, HnSlot, HnSrc — lets a foreign-language binding verify its mirror. */
 int hn_abi_sizes(int32_t* out, int n);
+/* The build-time tuning knobs of THIS library (ABI 340): out[0..] = ring depth and LDS-DMA pieces per wave and stage of
+ * hn_wgrad_kernel, bias-by-MFMA build (0/1), weight-stream chunk in units, block-read build (0/1), asymmetric weight-stream
+ * issue (0/1), waves per workgroup of the bf16 machines, cache policy of the stash stream.  Returns the number of
+ * entries.  A binding derives its host-side mirrors (job stage cuts, chunk alignment, reduce tables) from these instead of
+ * assuming the defaults. */
+#define HN_BUILD_CONFIG_N 8
+int hn_build_config(int32_t* out, int n);
 
 /* Pack fp32 nn.Linear weights (row-major (out,in), reference layout hypernerf/modules.py:99-102)
  * into MFMA A-fragment order.  ptrs: device array of source pointers. */
@@ -344,6 +352,30 @@ typedef struct {
 int hn_mlp_wgrad_reduce(int mode, const HnDwReduceTile* tiles_dev, int n_tiles, const uint32_t* list_dev,
                         const HnDwBatch* batches_host, int n_batches, const HnEmbedReduce* embed_host,
                         hnStream_t stream);
+
+/* The same launch, ALSO applying the optimizer (ABI 340; reference: train.py:116-131 configure_optimizers ->
+ * utils.get_optimizer's torch.optim.Adam, utils/__init__.py:23-41, stepped right after loss.backward()): a workgroup
+ * that has summed its destination tile updates the parameters behind it in registers (hn_adam_step's arithmetic,
+ * operation for operation) and leaves the gradient buffer zeroed (zero_grad) or completed.  Single-GPU steps only: with an
+ * all-reduce between backward and the optimizer the two-launch form stays.  `rest_dev`: the elements of the arena that
+ * no tile / bias record / table row of this launch covers, as (start, len) ranges — each is handled by one more
+ * workgroup, so that EVERY element of [0, n) is updated exactly once (the host builds and proves the partition).  All
+ * `batches[i].grads` must be `grads`, the table gradient must lie inside [grads, grads + n): -9 otherwise. */
+typedef struct {
+  int64_t start;   /* first element (floats from the arena base) */
+  int32_t len, pad;
+} HnAdamRange;
+typedef struct {
+  float* params; float* grads; float* exp_avg; float* exp_avg_sq;   /* flat arena buffers of n floats, same layout */
+  int64_t n;
+  const float* hyper;   /* device: [lr, beta1, beta2, eps, weight_decay, grad_scale, -, -], as hn_adam_step */
+  float* step;          /* device: [updates done, ticket], as hn_adam_step */
+  const HnAdamRange* rest;   /* device */
+  int32_t n_rest, zero_grad;
+} HnAdamFuse;
+int hn_mlp_wgrad_reduce_adam(int mode, const HnDwReduceTile* tiles_dev, int n_tiles, const uint32_t* list_dev,
+                             const HnDwBatch* batches_host, int n_batches, const HnEmbedReduce* embed_host,
+                             const HnAdamFuse* adam_host, hnStream_t stream);
 
 /* ---- per-ray kernels --------------------------------------------------------------------- */
 
@@ -454,6 +486,14 @@ int hn_sample_pdf_split(const float* weights, int w_ld, const float* bins, int n
                         int n_rays, int n_fine, float* z_all, float* pts, int64_t* inds, float* z_samples,
                         int32_t* perm, float* pts_new, hnStream_t stream);
 
+/* A level's compositing (hn_composite_forward) AND the inverse-CDF sampling of the next level from its weights
+ * (hn_sample_pdf_split's fused form: bins = midpoints of a->z, weights = columns 1 .. S-2 of the level's weights) as ONE
+ * launch (ABI 340; reference call order models.py:744-768): the wave that composites a ray draws its fine samples, the
+ * weights reach the sampler through LDS.  Outputs and arithmetic of both entry points, bit for bit; a->perm must be NULL. */
+int hn_composite_sample_pdf(const HnCompositeArgs* a, const float* u, const float* origins, const float* dirs, int ray_ld,
+                            int n_fine, float* z_all, float* pts, int64_t* inds, float* z_samples, int32_t* perm,
+                            float* pts_new, hnStream_t stream);
+
 /* GLO embedding lookup (modules.GLOEmbed, hypernerf/modules.py:155-167) and its gradient:
  * d_table[idx[b]] += sum_s d_embed[b, s, col0 : col0+dim]. */
 int hn_embed_gather(const float* table, const int64_t* idx, int n_rays, int dim, int n_rows,
@@ -473,6 +513,25 @@ typedef struct HnDraw {
   int32_t pad;
 } HnDraw;
 int hn_random_fill(const HnDraw* draws_host, int n_draws, uint64_t* state_dev, hnStream_t stream);
+
+/* The head of a render step as ONE launch (ABI 340): the weight streams of the step's programs (hn_pack_units_multi's
+ * jobs), all its random draws (hn_random_fill's table and device state), the coarse samples placed from the t_rand draw
+ * (hn_sample_along_rays: reference hypernerf/model_utils.py:6-41, same three separately rounded operations) and the int64
+ * image ids of the (B, 9) ray rows (prepare_ray_dict's `rays[:, 8].type(torch.long)`, model_utils.py:365-404).  Any part
+ * may be empty (n_pack = 0, n_draws = 0, p = NULL / t_rand_draw = -1 / n_ids = 0). */
+typedef struct {
+  int32_t t_rand_draw;     /* index into `draws` of the uniform (n_rays x n) buffer that is t_rand, or -1: no sampling */
+  int32_t n_rays, n, ray_ld, per_ray_bounds;
+  float scale;
+  const float* origins; const float* dirs;   /* (n_rays, >= 3) rows, stride ray_ld */
+  const float* lower; const float* upper;    /* (n) or (n_rays, n) bin bounds */
+  float* z_out; float* pts_out;              /* (n_rays, n), (n_rays, n, 3) | NULL */
+  const float* ids_src; int64_t* ids_dst;    /* ids_dst[i] = (int64) ids_src[i * ids_ld], i < n_ids */
+  int32_t ids_ld, n_ids;
+} HnPrologue;
+int hn_render_prologue(int mode, const HnPackJob* pack_jobs_host, int n_pack, const HnDraw* draws_host, int n_draws,
+                       uint64_t* state_dev, const HnPrologue* p_host, hnStream_t stream);
+
 
 /* The reference's loss head (losses.py:4-14): loss = mean((coarse - gt)^2) [+ mean((fine - gt)^2)] over (B,3) pixels,
  * one launch forward (one workgroup; the result is written, not accumulated) and one launch backward:

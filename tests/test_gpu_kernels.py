@@ -346,9 +346,11 @@ def test_random_draws_one_launch_statistics_and_replay():
 
 
 def test_model_draws_are_one_launch_and_reproducible():
-    """NerfModel.forward draws t_rand, u and both levels' noise through ONE hn_random_fill launch (no ATen RNG kernel
-    left in the step); torch.manual_seed + seed_draws reproduces a stochastic forward exactly; supplied draws are
-    honoured (the fixtures' path) and HN_FAST_DRAWS=0 falls back to torch's generator."""
+    """NerfModel.forward draws t_rand, u and both levels' noise through ONE launch (no ATen RNG kernel left in the step) —
+    since round 6 the step head, hn_render_prologue, which also packs the stale weight streams and places the coarse
+    samples (hn_random_fill / hn_pack_units_multi / hn_sample_along_rays with HN_PROLOGUE=0: the same numbers, the Philox
+    counters do not depend on the launch that hosts them); torch.manual_seed + seed_draws reproduces a stochastic forward
+    exactly; supplied draws are honoured (the fixtures' path) and HN_FAST_DRAWS=0 falls back to torch's generator."""
     from hypernerf_torch_amd.hypernerf import models as M
     HN.set_precision("fp32")
     m = M.NerfModel(EMB, n_samples_coarse=16, n_samples_fine=16, noise_std=1.0, hyper_slice_method="bendy_sheet",
@@ -364,7 +366,25 @@ def test_model_draws_are_one_launch_and_reproducible():
         names = [k.split("[")[0] for k in L.collect_kernel_times()]
     finally:
         L.KERNEL_TIMES = None
-    assert names.count("hn_random_fill") == 1
+    assert names.count("hn_render_prologue") == 1 and names.count("hn_random_fill") == 0
+    assert names.count("hn_sample_along_rays") == 0 and names.count("hn_pack_units_multi") == 0 and names.count("hn_pack_units") == 0
+    # the same forward with the head as separate launches: bit-identical (same draws, same sample arithmetic, same packing)
+    F.PROLOGUE = False
+    L.KERNEL_TIMES = {}
+    try:
+        from hypernerf_torch_amd import machine as MM
+        MM.note_parameters_changed()            # make the weight streams stale again: this pass packs them itself
+        with torch.no_grad():
+            F.seed_draws(7)
+            a2 = m(rays, {})
+        names2 = [k.split("[")[0] for k in L.collect_kernel_times()]
+    finally:
+        L.KERNEL_TIMES = None
+        F.PROLOGUE = True
+    assert names2.count("hn_random_fill") == 1 and names2.count("hn_sample_along_rays") == 1 and "hn_render_prologue" not in names2
+    for lvl in ("coarse", "fine"):
+        for k in ("rgb", "weights", "points", "warped_points", "depth"):
+            assert torch.equal(a[lvl][k], a2[lvl][k]), f"step head as one launch vs separate launches: {lvl}/{k}"
     with torch.no_grad():
         b = m(rays, {})
         F.seed_draws(7)

@@ -1313,8 +1313,29 @@ def test_rigid_body_module_surface(golden_dir):
     assert_close(Tb[:, :3, 3], p_ref, 1e-4, "rigid_body.exp_se3 translation (batched)")
     assert torch.equal(Tb[:, 3].cpu(), torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(n, 4))
     assert_close(RB.exp_so3(w[:1].reshape(3).to(DEV), th[:1].to(DEV)), R_ref[0], 1e-4, "exp_so3, the reference's (3,) call")
-    with pytest.raises(ValueError):
-        RB.exp_so3((2.0 * w).to(DEV), th.to(DEV))                     # not a unit axis
+    # inputs upstream accepts beyond unit axes (advisor, round 5): a non-unit axis is the exponential of the twist itself
+    # (rotation about w/|w| by |w| theta), w = 0 the pure translation R = I, p = theta v (upstream's own result), the
+    # reference's __main__ example ones(1,1,6) runs; the strict refusal is opt-in
+    R2 = RB.exp_so3((2.0 * w).to(DEV), th.to(DEV))
+    R2_ref, _ = O.exp_se3(torch.cat([w, v], -1), 2.0 * th)
+    assert_close(R2, R2_ref, 1e-4, "rigid_body.exp_so3 with a non-unit axis == rotation by |w| theta")
+    S0 = torch.cat([torch.zeros(n, 3), v], -1)
+    S0[::2, :3] = w[::2]                                                  # every second screw rotates, the others do not
+    T0 = RB.exp_se3(S0.to(DEV), th.to(DEV))
+    assert torch.isfinite(T0).all()
+    assert torch.equal(T0[1::2, :3, :3].cpu(), torch.eye(3).expand(len(T0[1::2]), 3, 3))
+    assert_close(T0[1::2, :3, 3], (th[:, None] * v)[1::2], 1e-6, "exp_se3 with w = 0: p = theta v")
+    assert_close(T0[::2, :3, 3], p_ref[::2], 1e-4, "exp_se3: rotating screws next to still ones")
+    Tm = RB.exp_se3(torch.ones(1, 1, 6, device=DEV), torch.full((1, 1), 0.25, device=DEV))       # rigid_body.py __main__
+    assert Tm.shape == (4, 4) and torch.isfinite(Tm).all()
+    far = RB.exp_se3(torch.cat([w, 1e6 * v], -1).to(DEV), th.to(DEV))    # R is read with v = 0: no (R e + t) - t cancellation
+    assert_close(far[:, :3, :3], R_ref, 1e-4, "exp_se3 rotation next to a translation of 1e6")
+    RB.STRICT_UNIT_AXIS = True
+    try:
+        with pytest.raises(ValueError):
+            RB.exp_so3((2.0 * w).to(DEV), th.to(DEV))                     # opt-in: not a unit axis
+    finally:
+        RB.STRICT_UNIT_AXIS = False
     hom = RB.to_homogenous(x[:, None, :].to(DEV))                        # (N,1,3) -> (4,N)
     assert hom.shape == (4, n) and torch.equal(hom[:3].T.cpu(), x) and bool((hom[3] == 1).all())
     one = RB.to_homogenous(x[:1, None, :].to(DEV))                       # the only shape upstream handles: identical

@@ -386,6 +386,7 @@ def _rccl_one_rank_worker(port, q):
             ts._forward_backward()
             if ts.dp:
                 ts.sync.reduce(None, force=True)
+            ts.optimizer.finish_gradients()     # one GPU: the reduce launch is held for the optimizer's fused launch (round 6)
             grad = ts.arena.grad.cpu().clone()
             ts.arena.zero_grad()
             start = ts.arena.data.cpu().numpy().copy()
@@ -545,6 +546,7 @@ def test_train_step_two_ranks_match_one_rank(use_graph, overlap):
     start = ts.arena.data.cpu().clone()
     ts._rays, ts._rgbs = rays.to(DEV), rgbs.to(DEV)
     ts._forward_backward()
+    ts.optimizer.finish_gradients()     # one GPU: the reduce launch is held for the optimizer's fused launch (round 6)
     ref = ts.arena.grad.cpu()
     err = float((torch.from_numpy(got[0][0]) - ref).norm() / ref.norm())
     assert err <= 1e-5, f"mean of the two shard gradients vs the full-batch gradient: rel L2 {err:.2e}"
@@ -614,6 +616,7 @@ def test_two_rank_rccl_step():
     start = ts.arena.data.cpu().clone()
     ts._rays, ts._rgbs = rays.to(DEV), rgbs.to(DEV)
     ts._forward_backward()
+    ts.optimizer.finish_gradients()     # one GPU: the reduce launch is held for the optimizer's fused launch (round 6)
     ref = ts.arena.grad.cpu()
     err = float((torch.from_numpy(got[0][0]) - ref).norm() / ref.norm())
     assert err <= 1e-5, f"mean of the two shard gradients vs the full-batch gradient: rel L2 {err:.2e}"
@@ -1010,3 +1013,75 @@ def test_eight_bit_stash_trains_and_stand_alone_modules_fall_back():
         grads[prec] = torch.cat([p.grad.flatten() for p in mm.parameters()])
     scale = float(grads["bf16"].abs().max())
     assert float((grads["bf16s8"] - grads["bf16"]).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("precision,use_graph,chunk", [("fp32", False, 1 << 20), ("bf16", True, 1 << 20), ("bf16", False, 32)],
+                         ids=["fp32-eager", "bf16-graph", "bf16-eager-two-chunks"])
+def test_reduce_fused_with_adam_equals_reduce_then_adam(precision, use_graph, chunk):
+    """Round 6: on one GPU the launch that completes the gradient also applies the optimizer (hn_mlp_wgrad_reduce_adam,
+    optim.ArenaAdam(fuse_reduce=True): TrainStep's default without a process group).  Same sums in the same order, the
+    same Adam arithmetic operation for operation: parameters, both moments, the zeroed gradient buffer and the step
+    counter are BIT-identical to the two-launch form after every one of 4 steps — also with the batch in two chunks
+    (the first chunk's reduce is completed by the plain launch, the last one's is fused).  `finish_gradients()` between
+    backward and step() yields the complete gradient."""
+    from hypernerf_torch_amd import optim, machine
+    _, _, _, rays = ray_rows(61, 64)
+    rgbs = H.uniform(61, "rgbs", (64, 3), 0.1, 0.9).to(DEV)
+    state = {}
+    for fuse in (False, True):
+        old = optim.FUSE_REDUCE
+        optim.FUSE_REDUCE = fuse
+        try:
+            m, _ = small_model(61, nc=32, nf=32, precision=precision)
+            m.use_stratified_sampling = False           # no random draws: both runs see the same samples
+            ts = TrainStep(m, lr=2e-3, use_graph=use_graph, chunk=chunk)
+            assert ts.optimizer.fuse_reduce == fuse
+            names = []
+            L_launch = HN._lib.launch
+
+            def spy(name, *a, **k):
+                names.append(name)
+                return L_launch(name, *a, **k)
+            if not use_graph:
+                HN._lib.launch = spy
+                for mod in (machine, optim):
+                    mod.L.launch = spy
+            snaps = []
+            try:
+                for _ in range(4):
+                    ts.step(rays.to(DEV), rgbs)
+                    o = ts.optimizer
+                    snaps.append([t.clone() for t in (ts.arena.data, o.exp_avg, o.exp_avg_sq, ts.arena.grad, o.step_count)])
+            finally:
+                HN._lib.launch = L_launch
+                for mod in (machine, optim):
+                    mod.L.launch = L_launch
+            state[fuse] = snaps
+            if not use_graph:
+                n_chunks = -(-64 // chunk)
+                if fuse:
+                    assert names.count("hn_mlp_wgrad_reduce_adam") == 4 and names.count("hn_adam_step") == 0
+                    assert names.count("hn_mlp_wgrad_reduce") == 4 * (n_chunks - 1)
+                else:
+                    assert names.count("hn_mlp_wgrad_reduce_adam") == 0 and names.count("hn_adam_step") == 4
+        finally:
+            optim.FUSE_REDUCE = old
+    for k, (a, b) in enumerate(zip(state[False], state[True])):
+        for what, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "gradient buffer", "step counter"), a, b):
+            assert torch.equal(x, y), f"step {k}: {what} differ between reduce -> Adam and the fused launch"
+    assert float(state[True][-1][4]) == 4.0 and not bool(state[True][-1][3].any())
+    # the complete gradient on request: backward, finish_gradients() == the two-launch form's gradient
+    grads = {}
+    for fuse in (False, True):
+        m, _ = small_model(61, nc=32, nf=32, precision=precision)
+        m.use_stratified_sampling = False
+        arena = HN.ParamArena(m.parameters())
+        opt = HN.ArenaAdam(arena, lr=1e-3, fuse_reduce=fuse)
+        from hypernerf_torch_amd.hypernerf import model_utils
+        from hypernerf_torch_amd.losses import MSELoss
+        out = m(model_utils.prepare_ray_dict(rays.to(DEV)), {})
+        F.backward(MSELoss()(out, rgbs))
+        opt.finish_gradients()
+        grads[fuse] = arena.grad.clone()
+        opt.step()
+    assert torch.equal(grads[False], grads[True]) and bool(grads[True].any())

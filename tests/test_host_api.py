@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hn_version() == 331
+    assert lib.hn_version() == 340
 
 
 def test_abi_struct_sizes_match_c():
@@ -558,3 +558,70 @@ def test_wgrad_ring_constants_mirror_the_kernel_defaults():
                 units = bps * (jobs["n_nt"] + jobs["n_kt"]) * tile_units
                 assert (bps >= 1).all() and int(units.max()) <= 8 * L.WGRAD_MAXSLOT
                 assert int(units.max()) * L.WGRAD_STAGES <= 160
+
+
+def test_adam_rest_ranges_partition_the_arena():
+    """hn_mlp_wgrad_reduce_adam steps every element of the arena exactly once only if the destinations of the reduce
+    launch (32 x 32 tiles, bias records, the gathered table's rows) plus the `rest` ranges PARTITION it:
+    machine.adam_rest_ranges proves that on the host.  Synthetic tables first (edge tiles, a masked table, an overlap that
+    must be refused), then the real job tables of the config-2 programs laid out in a ParamArena."""
+    from hypernerf_torch_amd import machine as M
+    from hypernerf_torch_amd.arena import ParamArena
+    # a 70 x 50 matrix at offset 8 (3 x 2 tiles, ragged edges), its 70 biases at 3600 (3 dZ tiles), a 10 x 8 table at 3700
+    tiles = np.zeros(7, dtype=L.DWREDUCE_DT)
+    k = 0
+    for i in range(3):
+        for j in range(2):
+            tiles[k] = (0, 8, 50, 32 * i, 32 * j, 70, 50, 0, 1)
+            k += 1
+    tiles[6] = (0, 3600, 0, 0, 3, 70, 0, 0, 1)
+    ranges, cov = M.adam_rest_ranges(tiles, 4000, (3700, 10, 8, 0b10111111))
+    assert ranges is not None and int(cov.max()) == 1
+    full = cov.astype(np.int64).copy()
+    for a, n in ranges:
+        assert 0 < n <= M.ADAM_REST_CHUNK
+        full[a:a + n] += 1
+    assert (full == 1).all()                                             # every element exactly once
+    assert cov[8:8 + 3500].all() and cov[3600:3670].all() and not cov[:8].any() and not cov[3670:3700].any()
+    assert not cov[3700 + 6:3700 + 80:8].any() and cov[3700:3700 + 6].all()      # column 6 of the table is masked out -> rest
+    big = np.zeros(1, dtype=L.DWREDUCE_DT)
+    big[0] = (0, 0, 0, 0, 200, 6400, 0, 0, 1)                           # a 6400-row bias: the rest behind it is chunked
+    ranges, _ = M.adam_rest_ranges(big, 6400 + 5000)
+    assert [int(n) for _, n in ranges] == [2048, 2048, 904] and int(ranges[0][0]) == 6400
+    dup = np.concatenate([tiles, tiles[:1]])
+    assert M.adam_rest_ranges(dup, 4000)[0] is None                     # an element that is a destination twice: no fusion
+    # the real thing: the three programs of a config-2 step on one arena
+    m = models.NerfModel(EMB, n_samples_coarse=64, n_samples_fine=64, hyper_slice_method="bendy_sheet",
+                         use_nerf_embed=True, use_alpha_cond=True)
+    arena = ParamArena(m.parameters())
+    calls = [m._level_call("coarse"), m._level_call("fine"), m._template_reuse_call("fine", m.hyper_sheet_out_dim, False, True)]
+    grp = []
+    total = sum(c.program.wgrad_stream_bytes(L.HN_MODE_BF16, 65536) for c in calls)
+    for c in calls:
+        goffs = tuple(ParamArena.lookup(c.program.params)[1])
+        # (MlpRunner.wgrad_tables' host half: it asks the runtime whether a stream capture is open, which needs a GPU)
+        jh = np.ascontiguousarray(c.program.wgrad_jobs(L.HN_MODE_BF16, 65536, grad_offsets=goffs,
+                                                       job_bytes=M.WGRAD_JOB_BYTES, launch_bytes=total))
+        tl = M.slab_tiles(jh)
+        jh["p_tile"] = np.cumsum(tl) - tl
+        grp.append(M.ResolvedWgrad(L.HN_MODE_BF16, torch.zeros(1), len(jh), arena.grad, arena.grad, None, jobs_host=jh,
+                                   owner=c.runner))
+    red = M._reduce_tables(grp, "cpu")
+    assert red[3]["one_buffer"]
+    table = m.warp_embed.embed.weight
+    emb = (ParamArena.lookup([table])[1][0], table.shape[0], table.shape[1], (1 << table.shape[1]) - 1)
+    ranges, cov = M.adam_rest_ranges(red[3]["tiles_host"], arena.numel, emb)
+    assert ranges is not None, "two destination records of one launch overlap"
+    full = cov.astype(np.int64).copy()
+    for a, n in ranges:
+        full[a:a + n] += 1
+    assert (full == 1).all()
+    covered = set()
+    for c in calls:
+        covered |= {id(p) for p in c.program.params}
+    for p, o in zip(arena.params, arena.offsets):
+        if id(p) in covered or p is table:
+            assert cov[o:o + p.numel()].all(), "a parameter of the launch's programs is not fully a destination"
+        else:
+            assert not cov[o:o + p.numel()].any()
+    assert sum(int(n) for _, n in ranges) == arena.numel - int(cov.sum())

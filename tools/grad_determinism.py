@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, hashprng as H
 import hypernerf_torch_amd as HN
 from hypernerf_torch_amd.hypernerf.models import NerfModel

@@ -1,7 +1,7 @@
 """Diagnostic (HN_PROF build): where hn_wgrad_kernel's stages spend their cycles — wait for the LDS-DMA, stage barrier,
 issue of the next stage's DMA, LDS reads + MFMAs — for wave 0 of every 97th workgroup of the batched launch."""
 import os, sys, ctypes
-ROOT='/root/repo'; sys.path[:0]=[ROOT, ROOT+'/tests']
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0]=[ROOT, ROOT+'/tests']
 import torch
 import hypernerf_torch_amd as HN
 from hypernerf_torch_amd import _lib as L
