@@ -1443,6 +1443,15 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     return;
   }
   const HnDwJob jb = jobs[job_id];
+#ifdef HN_WGRAD_JOBTIMES   // diagnostic build (tools/wg_jobtimes.py): every job stamps the 100 MHz wall clock at its entry, when its
+  // first stage has landed, behind its last product and behind its flush, with the CU it ran on — the per-CU timeline of
+  // the launch (ramp, flush, the gap to the next workgroup on that CU, the idle tail), i.e. the ceiling of what a persistent
+  // form of this kernel could recover.  Buffer from hn_set_wgrad_prof: 8 int64 per workgroup.
+  long long* jt_buf = (long long*)tab.b[HN_MAX_WGRAD_BATCH - 1].jobs;
+  const bool jt_on = jt_buf != nullptr && tab.n < HN_MAX_WGRAD_BATCH && threadIdx.x == 0;
+  unsigned long long jt0 = 0, jt1 = 0, jt2 = 0;
+  if (jt_on) jt0 = wall_clock64();
+#endif
   const int c = lane & 31, h = lane >> 5;
   const int gn = jb.pad & 255, gk = (jb.pad >> 8) & 255, bps = (jb.pad >> 16) & 255;
   const int tn = (jb.n_nt + gn - 1) / gn, tk = (jb.n_kt + gk - 1) / gk;   // tiles per wave (<= 4, <= 2)
@@ -1567,6 +1576,9 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone finished stage s-1
     __builtin_amdgcn_sched_barrier(0);
+#ifdef HN_WGRAD_JOBTIMES
+    if (jt_on && s == 0) jt1 = wall_clock64();
+#endif
 #ifdef HN_PROF
     if (prof_on) HN_TS(t2_);
 #endif
@@ -1660,6 +1672,9 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
     if (prof_on) { HN_TS(t4_); tw += t1_ - t0_; tb += t2_ - t1_; ti += t3_ - t2_; tc += t4_ - t3_; }
 #endif
   }
+#ifdef HN_WGRAD_JOBTIMES
+  if (jt_on) jt2 = wall_clock64();
+#endif
 #ifdef HN_PROF
   if (prof_on && lane == 0) {
     long long* o = prof_buf + (blockIdx.x / 97) * 8;
@@ -1764,6 +1779,18 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
           if (row >= 0 && row < jb.r_end) atomicAdd(gb + row, S8 ? accb[i % NB][q] * tab.unscale : accb[i % NB][q]);
         }
   }
+#ifdef HN_WGRAD_JOBTIMES
+  __syncthreads();      // every wave's stores are issued
+  if (jt_on) {
+    unsigned hw = 0, xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    long long* o = jt_buf + (size_t)blockIdx.x * 8;
+    o[0] = (long long)hw | ((long long)(xcc & 15u) << 32);
+    o[1] = (long long)jt0; o[2] = (long long)jt1; o[3] = (long long)jt2; o[4] = (long long)wall_clock64();
+    o[5] = (long long)nstage * (long long)stage_bytes; o[6] = jb.n_nt * 16 + jb.n_kt; o[7] = 1;
+  }
+#endif
   hn_timeline_end(tab.timeline);
 }
 
@@ -2014,6 +2041,9 @@ struct HnAdamFuseDev {
 #ifndef HN_REDUCE_SPLIT
 #define HN_REDUCE_SPLIT 1      /* parts a destination tile's slab list is summed in (workgroup = SPLIT x 256 threads) */
 #endif
+#ifndef HN_REDUCE_INFLIGHT
+#define HN_REDUCE_INFLIGHT 8   /* slab loads a thread keeps in flight */
+#endif
 template <bool S8, bool ADAM>
 __global__ __launch_bounds__(256 * HN_REDUCE_SPLIT) void hn_wgrad_reduce_kernel(const HnDwReduceTile* __restrict__ tiles, int n_tiles,
                                                               const uint32_t* __restrict__ list, const HnDwReduceTable tab,
@@ -2036,7 +2066,11 @@ __global__ __launch_bounds__(256 * HN_REDUCE_SPLIT) void hn_wgrad_reduce_kernel(
       hn_adam_update(K, A.p[i], g, A.m[i], A.v[i]);
       *Gp = A.zero_grad ? 0.0f : g;
     } else {
+#if defined(HN_REDUCE_ATOMIC) && HN_REDUCE_ATOMIC
       atomicAdd(Gp, add);
+#else
+      *Gp += add;      // one writer per element in this launch, every other launch is ordered before or behind it
+#endif
     }
   };
   // (with HN_REDUCE_SPLIT > 1 the table-row, bias and rest paths run on the first 256 threads; every barrier below is
@@ -2053,24 +2087,35 @@ __global__ __launch_bounds__(256 * HN_REDUCE_SPLIT) void hn_wgrad_reduce_kernel(
     float acc[32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) acc[c] = 0.0f;
-    for (int sIdx = 0; first256 && sIdx < em.n_src; ++sIdx) {
-      const float* P = em.partial[sIdx];
-      const int64_t* idx = em.idx[sIdx];
-      const int nb = em.n_blocks[sIdx], spr = em.samples_per_ray[sIdx];
-      const int bpr = spr / 32;                         // blocks per ray (this path: samples_per_ray % 32 == 0)
-      const int n_rays = nb / bpr;
-      for (int r0 = threadIdx.x; r0 < n_rays; r0 += 4 * 256) {
-        long long id[4];
+    // (round 6) wave w takes programs w, w + 4, ...: the programs' load chains — ray index, then the blocks' partial rows
+    // — run side by side instead of one after the other (three programs in a training step: 9 dependent memory latencies
+    // became 3; these workgroups were the tail of the launch).  Lane l takes rays l, l + 64, ... of its program, sixteen
+    // index loads in flight.  Still a fixed order: lane sums, the shuffle tree, then the waves in order.
+    {
+      const int lane_ = threadIdx.x & 63, wave_ = (threadIdx.x >> 6) & 3;
+#ifdef HN_REDUCE_EXP_NOEMBED      /* timing-only experiment: the table rows do no work (their gradient is WRONG) */
+      for (int sIdx = wave_; first256 && sIdx < 0; sIdx += 4) {
+#else
+      for (int sIdx = wave_; first256 && sIdx < em.n_src; sIdx += 4) {
+#endif
+        const float* P = em.partial[sIdx];
+        const int64_t* idx = em.idx[sIdx];
+        const int nb = em.n_blocks[sIdx], spr = em.samples_per_ray[sIdx];
+        const int bpr = spr / 32;                         // blocks per ray (this path: samples_per_ray % 32 == 0)
+        const int n_rays = nb / bpr;
+        for (int r0 = lane_; r0 < n_rays; r0 += 16 * 64) {     // 1024 rays (a config-2 batch) = ONE round of index loads
+          long long id[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) id[u] = (r0 + 256 * u < n_rays) ? (long long)idx[r0 + 256 * u] : -1ll;
+          for (int u = 0; u < 16; ++u) id[u] = (r0 + 64 * u < n_rays) ? (long long)idx[r0 + 64 * u] : -1ll;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (id[u] != row) continue;
-          for (int k = 0; k < bpr; ++k) {
-            const size_t b = (size_t)(r0 + 256 * u) * bpr + k;
+          for (int u = 0; u < 16; ++u) {
+            if (id[u] != row) continue;
+            for (int k = 0; k < bpr; ++k) {
+              const size_t b = (size_t)(r0 + 64 * u) * bpr + k;
 #pragma unroll
-            for (int c = 0; c < 32; ++c)
-              if (c < em.dim && ((em.col_mask >> c) & 1u)) acc[c] += P[b * em.dim + c];
+              for (int c = 0; c < 32; ++c)
+                if (c < em.dim && ((em.col_mask >> c) & 1u)) acc[c] += P[b * em.dim + c];
+            }
           }
         }
       }
@@ -2102,13 +2147,22 @@ __global__ __launch_bounds__(256 * HN_REDUCE_SPLIT) void hn_wgrad_reduce_kernel(
       if (first256 && !(i_n >= t.col0 || row < 0 || row >= t.r_end)) {
         const int off = i_n * 32 + rr;
         float sb = 0.0f;
-        for (int k = 0; k < t.count; ++k) {
-          const uint32_t e = list[t.first + k];
-          float* P = tab.partials[0];
+        for (int k0 = 0; k0 < t.count; k0 += 8) {         // eight slab loads in flight (a load-add chain of up to 40 before)
+          float v[8];
 #pragma unroll
-          for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
-            if ((int)(e >> 28) == i) P = tab.partials[i];
-          sb += P[(size_t)(e & 0x0fffffffu) * 1024 + off];
+          for (int u = 0; u < 8; ++u) {
+            v[u] = 0.0f;
+            if (k0 + u < t.count) {
+              const uint32_t e = list[t.first + k0 + u];
+              float* P = tab.partials[0];
+#pragma unroll
+              for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
+                if ((int)(e >> 28) == i) P = tab.partials[i];
+              v[u] = P[(size_t)(e & 0x0fffffffu) * 1024 + off];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) sb += v[u];          // fixed order: slab k0, k0 + 1, ...
         }
         float* Gb = tab.grads[0];
 #pragma unroll
@@ -2151,10 +2205,11 @@ __global__ __launch_bounds__(256 * HN_REDUCE_SPLIT) void hn_wgrad_reduce_kernel(
         }
       }
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
-      for (int k0 = part; k0 < t.count; k0 += 8 * SP) {
-        f32x4 v[8];
+      constexpr int NF = HN_REDUCE_INFLIGHT;
+      for (int k0 = part; k0 < t.count; k0 += NF * SP) {
+        f32x4 v[NF];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NF; ++u) {
           v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
           const int k = k0 + u * SP;
           if (k < t.count) {
@@ -2167,7 +2222,7 @@ __global__ __launch_bounds__(256 * HN_REDUCE_SPLIT) void hn_wgrad_reduce_kernel(
           }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];          // fixed order: slab k0, k0 + SPLIT, ...
+        for (int u = 0; u < NF; ++u) s += v[u];          // fixed order: slab k0, k0 + SPLIT, ...
       }
       float tot[EPT];
       if (SP > 1) {
@@ -2192,7 +2247,11 @@ __global__ __launch_bounds__(256 * HN_REDUCE_SPLIT) void hn_wgrad_reduce_kernel(
           g4[j] += tot[j];
           hn_adam_update(K, p4[j], g4[j], m4[j], v4[j]);
         } else {
+#if defined(HN_REDUCE_ATOMIC) && HN_REDUCE_ATOMIC
           atomicAdd(gp[j], tot[j]);
+#else
+          *gp[j] += tot[j];
+#endif
         }
       }
       if (ADAM) {
@@ -2275,7 +2334,7 @@ extern "C" int hn_mlp_wgrad_reduce_adam(int mode, const HnDwReduceTile* tiles, i
   return hn_launch_reduce(mode, tiles, n_tiles, list, batches, n_batches, embed, adam, stream);
 }
 
-#ifdef HN_PROF
+#if defined(HN_PROF) || defined(HN_WGRAD_JOBTIMES)
 static void* hn_wgrad_prof = nullptr;
 extern "C" void hn_set_wgrad_prof(void* p) { hn_wgrad_prof = p; }     // diagnostic builds only: (64, 8) int64 buffer
 #endif
@@ -2346,7 +2405,7 @@ extern "C" int hn_mlp_wgrad_batched_t(int mode, const HnDwBatch* batches, int n_
   }
   tab.order = order_dev;
   tab.timeline = timeline_dev;
-#ifdef HN_PROF
+#if defined(HN_PROF) || defined(HN_WGRAD_JOBTIMES)
   if (hn_wgrad_prof != nullptr && tab.n < HN_MAX_WGRAD_BATCH) tab.b[HN_MAX_WGRAD_BATCH - 1].jobs = (const HnDwJob*)hn_wgrad_prof;
 #endif
   if (total == 0) return 0;

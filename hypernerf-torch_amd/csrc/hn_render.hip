@@ -182,9 +182,9 @@ struct HnPartRow {
   size_t row;
   bool second;
 };
-HN_DEV HnPartRow hn_part_row(const HnCompositeArgs& a, int ray, size_t row, int s) {
+HN_DEV HnPartRow hn_part_row(const HnCompositeArgs& a, int ray, size_t row, int s, const int* perm_lds = nullptr) {
   if (a.perm == nullptr) return HnPartRow{row + s, false};
-  const int k = a.perm[row + s];
+  const int k = perm_lds != nullptr ? perm_lds[s] : a.perm[row + s];
   if (k < a.split) return HnPartRow{(size_t)ray * a.split + k, false};
   return HnPartRow{(size_t)ray * (a.n_samples - a.split) + (k - a.split), true};
 }
@@ -192,7 +192,7 @@ HN_DEV HnPartRow hn_part_row(const HnCompositeArgs& a, int ray, size_t row, int 
 // One ray's compositing on one wave.  `w_lds` (forward only, optional): the ray's weights are ALSO left in LDS there — the
 // inverse-CDF sampler of the same wave reads them from it (hn_composite_pdf_kernel).
 template <bool BACKWARD>
-HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float* w_lds) {
+HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float* w_lds, int* perm_lds = nullptr) {
   const int S = a.n_samples;
   const int nseg = (S + 63) / 64;
   const size_t row = (size_t)ray * S;
@@ -201,6 +201,14 @@ HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float*
   const float eps = a.variant != 1 ? 1e-5f : 1e-10f;
   const float last = a.variant != 1 ? (a.sample_at_infinity ? 1e7f : 1e-7f) : 1e10f;
 
+  // a level in two parts: the merge permutation is staged in LDS once (round 6) — a sample's rgb / density address then
+  // depends on no other global load (perm, then the row: two memory latencies per segment and direction before)
+  if (a.perm == nullptr) perm_lds = nullptr;
+  if (perm_lds != nullptr) {
+    for (int i = lane; i < S; i += 64) perm_lds[i] = a.perm[row + i];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
   float alpha[HN_MAX_SEG], om[HN_MAX_SEG], trans[HN_MAX_SEG], wgt[HN_MAX_SEG], pre[HN_MAX_SEG], dist[HN_MAX_SEG];
   float carry = 1.0f;   // product of (1-alpha+eps) over all earlier segments
   float csum = 0.0f;    // running sum of weights (median depth)
@@ -212,14 +220,18 @@ HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float*
     if (k < nseg) {
       const int s = k * 64 + lane;
       const bool in = s < S;
-      float zz = 0.f, zn = 0.f, raw = 0.f;
+      float zz = 0.f, zn = 0.f, raw = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
       HnPartRow pr{row, false};
       if (in) {
         zz = a.z[row + s];
         zn = (s + 1 < S) ? a.z[row + s + 1] : 0.f;
-        pr = hn_part_row(a, ray, row, s);
+        pr = hn_part_row(a, ray, row, s, perm_lds);
         raw = (pr.second ? a.raw1 : a.raw)[pr.row];
         if (a.noise != nullptr) raw = __fadd_rn(raw, __fmul_rn(a.noise[row + s], a.noise_scale));
+        if (!BACKWARD) {      // the sample's colour with the same round of loads (behind the weight store further down the
+          const float* c = (pr.second ? a.rgb1 : a.rgb) + pr.row * 3;      // compiler cannot hoist it: one more latency)
+          cr = c[0]; cg = c[1]; cb = c[2];
+        }
       }
       const float dz = (s + 1 < S) ? (zn - zz) : last;
       const float dd = dz * dnorm;
@@ -244,10 +256,9 @@ HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float*
         if (in) {
           a.out_weights[row + s] = w;
           if (w_lds != nullptr) w_lds[s] = w;
-          const float* c = (pr.second ? a.rgb1 : a.rgb) + pr.row * 3;
-          s_r += w * c[0];
-          s_g += w * c[1];
-          s_b += w * c[2];
+          s_r += w * cr;
+          s_g += w * cg;
+          s_b += w * cb;
           s_d += w * zz;
           s_w += w;
           if (s < S - 1) s_wl += w;
@@ -261,7 +272,7 @@ HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float*
             med_z = __shfl(zz, first, 64);
             const int sidx = k * 64 + first;
             if (a.warped != nullptr) {
-              const HnPartRow mp = hn_part_row(a, ray, row, sidx);
+              const HnPartRow mp = hn_part_row(a, ray, row, sidx, perm_lds);
               med_pt = (mp.second ? a.warped1 : a.warped)[mp.row * a.warped_ld];
             }
             med_found = true;
@@ -273,13 +284,35 @@ HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float*
   }
   if (!BACKWARD && a.out_warped != nullptr) {
     // the level's `warped_points` in sorted order, gathered from the parts: the ray's S x ld floats as ONE contiguous
-    // run — lane-consecutive stores (a row per lane would scatter 28-byte pieces over the wave's store)
+    // run — lane-consecutive stores (a row per lane would scatter 28-byte pieces over the wave's store).  The merge
+    // permutation is staged in LDS first (round 6): an element's source address then depends on no global load, and the
+    // wave keeps eight gathers in flight — the loop used to pay two dependent memory latencies (perm, then the row) for
+    // each of its S ld / 64 rounds: 10 of the launch's 15 us at config 2.
     const int ld = a.warped_ld, n = S * ld;
-    float* wdst = a.out_warped + row * ld;
-    for (int e = lane; e < n; e += 64) {
-      const int s = e / ld, cc = e - s * ld;
-      const HnPartRow pr = hn_part_row(a, ray, row, s);
-      wdst[e] = (pr.second ? a.warped1 : a.warped)[pr.row * ld + cc];
+    float* __restrict__ wdst = a.out_warped + row * ld;
+    const float* __restrict__ w0 = a.warped + (size_t)ray * a.split * ld;
+    const float* __restrict__ w1 = a.warped1 + (size_t)ray * (S - a.split) * ld;
+    if (perm_lds != nullptr) {
+      for (int e0 = lane; e0 < n; e0 += 64 * 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int e = e0 + 64 * j;
+          if (e < n) {
+            const int s = e / ld, cc = e - s * ld, k = perm_lds[s];
+            v[j] = k < a.split ? w0[k * ld + cc] : w1[(k - a.split) * ld + cc];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (e0 + 64 * j < n) wdst[e0 + 64 * j] = v[j];
+      }
+    } else {
+      for (int e = lane; e < n; e += 64) {
+        const int s = e / ld, cc = e - s * ld;
+        const HnPartRow pr = hn_part_row(a, ray, row, s);
+        wdst[e] = (pr.second ? a.warped1 : a.warped)[pr.row * ld + cc];
+      }
     }
   }
   if (!BACKWARD) {
@@ -297,7 +330,7 @@ HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float*
         if (a.out_med_points != nullptr) {
           float first_pt = 0.0f;
           if (a.warped != nullptr) {
-            const HnPartRow mp = hn_part_row(a, ray, row, 0);
+            const HnPartRow mp = hn_part_row(a, ray, row, 0, perm_lds);
             first_pt = (mp.second ? a.warped1 : a.warped)[mp.row * a.warped_ld];
           }
           a.out_med_points[ray] = med_found ? med_pt : first_pt;
@@ -324,7 +357,7 @@ HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float*
       float dw = 0.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
       HnPartRow pr{row, false};
       if (in) {
-        pr = hn_part_row(a, ray, row, s);
+        pr = hn_part_row(a, ray, row, s, perm_lds);
         const float* c = (pr.second ? a.rgb1 : a.rgb) + pr.row * 3;
         c0 = c[0]; c1 = c[1]; c2 = c[2];
         dw = gr * c0 + gg * c1 + gb * c2 + gd * a.z[row + s] + gbg;
@@ -362,10 +395,11 @@ HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float*
 }
 template <bool BACKWARD>
 __global__ __launch_bounds__(256) void hn_composite_kernel(const HnCompositeArgs a) {
+  __shared__ int s_perm[4][64 * HN_MAX_SEG];
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= a.n_rays) return;
-  hn_composite_ray<BACKWARD>(a, ray, lane, nullptr);
+  hn_composite_ray<BACKWARD>(a, ray, lane, nullptr, s_perm[threadIdx.x >> 6]);
 }
 
 static int hn_check_comp(const HnCompositeArgs* a, bool bwd) {
@@ -555,6 +589,62 @@ HN_DEV void hn_pdf_ray(const HnPdfArgs& q, int ray, int lane, const float* wr, f
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   for (int i = lane; i < nmerge; i += 64) srt[i] = zr[i];
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  // Merge by RANK (round 6) when the level's own depths arrive sorted and every value is a number — what the render path
+  // always hands over (stratified / previous-level depths): the sorted position of an entry of cat(z, z_samples) is the
+  // number of entries before it in (depth, position) order, which each lane COUNTS for its own entries — a coarse depth k
+  // stands behind k coarse depths and behind the new samples below it; new sample i behind the coarse depths <= it
+  // (binary search) and the new samples below it or equal with a smaller index — then scatters them to that position in
+  // LDS.  The same sequence, bit for bit, as the (depth, position) bitonic sort below — which stays for any other input —
+  // in 2 LDS passes instead of log2(n)(log2(n)+1)/2 = 28 rounds of compare-exchange at 128 entries (16 -> 10 us a launch).
+  bool fast = true;
+  for (int i = lane; i < total; i += 64) {
+    const float x = srt[i];
+    fast = fast && (x == x) && !(i + 1 < nmerge && !(x <= srt[i + 1]));
+  }
+  if (__ballot(!fast) == 0ull) {
+    float xs[12];
+    int rk[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {          // this lane's coarse depths: entries lane + 64 k
+      const int i = lane + 64 * k;
+      if (i < nmerge) {
+        const float x = srt[i];
+        int c = i;
+        for (int j = 0; j < nf; ++j) c += srt[nmerge + j] < x ? 1 : 0;
+        xs[k] = x; rk[k] = c;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {          // this lane's new samples
+      const int i = lane + 64 * k;
+      if (i < nf) {
+        const float x = srt[nmerge + i];
+        int lo = 0, hi = nmerge;           // coarse depths <= x (they all stand at smaller positions: ties count)
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (srt[mid] <= x) lo = mid + 1; else hi = mid;
+        }
+        int c = lo;
+        for (int j = 0; j < nf; ++j) {
+          const float y = srt[nmerge + j];
+          c += (y < x || (y == x && j < i)) ? 1 : 0;
+        }
+        xs[4 + k] = x; rk[4 + k] = c;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();       // every lane has read what it needs: the buffer becomes the output
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lane + 64 * k < nmerge) { srt[rk[k]] = xs[k]; if (PERM) sidx[rk[k]] = lane + 64 * k; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (lane + 64 * k < nf) { srt[rk[4 + k]] = xs[4 + k]; if (PERM) sidx[rk[4 + k]] = nmerge + lane + 64 * k; }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  } else {
   // pad to a power of two with +inf and bitonic-sort ascending
   int n2 = 1;
   while (n2 < total) n2 <<= 1;
@@ -582,6 +672,7 @@ HN_DEV void hn_pdf_ray(const HnPdfArgs& q, int ray, int lane, const float* wr, f
       __builtin_amdgcn_s_waitcnt(0);
       __builtin_amdgcn_wave_barrier();
     }
+  }
   }
   for (int i = lane; i < total; i += 64) {
     const float zz = srt[i];

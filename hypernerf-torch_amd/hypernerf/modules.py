@@ -105,6 +105,29 @@ class MLP(nn.Module):
         if self.output_init is not None:
             self.output_init(self.logit_layer.weight)
         self._calls = {}
+        self._check_machine_limits()
+
+    def _check_machine_limits(self):
+        """What the HIP MLP machine does not run is refused HERE, at construction — before a mis-configured model reaches
+        the GPU (round 6; the first forward raised before).  The reference's own configurations all pass (ReLU hidden
+        layers, Identity / Sigmoid heads, width <= 256: modules.py:62-114, models.py:139-166).  INTEGRATION.md lists these."""
+        name = type(self).__name__
+        if _act_name(self.hidden_activation, name) != "relu":
+            raise NotImplementedError(f"{name}: hidden_activation {type(self.hidden_activation).__name__}: the hidden layers "
+                                      "of the HIP MLP machine are ReLU (mask bit + v_max on the bit pattern)")
+        out_act = _act_name(self.output_activation, name)           # raises for anything but Identity / ReLU / Sigmoid
+        if self.width > 256:
+            raise NotImplementedError(f"{name}: width {self.width} > 256 — a wave carries one hidden vector of <= 256 "
+                                      "features (64 VGPRs in bf16) through the layers in registers; not a host-side limit")
+        if self.width < 1 or self.depth < 0 or self.in_ch < 1 or self.out_ch < 1:
+            raise ValueError(f"{name}: in_ch, out_ch, width >= 1 and depth >= 0")
+        if self.out_ch > 256:
+            raise NotImplementedError(f"{name}: out_ch {self.out_ch} > 256 (one layer = <= 8 tiles of 32 rows)")
+        if self.out_ch > 4 and out_act == "sigmoid":
+            raise NotImplementedError(f"{name}: Sigmoid on an output of {self.out_ch} > 4 columns (the sigmoid lives in the "
+                                      "narrow-head epilogue: rgb / alpha heads)")
+        if self.in_ch > 64 * L.HN_AUXG_MAX:
+            raise NotImplementedError(f"{name}: in_ch {self.in_ch} > {64 * L.HN_AUXG_MAX} input features of one layer")
 
     def _call(self, need_input_grad: bool) -> F.ProgramCall:
         call = self._calls.get(need_input_grad)
@@ -198,6 +221,13 @@ class NerfMLP(nn.Module):
         self.alpha_mlp = nn.Linear(alpha_brach_width + alpha_condition_dim, alpha_channels)
         nn.init.xavier_uniform_(self.alpha_mlp.weight)
         self._calls = {}
+        # refused at construction (round 6), not at the first forward: the rgb head is a narrow (<= 4 column) head of the
+        # machine — Identity or Sigmoid (models.py:164, 288) —, the trunk feeds the bottleneck at trunk_width // 2
+        if _act_name(self.rgb_mlp.output_activation, "NerfMLP.rgb_mlp") == "relu":
+            raise NotImplementedError("NerfMLP: rgb_activation ReLU (a ReLU on a <= 4-column head is not implemented in "
+                                      "the HIP MLP machine; the reference uses Sigmoid / Identity)")
+        if rgb_channels > 4 or alpha_channels > 4:
+            raise NotImplementedError("NerfMLP: rgb_channels / alpha_channels > 4 (narrow heads of the HIP MLP machine)")
 
     def broadcast_condition(self, c, num_samples):
         if c.dim() == 2:
