@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("HN_LIB_PATH") or PRODUCT_LIB_PATH
 SOURCES = ["hn_mlp.hip", "hn_render.hip", "hn_calib.hip"]
 CSRC_HEADERS = ["hn_common.h", "hn_pack.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hn_kernels.h")
-BUILD_MACROS = ("HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX", "HN_WGRAD_EXP", "HN_WGRAD_BIAS_MFMA", "HN_WGRAD_BLOCK", "HN_WGRAD_STAGES", "HN_WGRAD_MAXSLOT", "HN_WSTREAM_ASYM")     # build-time tuning knobs (A/B experiments)
+BUILD_MACROS = ("HN_WGRAD_PERSIST", "HN_REDUCE_SPLIT", "HN_BF16_WAVES", "HN_PROF", "HN_CHUNK_UNITS", "HN_WGRAD_AUX", "HN_WGRAD_EXP", "HN_WGRAD_BIAS_MFMA", "HN_WGRAD_BLOCK", "HN_WGRAD_STAGES", "HN_WGRAD_MAXSLOT", "HN_WSTREAM_ASYM")     # build-time tuning knobs (A/B experiments)
 
 HN_MODE_F32, HN_MODE_BF16, HN_MODE_BF16_S8 = 0, 1, 2
 BUILD_CONFIG_KEYS = ("WGRAD_STAGES", "WGRAD_MAXSLOT", "WGRAD_BIAS_MFMA", "CHUNK_UNITS", "WGRAD_BLOCK", "WSTREAM_ASYM",

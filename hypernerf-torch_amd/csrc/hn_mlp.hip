@@ -1794,6 +1794,290 @@ __global__ __launch_bounds__(512, 2) void hn_wgrad_kernel(const HnDwBatchTable t
   hn_timeline_end(tab.timeline);
 }
 
+#ifdef HN_WGRAD_PERSIST
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT BUILD ONLY (-DHN_WGRAD_PERSIST=1; round 6, verdict item 3 — measured and CLOSED, profiles/r06_wgrad_persistent.md):
+// a persistent form of the weight-gradient launch.  It does what it was built for — per job, ramp 4.1 -> 1.5 us, workgroup
+// turnover 12.8 -> 0 us, 5.8 % of launch x CUs of idle time gone (tools/wg_jobtimes.py) — and the launch is no faster
+// (0.575 against 0.550 ms, same box, alternating): the stream is bound by the AGGREGATE HBM rate, a CU that pauses between
+// two jobs leaves its share to the others, and hiding the pause only stretches every job's own streaming time (0.855 ->
+// 0.907 of launch x CUs).  What is really lost is the idle tail behind each CU's last job (7-8 %), which this form does
+// not touch.  Not compiled into the product library.
+// The same weight-gradient jobs, PERSISTENT form (round 6; bf16 stash, 2-stage ring, block reads): one workgroup per CU
+// walks the host-ordered job list through a device ticket.  tools/wg_jobtimes.py (profiles/r06_wgrad_jobtimes.log) had put
+// numbers on what one-workgroup-per-job leaves on the table at config 2: 4.1 us of ramp per job (entry -> first stage
+// landed), 1.1 us of flush, and 12.8 us between a job's exit and the next workgroup's entry on the same CU (dispatch of a
+// 512-thread / 128-KiB workgroup + two dependent descriptor loads) = 7.2 % of launch x CUs.  Here the ring runs ACROSS
+// jobs: while the last stage of job j is being multiplied, the first stage of job j + 1 — claimed and its descriptor
+// loaded one job ahead — is already on its way into the other buffer (the slot tables of job j are dead once its last
+// stage has been issued, so they are re-decoded in place: no second set of registers), and the slab stores of job j drain
+// under it.  Same products, same slabs, same reduce: results bit-identical to hn_wgrad_kernel<true>.
+// ------------------------------------------------------------------------------------------------
+struct HnDwCur {           // what a job's stages and flush need of its descriptor + geometry: wave-uniform, 27 scalar registers
+  int bps, n0, k0, my_n, my_k, UB, nb, nstage, blk0, blk1, n_nt, n_kt;
+  int w_off, p_tile, b_off, r0, c0, r_end, c_end, ld;
+  unsigned zstride, xstride, x2stride, bias_mask;
+  const char* stash; float* grads; float* partials;
+};
+__global__ __launch_bounds__(512, 2) void hn_wgrad_persist_kernel(const HnDwBatchTable tab, unsigned* __restrict__ ticket,
+                                                                  int total) {
+  hn_timeline_begin(tab.timeline);
+  using Fr = DwFrag<true>;
+  constexpr int TU = ModeT<true>::TILE_UNITS;
+  constexpr int TBc = TU * 1024;
+  constexpr size_t TB = TBc;
+  constexpr int MAXSLOT = HN_WGRAD_MAXSLOT;
+  constexpr unsigned BUF = 8u * MAXSLOT * 1024u;      // bytes per ring buffer: fixed (jobs differ in their stage size)
+  constexpr unsigned TK = (unsigned)(TBc / 1024);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_next = reinterpret_cast<int*>(smem + 2 * BUF);      // two words behind the ring (dynamic LDS: 2 x BUF + 64)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int G = (int)gridDim.x;
+  int tro0 = 0, tro1 = 0;
+  hn_dw_tr_offsets(lane, tro0, tro1);
+
+  // per-wave LDS-DMA slots of one stage (hn_wgrad_kernel's tables)
+  unsigned sbase[MAXSLOT];
+  int sinfo[MAXSLOT];
+  // job `g` of the launch's global order: its descriptor is read, boiled down to `q` (geometry of this wave, flush
+  // destination, batch pointers) and to the slot tables — the descriptor itself is dead afterwards
+  auto prepare = [&](int g, HnDwCur& q) __attribute__((always_inline)) {
+    int job_id = g, which = 0;
+    if (tab.order != nullptr) {
+      const int o = __builtin_amdgcn_readfirstlane(tab.order[g]);
+      which = o >> 24;
+      job_id = o & 0xffffff;
+    } else {
+#pragma unroll
+      for (int i = 0; i < HN_MAX_WGRAD_BATCH - 1; ++i)
+        if (which == i && i + 1 < tab.n && job_id >= tab.b[i].n_jobs) { job_id -= tab.b[i].n_jobs; which = i + 1; }
+    }
+    const HnDwJob* jobs = tab.b[0].jobs;
+    q.stash = reinterpret_cast<const char*>(tab.b[0].stash); q.grads = tab.b[0].grads; q.partials = tab.b[0].partials;
+#pragma unroll
+    for (int i = 1; i < HN_MAX_WGRAD_BATCH; ++i)
+      if (which == i) { jobs = tab.b[i].jobs; q.stash = reinterpret_cast<const char*>(tab.b[i].stash); q.grads = tab.b[i].grads; q.partials = tab.b[i].partials; }
+    const HnDwJob jd = jobs[job_id];
+    const int gn = jd.pad & 255, gk = (jd.pad >> 8) & 255;
+    q.bps = (jd.pad >> 16) & 255;
+    const int tn = (jd.n_nt + gn - 1) / gn, tk = (jd.n_kt + gk - 1) / gk;
+    const int wn = wave / gk, wk = wave % gk;
+    q.n0 = wn * tn; q.k0 = wk * tk;
+    q.my_n = wn < gn ? min(tn, jd.n_nt - q.n0) : 0;
+    q.my_k = min(tk, jd.n_kt - q.k0);
+    q.UB = TU * (jd.n_nt + jd.n_kt);
+    q.nb = jd.blk1 - jd.blk0;
+    q.nstage = (q.nb + q.bps - 1) / q.bps;
+    q.blk0 = jd.blk0; q.blk1 = jd.blk1; q.n_nt = jd.n_nt; q.n_kt = jd.n_kt;
+    q.w_off = jd.w_off; q.p_tile = jd.p_tile; q.b_off = jd.b_off; q.r0 = jd.r0; q.c0 = jd.c0; q.r_end = jd.r_end;
+    q.c_end = jd.c_end; q.ld = jd.ld;
+    q.zstride = (unsigned)jd.z_nt * TK; q.xstride = (unsigned)jd.x_nt * TK; q.x2stride = (unsigned)jd.x2_nt * TK;
+    q.bias_mask = 0;
+    if (jd.b_off >= 0 && q.my_n > 0)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < q.my_n && (i % gk) == wk) q.bias_mask |= 1u << i;
+#pragma unroll
+    for (int i = 0; i < MAXSLOT; ++i) {
+      const int qq = wave + 8 * i;
+      sinfo[i] = 1 << 30;
+      sbase[i] = 0;
+      if (qq < q.bps * q.UB) {
+        const int bi = qq / q.UB, r = qq % q.UB;
+        const int tile = r / TU, u = r % TU;
+        const bool isz = tile < jd.n_nt;
+        const int kt = tile - jd.n_nt;
+        const bool isx2 = !isz && kt >= jd.n_kt1;
+        const unsigned rel = isz ? ((unsigned)bi * jd.z_nt + jd.z_t0 + tile) * TK
+                           : isx2 ? ((unsigned)bi * jd.x2_nt + jd.x2_t0 + (kt - jd.n_kt1)) * TK
+                                  : ((unsigned)bi * jd.x_nt + jd.x_t0 + kt) * TK;
+        sbase[i] = (unsigned)((isz ? jd.z_off : (isx2 ? jd.x2_off : jd.x_off)) >> 10) + rel + (unsigned)u;
+        sinfo[i] = bi << 2 | (isz ? 1 : (isx2 ? 2 : 0));
+      }
+    }
+  };
+  // stage `s` of job `q` (whose tables are the decoded ones) into ring buffer `buf`
+  auto issue = [&](const HnDwCur& q, int s, int buf) __attribute__((always_inline)) {
+    char* dst = smem + (size_t)buf * BUF;
+    const int b0 = q.blk0 + s * q.bps;
+    const int nblk_s = min(q.bps, q.blk1 - b0);
+#pragma unroll
+    for (int i = 0; i < MAXSLOT; ++i) {
+      if ((sinfo[i] >> 2) < nblk_s) {
+        const unsigned kind = sinfo[i] & 3;
+        const char* src = q.stash + ((unsigned long long)(sbase[i] + (unsigned)b0 * (kind == 1 ? q.zstride : (kind == 2 ? q.x2stride : q.xstride))) << 10);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0,
+                                         HN_WGRAD_AUX);
+      }
+    }
+  };
+
+  if ((int)blockIdx.x >= total) {       // (the host never launches more workgroups than jobs)
+    hn_timeline_end(tab.timeline);
+    return;
+  }
+  HnDwCur cj, nj;                       // current job, next job
+  prepare((int)blockIdx.x, cj);         // this workgroup's first job: one per workgroup, the tickets hand out the rest
+  int rb = 0;                           // ring buffer of the current job's stage 0
+  issue(cj, 0, rb);
+  int parity = 0;
+#ifdef HN_WGRAD_JOBTIMES
+  long long* jt_buf = (long long*)tab.b[HN_MAX_WGRAD_BATCH - 1].jobs;
+  const bool jt_on = jt_buf != nullptr && tab.n < HN_MAX_WGRAD_BATCH && threadIdx.x == 0;
+  int jt_idx = (int)blockIdx.x;
+  unsigned long long jt_prev_end = wall_clock64();
+#endif
+  for (;;) {
+#ifdef HN_WGRAD_JOBTIMES
+    unsigned long long jt0 = jt_prev_end, jt1 = 0, jt2 = 0;
+#endif
+    // The job after this one is claimed LATE — one stage before its descriptor is needed (stage nstage - 3's products hide
+    // the atomic, stage nstage - 2 publishes it through LDS) —: a claim at the start of the job turned the ticket into a
+    // round-robin assignment (every workgroup holds two jobs, a third of the list is handed out blind) and the launch ran
+    // 12 % LONGER than one workgroup per job (profiles/r06_wgrad_persist_ab.log).
+    const int s_pub = max(0, cj.nstage - 2);
+    unsigned tk_raw = 0;
+    if (s_pub == 0 && threadIdx.x == 0) tk_raw = atomicAdd(ticket, 1u);
+    int nxt = total;
+    bool prepared = false;
+    f32x16 acc[4][2];
+    float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    for (int s = 0; s < cj.nstage; ++s) {
+      // stage s has landed: everything this wave issued is older than it or it (2-stage ring: nothing younger in flight)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (s == s_pub && threadIdx.x == 0) s_next[parity] = G + (int)tk_raw;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef HN_WGRAD_JOBTIMES
+      if (jt_on && s == 0) jt1 = wall_clock64();
+#endif
+      if (s == s_pub) nxt = __builtin_amdgcn_readfirstlane(s_next[parity]);
+      if (s + 1 == s_pub && threadIdx.x == 0) tk_raw = atomicAdd(ticket, 1u);
+      if (s + 1 < cj.nstage) {
+        issue(cj, s + 1, (rb + s + 1) & 1);
+      }
+      if (s + 2 >= cj.nstage && !prepared && nxt < total) {
+        // the current job's slot tables are dead — its last stage has been issued (or is the one in LDS): the next job's
+        // descriptor is read and decoded in place, one stage before it is needed where the job has two or more
+        prepare(nxt, nj);
+        prepared = true;
+      }
+      if (s + 1 >= cj.nstage && prepared) issue(nj, 0, (rb + s + 1) & 1);      // into the buffer stage s - 1 has just released
+      const char* st = smem + (size_t)((rb + s) & 1) * BUF;
+      const int nblk_s = min(cj.bps, cj.nb - s * cj.bps);
+      for (int bi = 0; bi < nblk_s; ++bi) {
+        const char* sb = st + (size_t)bi * cj.UB * 1024;
+        const unsigned a_blk = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)sb;
+        const unsigned ax = a_blk + (unsigned)((cj.n_nt + cj.k0) * TB), az = a_blk + (unsigned)(cj.n0 * TB);
+        Fr xb[2], za[4];
+        bf16x8 xv[2][2], zv[4][2];
+        if (cj.my_n > 2) hn_tr_block<4>(xv, zv, ax + tro0, ax + tro1, az + tro0, az + tro1);
+        else hn_tr_block<2>(xv, zv, ax + tro0, ax + tro1, az + tro0, az + tro1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { xb[j].v[0] = xv[j][0]; xb[j].v[1] = xv[j][1]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { za[i].v[0] = zv[i][0]; za[i].v[1] = zv[i][1]; }
+        static_for4([&](auto I) __attribute__((always_inline)) {
+          constexpr int i = decltype(I)::value;
+          if (i < cj.my_n) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (j < cj.my_k) Fr::mma(acc[i][j], za[i], xb[j]);
+            if (cj.bias_mask & (1u << i)) bsum[i] = za[i].add_point_sum(bsum[i]);
+          }
+        });
+      }
+    }
+#ifdef HN_WGRAD_JOBTIMES
+    if (jt_on) jt2 = wall_clock64();
+#endif
+    // ---- flush of the current job (hn_wgrad_kernel's: partial slabs or float atomics) ----
+    if (cj.w_off >= 0 && cj.partials != nullptr) {
+      float* P = cj.partials + (size_t)cj.p_tile * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < cj.my_n)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (j < cj.my_k) {
+              float* T = P + (size_t)((cj.n0 + i) * cj.n_kt + (cj.k0 + j)) * 1024 + lane * 4;
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+                *reinterpret_cast<f32x4*>(T + q4 * 256) = v;
+              }
+            }
+    } else if (cj.w_off >= 0) {
+      float* Gw = cj.grads + cj.w_off;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < cj.my_n)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (j < cj.my_k)
+#pragma unroll
+              for (int q = 0; q < 16; ++q) {
+                const int row = cj.r0 + 32 * (cj.n0 + i) + hn_rho(q, h);
+                const int col = cj.c0 + 32 * (cj.k0 + j) + c;
+                if (row >= 0 && col >= 0 && row < cj.r_end && col < cj.c_end) atomicAdd(Gw + (size_t)row * cj.ld + col, acc[i][j][q]);
+              }
+    }
+    if (cj.bias_mask != 0) {
+      float* Bp = cj.partials != nullptr ? cj.partials + (size_t)(cj.p_tile + cj.n_nt * cj.n_kt) * 1024 : nullptr;
+      float* gb = cj.grads + cj.b_off;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (cj.bias_mask & (1u << i)) {
+          const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+          const int row = cj.r0 + 32 * (cj.n0 + i) + c;
+          if (h == 0) {
+            if (Bp != nullptr) Bp[(cj.n0 + i) * 32 + c] = v;
+            else if (row >= 0 && row < cj.r_end) atomicAdd(gb + row, v);
+          }
+        }
+    }
+#ifdef HN_WGRAD_JOBTIMES
+    if (jt_on) {
+      unsigned hw = 0, xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      long long* o = jt_buf + (size_t)jt_idx * 8;
+      jt_prev_end = wall_clock64();
+      o[0] = (long long)hw | ((long long)(xcc & 15u) << 32);
+      o[1] = (long long)jt0; o[2] = (long long)jt1; o[3] = (long long)jt2; o[4] = (long long)jt_prev_end;
+      o[5] = (long long)cj.nb * cj.UB * 1024; o[6] = cj.n_nt * 16 + cj.n_kt; o[7] = 1;
+    }
+    jt_idx = nxt;
+#endif
+    if (!prepared) break;
+    rb = (rb + cj.nstage) & 1;
+    cj = nj;
+    parity ^= 1;
+  }
+  // the workgroup that leaves last re-arms the tickets for the next launch
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(ticket + 1, 1u) == (unsigned)G - 1) {
+      ticket[0] = 0u;
+      ticket[1] = 0u;
+    }
+  }
+  hn_timeline_end(tab.timeline);
+}
+
+#endif  // HN_WGRAD_PERSIST
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1842,6 +2126,9 @@ static void hn_allow_big_lds() {
   done[dev] = true;
   const int big = 160 * 1024;
 #define HN_BIG(k) (void)hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, big)
+#ifdef HN_WGRAD_PERSIST
+  HN_BIG(hn_wgrad_persist_kernel);
+#endif
   HN_BIG((hn_mlp_fwd_kernel<true, 2, false, true>)); HN_BIG((hn_mlp_fwd_kernel<true, 2, false, false>));
   HN_BIG((hn_mlp_fwd_kernel<true, 2, true, true>)); HN_BIG((hn_mlp_fwd_kernel<true, 2, true, false>));
   HN_BIG((hn_mlp_fwd_kernel<true, 3, false, true>)); HN_BIG((hn_mlp_fwd_kernel<true, 3, false, false>));
@@ -2386,8 +2673,36 @@ extern "C" int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches, int n_ba
   return hn_mlp_wgrad_batched_t(mode, batches, n_batches, order_dev, nullptr, stream);
 }
 
+static int hn_cu_count() {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
+static int hn_wgrad_batched_impl(int mode, const HnDwBatch* batches, int n_batches, const int32_t* order_dev,
+                                 uint64_t* timeline_dev, uint32_t* ticket_dev, hnStream_t stream);
+
 extern "C" int hn_mlp_wgrad_batched_t(int mode, const HnDwBatch* batches, int n_batches, const int32_t* order_dev,
                                       uint64_t* timeline_dev, hnStream_t stream) {
+  return hn_wgrad_batched_impl(mode, batches, n_batches, order_dev, timeline_dev, nullptr, stream);
+}
+
+#ifdef HN_WGRAD_PERSIST
+extern "C" int hn_mlp_wgrad_batched_p(int mode, const HnDwBatch* batches, int n_batches, const int32_t* order_dev,
+                                      uint64_t* timeline_dev, uint32_t* ticket_dev, hnStream_t stream) {
+  if (ticket_dev == nullptr) return -3;
+  return hn_wgrad_batched_impl(mode, batches, n_batches, order_dev, timeline_dev, ticket_dev, stream);
+}
+#endif
+
+static int hn_wgrad_batched_impl(int mode, const HnDwBatch* batches, int n_batches, const int32_t* order_dev,
+                                 uint64_t* timeline_dev, uint32_t* ticket_dev, hnStream_t stream) {
   if (hn_wgrad_stage_check(mode) != 0) return -8;
   if (n_batches < 0 || n_batches > HN_MAX_WGRAD_BATCH) return -1;
   if (n_batches > 0 && batches == nullptr) return -3;
@@ -2410,5 +2725,19 @@ extern "C" int hn_mlp_wgrad_batched_t(int mode, const HnDwBatch* batches, int n_
 #endif
   if (total == 0) return 0;
   if (total > 0x7fffffffLL) return -2;
+#ifdef HN_WGRAD_PERSIST
+  // the persistent form exists for the bf16 stash on the 2-stage ring with block reads (the product's build)
+  if (ticket_dev != nullptr && (mode & 255) == HN_MODE_BF16 && HN_WGRAD_STAGES == 2 && HN_WGRAD_BLOCK != 0 && !HN_WGRAD_BIAS_MFMA) {
+    hn_allow_big_lds();
+    const size_t lds = (size_t)2 * 8 * HN_WGRAD_MAXSLOT * 1024 + 64;
+    if (lds > 160 * 1024) return -8;
+    const int cus = hn_cu_count();
+    const int grid = total < cus ? (int)total : cus;      // one workgroup per CU (128 KiB of LDS each)
+    hipLaunchKernelGGL(hn_wgrad_persist_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, tab, ticket_dev, (int)total);
+    HN_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
+  (void)ticket_dev;
   return hn_launch_wgrad(mode, tab, (int)total, stream);
 }

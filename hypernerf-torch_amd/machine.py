@@ -1112,6 +1112,27 @@ WGRAD_SPLIT_OFFSET: Optional[int] = None
 HELD_JOB_DIV = int(os.environ.get("HN_HELD_JOB_DIV", 6))
 
 
+# EXPERIMENT builds only (-DHN_WGRAD_PERSIST=1 exports hn_mlp_wgrad_batched_p): the persistent weight-gradient launch of
+# round 6 — measured, no gain, closed (profiles/r06_wgrad_persistent.md); the product library does not carry it
+WGRAD_PERSISTENT = os.environ.get("HN_WGRAD_PERSISTENT", "0") != "0"
+_TICKETS: Dict[tuple, torch.Tensor] = {}
+
+
+def _wgrad_tickets(device) -> torch.Tensor:
+    """The persistent weight-gradient launch's job ticket + exit counter: two zeroed uint32 per (device, stream) — the
+    kernel re-arms them itself, launches that share a pair must be stream-ordered."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _TICKETS.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            key0 = next((k for k in _TICKETS if k[0] == str(device)), None)
+            if key0 is None:
+                raise L.HnError("persistent weight gradient: tickets first needed inside a stream capture (run a warm-up step)")
+            return _TICKETS[key0]      # a capture on a side stream: it replays in the order of its warm-up, one launch at a time
+        t = _TICKETS[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return t
+
+
 def resolve_pending(pending: Sequence[PendingWgrad]) -> List[ResolvedWgrad]:
     """Cut the shares of ONE launch into jobs.  The launch's bytes — the sum over the programs queued for it, first
     bucket only when the pass is split — size the jobs of big rectangles (one flush of a dW rectangle per CU);
@@ -1174,9 +1195,16 @@ def launch_resolved_wgrads(shares: Sequence[ResolvedWgrad]):
                         raise L.HnError("weight-gradient reduce tables: first use of this set of programs inside a stream "
                                         "capture (run one warm-up step of the same shapes first)")
                     red = cache[rkey] = _reduce_tables(grp, grp[0].stash.device)
-            L.launch("hn_mlp_wgrad_batched_t", C.c_int(wgrad_mode_word(mode)), arr, C.c_int(len(grp)), L.ptr(order),
-                     C.c_void_p(L.timeline_slot("hn_mlp_wgrad_batched", grp[0].stash.device)), L.stream_handle(),
-                     tag="batched")
+            if WGRAD_PERSISTENT and mode == L.HN_MODE_BF16 and hasattr(L.load(), "hn_mlp_wgrad_batched_p"):
+                # one workgroup per CU walking the job list (hn_wgrad_persist_kernel): the next job's first stage in flight
+                # under the current job's last products and flush
+                L.launch("hn_mlp_wgrad_batched_p", C.c_int(wgrad_mode_word(mode)), arr, C.c_int(len(grp)), L.ptr(order),
+                         C.c_void_p(L.timeline_slot("hn_mlp_wgrad_batched", grp[0].stash.device)),
+                         L.ptr(_wgrad_tickets(grp[0].stash.device)), L.stream_handle(), tag="batched")
+            else:
+                L.launch("hn_mlp_wgrad_batched_t", C.c_int(wgrad_mode_word(mode)), arr, C.c_int(len(grp)), L.ptr(order),
+                         C.c_void_p(L.timeline_slot("hn_mlp_wgrad_batched", grp[0].stash.device)), L.stream_handle(),
+                         tag="batched")
             embeds = [p.embed for p in grp if p.embed is not None]
             by_table: Dict[int, list] = {}
             for e in embeds:

@@ -317,6 +317,7 @@ int hn_mlp_wgrad_batched(int mode, const HnDwBatch* batches_host, int n_batches,
 int hn_mlp_wgrad_batched_t(int mode, const HnDwBatch* batches_host, int n_batches, const int32_t* order_dev,
                            uint64_t* timeline_dev, hnStream_t stream);
 
+
 /* Second half of a batched launch whose batches carry `partials` (ABI 331).  A job ends with the flush of its dW
  * rectangle; by float atomics one CU retires ~5 GB/s of them (one 256-B wave-instruction per ~50 ns), 100 us of a
  * 650-us launch at BASELINE config 2 during which the CU streams nothing.  With partials the jobs store their raw

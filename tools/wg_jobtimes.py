@@ -43,7 +43,7 @@ torch.cuda.synchronize()
 lib = L.load()
 if not hasattr(lib, "hn_set_wgrad_prof"):
     sys.exit("this library has no hn_set_wgrad_prof: build it with -DHN_WGRAD_JOBTIMES=1 and point HN_LIB_PATH at it")
-buf = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros((1 << 17) * 8, dtype=torch.int64, device="cuda")      # 8 int64 per job; config 3 cuts ~10 k jobs
 lib.hn_set_wgrad_prof(ctypes.c_void_p(buf.data_ptr()))
 acc = []
 for _ in range(reps):
