@@ -2370,53 +2370,91 @@ __global__ __launch_bounds__(256 * HN_REDUCE_SPLIT) void hn_wgrad_reduce_kernel(
     // the 256 partial sums are added by a fixed shuffle tree per wave, the four waves' sums in wave order by threads
     // 0 .. dim-1, which add the row to the gradient (one writer per element)
     __shared__ float red[4][32];
+    __shared__ int s_match[4][1024];
     const long long row = blockIdx.x;
-    float acc[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] = 0.0f;
-    // (round 6) wave w takes programs w, w + 4, ...: the programs' load chains — ray index, then the blocks' partial rows
-    // — run side by side instead of one after the other (three programs in a training step: 9 dependent memory latencies
-    // became 3; these workgroups were the tail of the launch).  Lane l takes rays l, l + 64, ... of its program, sixteen
-    // index loads in flight.  Still a fixed order: lane sums, the shuffle tree, then the waves in order.
-    {
-      const int lane_ = threadIdx.x & 63, wave_ = (threadIdx.x >> 6) & 3;
+    // (round 6) Wave w takes programs w, w + 4, ... — the programs' load chains run side by side.  Per program and 1024
+    // rays: (1) sixteen ray-index loads per lane in flight, (2) the rays that carry this row are COMPACTED into an LDS
+    // list in ray order (ballot + prefix count: deterministic), (3) the list is walked eight rays at a time, lane e
+    // loading element e = (block of the ray, column) of each ray's partial rows — eight independent loads in flight, then
+    // eight adds in list order.  The scan-and-accumulate form this replaces branched on every ray index and waited for
+    // each matching ray's loads in turn: ~20 serialized memory round trips per row and program, the tail of the launch
+    // (10 of its 35 us at config 2).  A fixed order throughout: the row's gradient stays bit-reproducible.
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    float colsum = 0.0f;          // lanes c < dim: column c of this wave's programs
+    int* mlist = s_match[wave];
 #ifdef HN_REDUCE_EXP_NOEMBED      /* timing-only experiment: the table rows do no work (their gradient is WRONG) */
-      for (int sIdx = wave_; first256 && sIdx < 0; sIdx += 4) {
+    for (int sIdx = wave; first256 && sIdx < 0; sIdx += 4) {
 #else
-      for (int sIdx = wave_; first256 && sIdx < em.n_src; sIdx += 4) {
+    for (int sIdx = wave; first256 && sIdx < em.n_src; sIdx += 4) {
 #endif
-        const float* P = em.partial[sIdx];
-        const int64_t* idx = em.idx[sIdx];
-        const int nb = em.n_blocks[sIdx], spr = em.samples_per_ray[sIdx];
-        const int bpr = spr / 32;                         // blocks per ray (this path: samples_per_ray % 32 == 0)
-        const int n_rays = nb / bpr;
-        for (int r0 = lane_; r0 < n_rays; r0 += 16 * 64) {     // 1024 rays (a config-2 batch) = ONE round of index loads
-          long long id[16];
+      const float* __restrict__ P = em.partial[sIdx];
+      const int64_t* __restrict__ idx = em.idx[sIdx];
+      const int nb = em.n_blocks[sIdx], spr = em.samples_per_ray[sIdx];
+      const int bpr = spr / 32;                         // blocks per ray (this path: samples_per_ray % 32 == 0)
+      const int n_rays = nb / bpr;
+      const int E = bpr * em.dim;                       // floats per ray: [block][column]
+      float accv = 0.0f;                                // E <= 64: lane e sums element e over the row's rays
+      float accw[32];                                   // E > 64 (spr > 256 at dim 8): per-column sums, lanes walk the blocks
 #pragma unroll
-          for (int u = 0; u < 16; ++u) id[u] = (r0 + 64 * u < n_rays) ? (long long)idx[r0 + 64 * u] : -1ll;
+      for (int c = 0; c < 32; ++c) accw[c] = 0.0f;
+      for (int r0 = 0; r0 < n_rays; r0 += 1024) {
+        long long id[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            if (id[u] != row) continue;
-            for (int k = 0; k < bpr; ++k) {
-              const size_t b = (size_t)(r0 + 64 * u) * bpr + k;
+        for (int u = 0; u < 16; ++u) {
+          const int ray = r0 + 64 * u + lane;
+          id[u] = ray < n_rays ? (long long)idx[ray] : -1ll;
+        }
+        int nm = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const bool ok = id[u] == row;
+          const unsigned long long m = __ballot(ok);
+          if (ok) mlist[nm + __popcll(m & ((1ull << lane) - 1ull))] = r0 + 64 * u + lane;
+          nm += __popcll(m);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (E <= 64) {
+          for (int i0 = 0; i0 < nm; i0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              v[j] = 0.0f;
+              if (i0 + j < nm && lane < E) v[j] = P[(size_t)mlist[i0 + j] * E + lane];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) accv += v[j];            // list order = ray order
+          }
+        } else {
+          for (int i = 0; i < nm; ++i)
+            for (int k = lane; k < bpr; k += 64) {
+              const size_t bb = (size_t)mlist[i] * bpr + k;
 #pragma unroll
               for (int c = 0; c < 32; ++c)
-                if (c < em.dim && ((em.col_mask >> c) & 1u)) acc[c] += P[b * em.dim + c];
+                if (c < em.dim) accw[c] += P[bb * em.dim + c];
             }
-          }
+        }
+        __builtin_amdgcn_wave_barrier();                          // the list is reused by the next 1024 rays
+      }
+      if (E <= 64) {
+        // column c = the sum over the ray's blocks k of lane k * dim + c, blocks in order
+        float t = 0.0f;
+        for (int k = 0; k < bpr; ++k) {
+          const float o = __shfl(accv, (k * em.dim + lane) & 63, 64);
+          if (lane < em.dim) t += o;
+        }
+        colsum += t;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+          float v = accw[c];
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+          if (lane == c) colsum += v;
         }
       }
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      if (c < em.dim && ((em.col_mask >> c) & 1u)) {
-        float v = acc[c];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-        if (lane == 0 && wave < 4) red[wave][c] = v;
-      }
-    }
+    if (first256 && lane < 32) red[wave][lane] = (lane < em.dim && ((em.col_mask >> lane) & 1u)) ? colsum : 0.0f;
     __syncthreads();
     const int c = threadIdx.x;
     if (c < em.dim && ((em.col_mask >> c) & 1u)) {

@@ -72,15 +72,66 @@ def render_image(model, rays: torch.Tensor, chunk: int = 16384, level: str = 'fi
     return result
 
 
+def write_png(path: str, img8) -> None:
+    """8-bit RGB (H, W, 3) uint8 array / tensor -> a PNG file, with the standard library only (zlib + struct): what
+    eval.py:166 does through imageio (`imageio.imwrite(f'{i:03d}.png', img_pred_)`), without an image library in the
+    package's dependencies.  Truecolour, 8 bits per channel, no interlace, filter type 0 on every scanline."""
+    import struct
+    import zlib
+    import numpy as np
+    a = np.ascontiguousarray(img8.cpu().numpy() if isinstance(img8, torch.Tensor) else img8, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("write_png: (H, W, 3) uint8")
+    h, w = a.shape[:2]
+    raw = np.concatenate([np.zeros((h, 1), dtype=np.uint8), a.reshape(h, w * 3)], axis=1).tobytes()      # filter byte 0 per row
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def read_png(path: str):
+    """The inverse of write_png for its own files (tests): (H, W, 3) uint8 numpy array."""
+    import struct
+    import zlib
+    import numpy as np
+    data = open(path, "rb").read()
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG")
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, tag = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        if struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] != (zlib.crc32(tag + body) & 0xffffffff):
+            raise ValueError("PNG chunk CRC mismatch")
+        if tag == b"IHDR":
+            w, h, depth, colour = struct.unpack(">IIBB", body[:10])
+            if (depth, colour) != (8, 2):
+                raise ValueError("read_png reads 8-bit truecolour only")
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + 3 * w)
+    if rows[:, 0].any():
+        raise ValueError("read_png reads filter type 0 only")
+    return rows[:, 1:].reshape(h, w, 3).copy()
+
+
 @torch.no_grad()
-def evaluate_images(model, images, chunk: int = 16384, white_back: bool = False, save_dir=None, group=None) -> Dict:
+def evaluate_images(model, images, chunk: int = 16384, white_back: bool = False, save_dir=None, group=None,
+                    image_format: str = "png") -> Dict:
     """The per-image loop of the reference's eval.py:145-178 on the GPU: for every sample {'rays': (H*W, 8|9),
     'rgbs': (H*W, 3) optional, 'hw': (H, W) optional} render the fine level in chunks, form the (H, W, 3) image,
     its 8-bit version (eval.py:165 `(img*255).astype(uint8)`) and, when ground truth is present, the PSNR
     (metrics.psnr, eval.py:169-172).  Returns {'images': [uint8 (H,W,3) CPU tensors], 'depths': [...],
-    'psnrs': [float], 'mean_psnr': float | None}.  With `save_dir` the 8-bit frames are also written as binary PPM
-    (no image library in the hot path; the reference writes PNG through imageio, which is IO glue out of scope).
+    'psnrs': [float], 'mean_psnr': float | None}.  With `save_dir` the 8-bit frames are also written as `{i:03d}.png`
+    (eval.py:166; `write_png`: standard library only — round 6; `image_format="ppm"` keeps the binary PPM of rounds 2-5).
+    The reference's GIF of all frames (eval.py:172, imageio.mimsave) is not written: the frames are in the result.
     `white_back` is accepted and ignored as in the reference's batched_inference (eval.py:77-85)."""
+    if image_format not in ("png", "ppm"):
+        raise ValueError("image_format: 'png' or 'ppm'")
     from .losses import psnr as _psnr
     imgs, depths, psnrs = [], [], []
     for i, sample in enumerate(images):
@@ -98,7 +149,10 @@ def evaluate_images(model, images, chunk: int = 16384, white_back: bool = False,
         if save_dir is not None:
             import os
             os.makedirs(save_dir, exist_ok=True)
-            with open(os.path.join(save_dir, f"{i:03d}.ppm"), "wb") as f:
-                f.write(f"P6 {w} {h} 255\n".encode() + img8.numpy().tobytes())
+            if image_format == "png":
+                write_png(os.path.join(save_dir, f"{i:03d}.png"), img8)
+            else:
+                with open(os.path.join(save_dir, f"{i:03d}.ppm"), "wb") as f:
+                    f.write(f"P6 {w} {h} 255\n".encode() + img8.numpy().tobytes())
     return {'images': imgs, 'depths': depths, 'psnrs': psnrs,
             'mean_psnr': (sum(psnrs) / len(psnrs)) if psnrs else None}

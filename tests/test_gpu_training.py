@@ -766,7 +766,9 @@ def test_eval_image_loop_vs_oracle_deterministic(tmp_path):
         assert_close(res["depths"][i], depth.view(h, w), 1e-4, f"image {i} depth")
         psnr_ref = float(-10 * torch.log10(((gt - rgb) ** 2).mean()))
         assert abs(res["psnrs"][i] - psnr_ref) <= 1e-3, (res["psnrs"][i], psnr_ref)
-        assert os.path.getsize(os.path.join(str(tmp_path), f"{i:03d}.ppm")) == len(f"P6 {w} {h} 255\n") + h * w * 3
+        from hypernerf_torch_amd.inference import read_png
+        back = read_png(os.path.join(str(tmp_path), f"{i:03d}.png"))           # eval.py:166 writes {i:03d}.png
+        assert back.shape == (h, w, 3) and np.array_equal(back, res["images"][i].numpy())
     assert abs(res["mean_psnr"] - sum(res["psnrs"]) / 2) < 1e-12
 
 

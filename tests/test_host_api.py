@@ -651,3 +651,19 @@ def test_adam_rest_ranges_partition_the_arena():
         else:
             assert not cov[o:o + p.numel()].any()
     assert sum(int(n) for _, n in ranges) == arena.numel - int(cov.sum())
+
+
+def test_png_writer_round_trip(tmp_path):
+    """inference.write_png (what evaluate_images saves, eval.py:166) with the standard library only: signature, IHDR, CRCs
+    and the pixels survive a round trip through read_png; sizes that are no multiple of anything."""
+    from hypernerf_torch_amd.inference import read_png, write_png
+    rs = np.random.RandomState(5)
+    for h, w in ((1, 1), (7, 13), (64, 48)):
+        img = rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        path = os.path.join(str(tmp_path), f"{h}x{w}.png")
+        write_png(path, torch.from_numpy(img))
+        raw = open(path, "rb").read()
+        assert raw[:8] == b"\x89PNG\r\n\x1a\n" and raw[12:16] == b"IHDR" and raw[-8:-4] == b"IEND"
+        assert np.array_equal(read_png(path), img)
+    with pytest.raises(ValueError):
+        write_png(os.path.join(str(tmp_path), "bad.png"), np.zeros((4, 4), dtype=np.uint8))

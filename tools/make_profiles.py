@@ -29,13 +29,18 @@ def one(pattern):
 shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats{sfx}.csv"))
 shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, f"{tag}_bench_line{sfx}.json"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+EXTRA = ["SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_ADDR_CONFLICT", "SQ_ACTIVE_INST_LDS",
+         "SQ_INST_CYCLES_VMEM_WR", "SQ_INST_CYCLES_VMEM_RD", "SQ_BUSY_CU_CYCLES", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU_MFMA_MOPS_BF16",
+         "SQ_LDS_DATA_FIFO_FULL", "SQ_LDS_CMD_FIFO_FULL", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA"]
+subs = ["pmc_fetch", "pmc_write", "pmc_sq"] + [s_ for s_ in ("pmc_lds", "pmc_vmem", "pmc_issue")
+                                               if glob.glob(os.path.join(src, f"{s_}/**/*counter_collection.csv"), recursive=True)]
+for sub in subs:
     for r in csv.DictReader(open(one(f"{sub}/**/*counter_collection.csv"))):
         k = r["Kernel_Name"]
         name = k.split("(")[0].replace("void ", "")
         agg[(name, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES",
-        "SQ_WAIT_ANY"]
+        "SQ_WAIT_ANY"] + (EXTRA if len(subs) > 3 else [])
 step_bytes, per_kernel_bytes, per_kernel_n = 0.0, collections.defaultdict(float), collections.defaultdict(float)
 with open(os.path.join(dst, f"{tag}_pmc_per_kernel{sfx}.csv"), "w") as f:
     f.write("kernel,grid,launches,FETCH_SIZE_KB,fetch_bytes_corrected,WRITE_SIZE_KB,write_bytes," + ",".join(cols[2:]) +
