@@ -704,6 +704,11 @@ def roofline(a, L, fwd_bwd, opt, progs, ref_progs, step_s, b, timeline, n_timed,
         rl = {"kernel": sym[dom] + ("<true>" if prec_key == "bf16" else "<false>"),
               "avg_launch_ms": ms_step / launches, "launches_per_step": launches,
               "times_from": "kernel timeline inside the timed graph replays" if timeline else "eager pass, HIP events",
+              "timeline_active_in_timed_region": bool(timeline),
+              "timeline_note": "the three machine kernels stamp the 100 MHz wall clock at entry and — behind a workgroup "
+                               "barrier — at exit: two device-scope atomics per workgroup, INSIDE the timed region that "
+                               "produces `value` (bench.py --no-roofline times the step without them; the independent check "
+                               "is profiles/rNN_graph_trace_configC.txt, a rocprofv3 kernel trace of the same replay)",
               "mfma": {"achieved": pk["achieved"], "peak": pk["peak"], "unit": "TFLOP/s", "frac": pk["frac"],
                        "executed_flops_per_launch": flops_pass / launches},
               "traffic": None,
