@@ -480,3 +480,68 @@ def test_composite_two_parts_equals_one_part(nc, nf):
     d_raw = torch.zeros(b, s).scatter_(1, perm, raw1_.grad.cpu())
     assert torch.equal(torch.cat([parts[0].grad, parts[2].grad], 1).cpu(), d_rgb), "d rgb"
     assert torch.equal(torch.cat([parts[1].grad, parts[3].grad], 1).cpu(), d_raw), "d raw"
+
+
+def test_sample_pdf_merge_falls_back_for_unsorted_or_non_finite_depths():
+    """Round 6: the sampler merges by RANK when the level's own depths arrive sorted and every value is a number, and
+    keeps the (depth, position) bitonic sort for anything else.  Both must give `sort(cat(z, z_samples))` with equal
+    depths in cat order: sorted input (rank path) and the same rays with two depths swapped (sort path) against
+    torch.sort(stable=True), indices and samples bit-identical between the two (they do not depend on the merge); rays
+    whose weights are NaN run through without a fault."""
+    b, nc, nf = 37, 64, 96
+    o, d, _ = rays_for(21, b)
+    z, _ = torch.sort(H.uniform(21, "z", (b, nc), 0, 1), dim=-1)
+    z[3, 10] = z[3, 11]                                   # a tie among the level's own depths
+    w = H.uniform(21, "w", (b, nc), 0, 1) ** 3
+    u = H.uniform(21, "u", (b, nf), 0, 1)
+    u[5, 7] = u[5, 3]                                     # two equal new samples
+    zu = z.clone()
+    zu[:, [20, 40]] = zu[:, [40, 20]]                     # no longer sorted: the bitonic path
+    for zin, name in ((z, "sorted input (rank merge)"), (zu, "unsorted input (bitonic sort)")):
+        z_all, pts, inds, zs, perm, pts_new = F.sample_pdf(w.to(DEV), zin.to(DEV), u.to(DEV), o.to(DEV), d.to(DEV), split=True)
+        cat = torch.cat([zin, zs.cpu()], dim=1)
+        ref, ref_perm = torch.sort(cat, dim=1, stable=True)
+        assert torch.equal(z_all.cpu(), ref), name + ": merged depths"
+        assert torch.equal(perm.cpu().long(), ref_perm), name + ": merge permutation (equal depths in cat order)"
+        assert torch.equal(pts.cpu(), o[:, None, :] + ref[..., None] * d[:, None, :]), name + ": points"
+        z_all2, _, inds2, zs2 = F.sample_pdf(w.to(DEV), zin.to(DEV), u.to(DEV), o.to(DEV), d.to(DEV))
+        assert torch.equal(z_all2, z_all) and torch.equal(inds2, inds) and torch.equal(zs2, zs), name + ": with / without payload"
+    wn = w.clone()
+    wn[2] = float("nan")
+    out = F.sample_pdf(wn.to(DEV), z.to(DEV), u.to(DEV), o.to(DEV), d.to(DEV), split=True)
+    torch.cuda.synchronize()
+    ok = torch.ones(b, dtype=torch.bool)
+    ok[2] = False
+    ref = torch.sort(torch.cat([z, out[3].cpu()], dim=1), dim=1, stable=True)[0]
+    assert torch.equal(out[0].cpu()[ok], ref[ok]), "the rays beside a NaN ray are untouched"
+
+
+def test_composite_then_pdf_equals_the_two_launches():
+    """hn_composite_sample_pdf (round 6: the coarse level's compositing and the fine level's inverse-CDF sampling as one
+    launch, the weights handed over in LDS) against hn_composite_forward followed by hn_sample_pdf_split: every output of
+    both, bit for bit, with and without the split outputs, and the compositing gradients."""
+    for b, nc, nf, split in ((29, 64, 64, True), (5, 33, 70, False), (64, 128, 200, True)):
+        o, d, _ = rays_for(23, b)
+        rgb = H.uniform(23, "rgb", (b, nc, 3), 0, 1)
+        raw = H.uniform(23, "raw", (b, nc), -3, 6)
+        noise = H.normal(23, "noise", (b, nc))
+        warped = H.uniform(23, "wp", (b, nc, 7), -1, 1)
+        z, _ = torch.sort(H.uniform(23, "z", (b, nc), 0, 1), dim=-1)
+        u = H.uniform(23, "u", (b, nf), 0, 1)
+        args = lambda: (rgb.to(DEV).requires_grad_(True), raw.to(DEV).requires_grad_(True))
+        r1, a1 = args()
+        sep = F.composite(r1, a1, noise.to(DEV), z.to(DEV), d.to(DEV), warped.to(DEV), noise_scale=0.5)
+        pdf = F.sample_pdf(sep[3], z.to(DEV), u.to(DEV), o.to(DEV), d.to(DEV), split=split)
+        r2, a2 = args()
+        fused = F.composite(r2, a2, noise.to(DEV), z.to(DEV), d.to(DEV), warped.to(DEV), noise_scale=0.5,
+                            then_pdf=dict(u=u.to(DEV), origins=o.to(DEV), directions=d.to(DEV), split=split))
+        n_pdf = 6 if split else 4
+        assert len(fused) == len(sep) + n_pdf
+        for i, (x, y) in enumerate(zip(sep, fused[:len(sep)])):
+            assert torch.equal(x, y), f"compositing output {i}"
+        for i, (x, y) in enumerate(zip(pdf, fused[len(sep):])):
+            assert torch.equal(x, y), f"sampler output {i} ({b} x {nc} + {nf}, split {split})"
+        g = H.uniform(23, "g", (b, 3), -1, 1).to(DEV)
+        (sep[0] * g).sum().backward()
+        (fused[0] * g).sum().backward()
+        assert torch.equal(r1.grad, r2.grad) and torch.equal(a1.grad, a2.grad)

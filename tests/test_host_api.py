@@ -667,3 +667,30 @@ def test_png_writer_round_trip(tmp_path):
         assert np.array_equal(read_png(path), img)
     with pytest.raises(ValueError):
         write_png(os.path.join(str(tmp_path), "bad.png"), np.zeros((4, 4), dtype=np.uint8))
+
+
+def test_ray_metadata_is_a_dict_that_converts_on_first_use():
+    """model_utils.RayMetadata (round 6): what prepare_ray_dict hands out for fp32 ray rows on the GPU — the reference's
+    four metadata keys over ONE int64 tensor (model_utils.py:389-398), converted on first access unless the model's step
+    head has done it in its own launch.  Dict semantics a caller may rely on: item access, get with default, items /
+    values, iteration, copy, rebuilding from pairs (DDP's input scatter); CPU rows keep the plain dict."""
+    from hypernerf_torch_amd.hypernerf.model_utils import RayMetadata, prepare_ray_dict, extract_rays_batch
+    col = torch.tensor([3.0, 7.9, 0.0, 99.0])
+    md = RayMetadata(col)
+    assert not md.converted() and set(md) == {"warp", "camera", "appearance", "time"} and len(md) == 4
+    assert md.get("hyper_point") is None and md.get("hyper_point", 5) == 5 and "hyper_point" not in md
+    idx = md["time"]
+    assert md.converted() and idx.dtype == torch.int64 and idx.tolist() == [3, 7, 0, 99]       # truncation, as .type(torch.long)
+    assert md["warp"] is idx and all(v is idx for v in md.values()) and dict(md.items())["camera"] is idx
+    md2 = RayMetadata(col)
+    buf = torch.tensor([1, 2, 3, 4])
+    md2.set_converted(buf)                                  # what NerfModel.forward does before its step-head launch
+    assert md2.converted() and md2["appearance"] is buf
+    md3 = RayMetadata(list(md.items()))                    # rebuilt from pairs: a plain, converted dict
+    assert md3.converted() and md3["warp"] is idx
+    assert md.copy() == dict(md.items()) and type(md.copy()) is dict
+    rays = torch.cat([torch.zeros(4, 8), col[:, None]], dim=1)
+    rd = prepare_ray_dict(rays)                             # CPU rows: converted eagerly, plain dict (the reference's behaviour)
+    assert type(rd["metadata"]) is dict and rd["metadata"]["warp"].tolist() == [3, 7, 0, 99]
+    sub = extract_rays_batch({"origins": rays[:, :3], "directions": rays[:, 3:6], "viewdirs": None, "metadata": RayMetadata(col)}, 1, 3)
+    assert sub["metadata"]["camera"].tolist() == [7, 0]
