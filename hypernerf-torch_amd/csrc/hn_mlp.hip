@@ -2326,7 +2326,7 @@ struct HnAdamFuseDev {
   int n_rest, zero_grad;
 };
 #ifndef HN_REDUCE_SPLIT
-#define HN_REDUCE_SPLIT 1      /* parts a destination tile's slab list is summed in (workgroup = SPLIT x 256 threads) */
+#define HN_REDUCE_SPLIT 2      /* parts a destination tile's slab list is summed in (workgroup = SPLIT x 256 threads): 1 / 2 / 4 = 24.1 / 21.7 / 26.5 us per launch at config 2 (profiles/r06_reduce_variants.log) */
 #endif
 #ifndef HN_REDUCE_INFLIGHT
 #define HN_REDUCE_INFLIGHT 8   /* slab loads a thread keeps in flight */

@@ -42,7 +42,50 @@ struct HnPackTable {
   int first_block[HN_MAX_PACK_JOBS + 1];
   int n;
 };
-// block `blk` (0 .. first_block[n]) of a multi-program pack: 4 waves, one 1-KiB unit (or bias record) each
+// Two units per wave, their load chains side by side (round 6): a unit is three dependent loads deep — descriptor, source
+// pointer, the 8 weights of the lane — and the ~10,000 waves of a step's pack fill the chip only once, so the launch is
+// one chain long; with two units per wave the chains overlap and the grid halves.  Every load is made unconditionally
+// from a clamped address and the out-of-range value replaced afterwards (no branch between the loads).
+template <bool BF16>
+HN_DEV void hn_pack_pair(const HnPackUnit* __restrict__ units, int n_units, const float* const* __restrict__ ptrs,
+                         char* __restrict__ out, int u0) {
+  const int lane = threadIdx.x & 63;
+  const int row = lane & 31, h = lane >> 5;
+  constexpr int NE = BF16 ? 8 : 4;
+  HnPackUnit u[2];
+  const float* W[2];
+  float v[2][NE];
+  bool ok[2][NE];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) u[q] = units[min(u0 + q, n_units - 1)];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) W[q] = u[q].w_id >= 0 ? ptrs[u[q].w_id] : nullptr;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int k = BF16 ? u[q].k0 + hn_pi16(h, e) : hn_rho(u[q].k0 + e, h);
+      int sr, sc;
+      if (u[q].transposed) { sr = u[q].r0 + k; sc = u[q].c0 + row; }
+      else { sr = u[q].r0 + row; sc = u[q].c0 + k; }
+      ok[q][e] = W[q] != nullptr && sr >= 0 && sc >= 0 && sr < u[q].r_end && sc < u[q].c_end;
+      v[q][e] = ok[q][e] ? W[q][(size_t)sr * u[q].ld + sc] : 0.0f;
+    }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (u0 + q >= n_units) continue;
+    char* dst = out + (size_t)(u0 + q) * 1024 + lane * 16;
+    if constexpr (BF16) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[q][e];
+      *reinterpret_cast<bf16x8*>(dst) = o;
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[q][0], v[q][1], v[q][2], v[q][3]};
+    }
+  }
+}
+// block `blk` (0 .. first_block[n]) of a multi-program pack: 4 waves, two 1-KiB units (or one bias record) each
 template <bool BF16>
 HN_DEV void hn_pack_block(const HnPackTable& tab, int blk) {
   int k = 0;
@@ -50,8 +93,10 @@ HN_DEV void hn_pack_block(const HnPackTable& tab, int blk) {
   for (int i = 1; i < HN_MAX_PACK_JOBS; ++i)
     if (i < tab.n && blk >= tab.first_block[i]) k = i;
   const HnPackJob jb = tab.j[k];
-  const int wid = (blk - tab.first_block[k]) * 4 + ((threadIdx.x >> 6) & 3);
-  hn_pack_one<BF16>(jb.units, jb.n_units, jb.ptrs, (char*)jb.wstream, jb.bias, jb.n_bias, jb.bias_out, wid);
+  const int wv = (blk - tab.first_block[k]) * 4 + ((threadIdx.x >> 6) & 3);
+  const int unit_waves = (jb.n_units + 1) / 2;
+  if (wv < unit_waves) hn_pack_pair<BF16>(jb.units, jb.n_units, jb.ptrs, (char*)jb.wstream, 2 * wv);
+  else hn_pack_one<BF16>(jb.units, 0, jb.ptrs, (char*)jb.wstream, jb.bias, jb.n_bias, jb.bias_out, wv - unit_waves);
 }
 // host: argument checks + block ranges of the jobs (256-thread blocks); returns 0 or a negative status
 static inline int hn_pack_table_fill(const HnPackJob* jobs, int n_jobs, HnPackTable& tab, int& blocks) {
@@ -66,7 +111,7 @@ static inline int hn_pack_table_fill(const HnPackJob* jobs, int n_jobs, HnPackTa
     if (jobs[i].n_bias > 0 && (jobs[i].bias == nullptr || jobs[i].bias_out == nullptr || jobs[i].ptrs == nullptr)) return -3;
     tab.j[i] = jobs[i];
     tab.first_block[i] = blocks;
-    blocks += (jobs[i].n_units + jobs[i].n_bias + 3) / 4;
+    blocks += ((jobs[i].n_units + 1) / 2 + jobs[i].n_bias + 3) / 4;      // two units or one bias record per wave
   }
   tab.first_block[n_jobs] = blocks;
   tab.n = n_jobs;

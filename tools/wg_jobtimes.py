@@ -74,7 +74,18 @@ for _ in range(reps):
                     head=head / tot, tail=tail / tot, compute=(busy - ramp - flush) / tot,
                     ramp_us_per_job=ramp / len(r) / 100.0, flush_us_per_job=flush / len(r) / 100.0,
                     turnover_us_per_gap=gap / max(1, len(r) - len(cus)) / 100.0, GB=float(r[:, 5].sum()) / 1e9))
+# per rectangle shape (dZ tiles x X tiles of the job's wave grid): how fast its jobs stream — the weights a time-based
+# job order would use (last launch)
+shapes = {}
+for sh in np.unique(r[:, 6]):
+    sel = r[:, 6] == sh
+    dur = (t3 - t0)[sel].astype(np.float64) / 100.0
+    mb = r[sel, 5].astype(np.float64) / 1e6
+    shapes[f"{int(sh) >> 4}x{int(sh) & 15}"] = dict(jobs=int(sel.sum()), mean_mb=float(mb.mean()), mean_us=float(dur.mean()),
+                                                  gb_per_s=float((mb.sum() / 1e3) / (dur.sum() / 1e6)),
+                                                  start_us_mean=float(((t0[sel] - start) / 100.0).mean()))
 med = {k: float(np.median([a[k] for a in acc])) for k in acc[0]}
+med["per_shape_last_launch"] = shapes
 med["recoverable_by_a_persistent_form"] = med["ramp"] + med["flush"] + med["turnover"]
 med["config"], med["launches"], med["build"] = cfg, reps, L.build_id()
 print(json.dumps(med))
@@ -84,4 +95,7 @@ print(f"# share of span x CUs:  streaming + products {med['compute']:.3f} | ramp
       f"({med['ramp_us_per_job']:.1f} us per job) | flush {med['flush']:.3f} ({med['flush_us_per_job']:.1f} us per job) | "
       f"workgroup turnover on a CU {med['turnover']:.3f} ({med['turnover_us_per_gap']:.1f} us per gap) | "
       f"before a CU's first job {med['head']:.3f} | idle tail behind its last job {med['tail']:.3f}")
+for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["jobs"] * kv[1]["mean_mb"]):
+    print(f"#   shape {k:>5}: {v['jobs']:4d} jobs, {v['mean_mb']:6.2f} MB and {v['mean_us']:6.1f} us each = {v['gb_per_s']:5.1f} GB/s per CU, "
+          f"mean start {v['start_us_mean']:6.1f} us")
 print(f"# ceiling of a persistent form (ramp + flush + turnover hidden completely): {med['recoverable_by_a_persistent_form']:.3f} of the launch")
