@@ -6,29 +6,42 @@
 #include "hn_pack.h"
 
 // ------------------------------------------------------------------------------------------------
-// wave64 scans
+// wave64 scans — on the DPP cross-lane paths of CDNA (round 6; rounds 1-5 went through `__shfl_up` = `ds_bpermute_b32`, an
+// LDS-pipe round trip per step): an inclusive scan is Kogge-Stone inside each row of 16 lanes (row_shr:1, 2, 4, 8; a lane
+// without a source keeps the identity), then lane 15 of rows 0 / 2 joins rows 1 / 3 (row_bcast:15, row mask 0xa) and lane
+// 31 rows 2-3 (row_bcast:31, row mask 0xc): six `v_mov_b32_dpp` + six ALU ops, no LDS traffic, no wait.
 // ------------------------------------------------------------------------------------------------
-HN_DEV float hn_wave_incl_scan_mul(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (lane >= d) v *= o;
-  }
+template <int CTRL, int ROW_MASK>
+HN_DEV float hn_dpp(float old, float src) {      // lanes whose source lane does not exist (or whose row is masked) return `old`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                               CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int HN_DPP_ROW_SHR = 0x110, HN_DPP_WAVE_SHR1 = 0x138, HN_DPP_BCAST15 = 0x142, HN_DPP_BCAST31 = 0x143;
+HN_DEV float hn_wave_incl_scan_mul(float v, int) {
+  v *= hn_dpp<HN_DPP_ROW_SHR + 1, 0xf>(1.0f, v);
+  v *= hn_dpp<HN_DPP_ROW_SHR + 2, 0xf>(1.0f, v);
+  v *= hn_dpp<HN_DPP_ROW_SHR + 4, 0xf>(1.0f, v);
+  v *= hn_dpp<HN_DPP_ROW_SHR + 8, 0xf>(1.0f, v);
+  v *= hn_dpp<HN_DPP_BCAST15, 0xa>(1.0f, v);
+  v *= hn_dpp<HN_DPP_BCAST31, 0xc>(1.0f, v);
   return v;
 }
-HN_DEV float hn_wave_incl_scan_add(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
+HN_DEV float hn_wave_incl_scan_add(float v, int) {
+  v += hn_dpp<HN_DPP_ROW_SHR + 1, 0xf>(0.0f, v);
+  v += hn_dpp<HN_DPP_ROW_SHR + 2, 0xf>(0.0f, v);
+  v += hn_dpp<HN_DPP_ROW_SHR + 4, 0xf>(0.0f, v);
+  v += hn_dpp<HN_DPP_ROW_SHR + 8, 0xf>(0.0f, v);
+  v += hn_dpp<HN_DPP_BCAST15, 0xa>(0.0f, v);
+  v += hn_dpp<HN_DPP_BCAST31, 0xc>(0.0f, v);
   return v;
 }
-HN_DEV float hn_wave_sum(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+// the value of the lane below (identity in lane 0): wave_shr:1
+HN_DEV float hn_wave_shr1(float v, float identity) { return hn_dpp<HN_DPP_WAVE_SHR1, 0xf>(identity, v); }
+// one lane's value in every lane (`lane_idx` wave-uniform): v_readlane_b32, a scalar-register broadcast
+HN_DEV float hn_wave_bcast(float v, int lane_idx) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_idx));
 }
+HN_DEV float hn_wave_sum(float v) { return hn_wave_bcast(hn_wave_incl_scan_add(v, 0), 63); }
 
 // ------------------------------------------------------------------------------------------------
 // sampling along rays
@@ -246,10 +259,9 @@ HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float*
       const float o = in ? (1.0f - al + eps) : 1.0f;
       // exclusive product scan: T_s = prod_{j<s} om_j
       const float inc = hn_wave_incl_scan_mul(o, lane);
-      float ex = __shfl_up(inc, 1, 64);
-      if (lane == 0) ex = 1.0f;
+      const float ex = hn_wave_shr1(inc, 1.0f);
       const float T = carry * ex;
-      carry *= __shfl(inc, 63, 64);
+      carry *= hn_wave_bcast(inc, 63);
       const float w = al * T;
       alpha[k] = al; om[k] = o; trans[k] = T; wgt[k] = w; pre[k] = raw; dist[k] = dd * kfac;   // d sigma' = kfac d sigma
       if (!BACKWARD) {
@@ -269,7 +281,7 @@ HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float*
           const unsigned long long m = __ballot(in && cs >= 0.5f);
           if (!med_found && m != 0ull) {
             const int first = __ffsll((long long)m) - 1;
-            med_z = __shfl(zz, first, 64);
+            med_z = hn_wave_bcast(zz, first);
             const int sidx = k * 64 + first;
             if (a.warped != nullptr) {
               const HnPartRow mp = hn_part_row(a, ray, row, sidx, perm_lds);
@@ -277,7 +289,7 @@ HN_DEV void hn_composite_ray(const HnCompositeArgs& a, int ray, int lane, float*
             }
             med_found = true;
           }
-          csum = __shfl(cs, 63, 64);
+          csum = hn_wave_bcast(cs, 63);
         }
       }
     }
@@ -455,7 +467,7 @@ __global__ __launch_bounds__(256) void hn_depth_index_kernel(const float* __rest
     const float cs = csum + hn_wave_incl_scan_add(in ? w[row + s] : 0.0f, lane);
     const unsigned long long m = __ballot(in && cs >= thr);
     if (found < 0 && m != 0ull) found = k * 64 + __ffsll((long long)m) - 1;
-    csum = __shfl(cs, 63, 64);
+    csum = hn_wave_bcast(cs, 63);
   }
   if (out_mask != nullptr)
     for (int s = lane; s < S; s += 64) out_mask[row + s] = s == found ? 1.0f : 0.0f;

@@ -3,7 +3,7 @@ batches and draws: held-out PSNR of both final parameter sets (same fp32 evaluat
 and its standard error.  The CPU runs go to spawned worker processes (they never touch the GPU).  Lives under tests/
 because it executes the oracle as the checker (only tests/, smoke() and bench.py's cpu_baseline leg may).
 
-    python tests/psnr_vs_oracle.py [steps=300] [rays=64] [nc=16] [nf=16] [seeds=8] [lr=1e-3] [modes=bf16,fp32] [lr_end=0] [freq=1]
+    python tests/psnr_vs_oracle.py [steps=300] [rays=64] [nc=16] [nf=16] [seeds=8] [lr=1e-3] [modes=bf16,fp32] [lr_end=0] [freq=1] [first_seed=0]
 Prints one JSON line."""
 import json
 import math
@@ -28,6 +28,7 @@ def main():
     modes = (a[6] if len(a) > 6 else "bf16,fp32").split(",")
     lr_end = float(a[7]) if len(a) > 7 and float(a[7]) > 0 else None
     freq = float(a[8]) if len(a) > 8 else 1.0
+    seed0 = int(a[9]) if len(a) > 9 else 0      # seeds first_seed .. first_seed + seeds - 1 (a second, independent sample)
     noise = 0.5
     cores = OT.usable_cores()
     # the oracle's small-batch steps are op-overhead bound (0.09 s per step at 8 threads, 0.12 at 2): few threads per run,
@@ -38,15 +39,15 @@ def main():
     t0 = time.perf_counter()
     ctx = mp.get_context("spawn")
     pool = ctx.Pool(procs)
-    fut = pool.map_async(OT.cpu_run, [(s, steps, b, nc, nf, lr, noise, threads, lr_end, freq) for s in range(n_seeds)])
+    fut = pool.map_async(OT.cpu_run, [(s, steps, b, nc, nf, lr, noise, threads, lr_end, freq) for s in range(seed0, seed0 + n_seeds)])
     gpu = {}
     for mode in modes:
-        gpu[mode] = [OT.gpu_run(s, steps, b, nc, nf, lr, noise, mode, lr_end=lr_end, freq=freq) for s in range(n_seeds)]
+        gpu[mode] = [OT.gpu_run(s, steps, b, nc, nf, lr, noise, mode, lr_end=lr_end, freq=freq) for s in range(seed0, seed0 + n_seeds)]
     t_gpu = time.perf_counter() - t0
     cpu = sorted(fut.get(timeout=3600))
     pool.close()
     wall = time.perf_counter() - t0
-    res = {"config": f"{steps} steps x {b} rays x ({nc}+{nf}) samples, Adam lr {lr} -> {lr_end}, scene freq {freq}, noise_std {noise}, {n_seeds} seeds",
+    res = {"config": f"{steps} steps x {b} rays x ({nc}+{nf}) samples, Adam lr {lr} -> {lr_end}, scene freq {freq}, noise_std {noise}, {n_seeds} seeds from {seed0}",
            "cpu_oracle_psnr_db": [round(c[1], 3) for c in cpu], "cpu_first_last_loss": [(round(c[2][0], 4), round(c[2][-1], 4)) for c in cpu],
            "wall_s": round(wall, 1), "gpu_part_s": round(t_gpu, 1), "cpu_procs": procs, "threads_per_proc": threads}
     ref = [c[1] for c in cpu]
